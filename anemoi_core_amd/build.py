@@ -1,0 +1,69 @@
+"""Build libanemoi_hip.so (gfx950 only) in-tree with hipcc.
+
+``python -m anemoi_core_amd.build`` or ``__graft_entry__.build()``.  hipcc cross-compiles without a GPU.
+The .so is git-ignored (history stays source-only) but travels to the GPU box with the repo snapshot.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIBDIR = os.path.join(PKG, "lib")
+LIBPATH = os.path.join(LIBDIR, "libanemoi_hip.so")
+INCLUDE = os.path.join(REPO, "include")
+
+SOURCES = ["lib.cpp", "gt_attention.hip", "rowwise.hip", "linear.hip"]
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm >= 7.0)")
+
+
+def _newer(target: str, deps: list[str]) -> bool:
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(d) <= t for d in deps)
+
+
+def build_library(force: bool = False, verbose: bool = True, extra_flags: tuple[str, ...] = ()) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    hipcc = _hipcc()
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "anemoi_hip.h")]
+    flags = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I", INCLUDE, "-I", CSRC, "-Wall", "-Wno-unused-function", *extra_flags]
+
+    def compile_one(src: str) -> str:
+        path = os.path.join(CSRC, src)
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        if not force and _newer(obj, [path, *headers]):
+            return obj
+        cmd = [hipcc, *flags, "-x", "hip", "-c", path, "-o", obj]
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    if force or not _newer(LIBPATH, objs):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIBPATH, *objs]
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return LIBPATH
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv))

@@ -1,0 +1,108 @@
+// Shared device/host helpers for libanemoi_hip.so (gfx950 / CDNA4 only: wave64, MFMA, DPP).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "anemoi_hip.h"
+
+namespace anemoi {
+
+// ---------------------------------------------------------------------------------------------- errors
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define ANEMOI_REQUIRE(cond, ...)             \
+  do {                                        \
+    if (!(cond)) {                            \
+      ::anemoi::set_error(__VA_ARGS__);       \
+      return ANEMOI_E_INVALID;                \
+    }                                         \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------- dtypes
+struct bf16_t {
+  uint16_t x;
+};
+struct f16_t {
+  _Float16 x;
+};
+
+__device__ __forceinline__ float to_float(float v) { return v; }
+__device__ __forceinline__ float to_float(bf16_t v) { return __uint_as_float(((uint32_t)v.x) << 16); }
+__device__ __forceinline__ float to_float(f16_t v) { return (float)v.x; }
+
+template <typename T>
+__device__ __forceinline__ T from_float(float v);
+template <>
+__device__ __forceinline__ float from_float<float>(float v) {
+  return v;
+}
+template <>
+__device__ __forceinline__ bf16_t from_float<bf16_t>(float v) {
+  // round-to-nearest-even, NaN preserved (same rule as torch's float -> bfloat16)
+  uint32_t u = __float_as_uint(v);
+  bf16_t r;
+  if ((u & 0x7fffffffu) > 0x7f800000u) {
+    r.x = (uint16_t)((u >> 16) | 0x40);
+  } else {
+    u += 0x7fffu + ((u >> 16) & 1u);
+    r.x = (uint16_t)(u >> 16);
+  }
+  return r;
+}
+template <>
+__device__ __forceinline__ f16_t from_float<f16_t>(float v) {
+  f16_t r;
+  r.x = (_Float16)v;
+  return r;
+}
+
+// Vector of N elements of T moved with the widest possible instructions (N*sizeof(T) in {2,4,8,16,32,64}).
+template <typename T, int N>
+struct alignas(sizeof(T) * N >= 16 ? 16 : sizeof(T) * N) Vec {
+  T v[N];
+};
+
+template <typename T, int N>
+__device__ __forceinline__ void load_vec(const T* __restrict__ p, float (&out)[N]) {
+  Vec<T, N> tmp = *reinterpret_cast<const Vec<T, N>*>(p);
+#pragma unroll
+  for (int i = 0; i < N; ++i) out[i] = to_float(tmp.v[i]);
+}
+
+template <typename T, int N>
+__device__ __forceinline__ void store_vec(T* __restrict__ p, const float (&in)[N]) {
+  Vec<T, N> tmp;
+#pragma unroll
+  for (int i = 0; i < N; ++i) tmp.v[i] = from_float<T>(in[i]);
+  *reinterpret_cast<Vec<T, N>*>(p) = tmp;
+}
+
+// ---------------------------------------------------------------------------------------------- cross-lane
+// Butterfly all-reduce (sum) over aligned groups of G lanes (G power of two, <= 64) of a wave64.
+// G <= 16 stays inside a DPP row: quad_perm for xor 1/2, row_half_mirror / row_mirror for xor 4/8
+// (valid because the lanes being mirrored already hold group-uniform partial sums).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+
+template <int G>
+__device__ __forceinline__ float group_sum(float x) {
+  if constexpr (G >= 2) x += dpp_f<0xB1>(x);   // quad_perm [1,0,3,2]
+  if constexpr (G >= 4) x += dpp_f<0x4E>(x);   // quad_perm [2,3,0,1]
+  if constexpr (G >= 8) x += dpp_f<0x141>(x);  // row_half_mirror
+  if constexpr (G >= 16) x += dpp_f<0x140>(x); // row_mirror
+  if constexpr (G >= 32) x += __shfl_xor(x, 16, 64);
+  if constexpr (G >= 64) x += __shfl_xor(x, 32, 64);
+  return x;
+}
+
+__device__ __forceinline__ float wave_sum(float x) { return group_sum<64>(x); }
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+}  // namespace anemoi

@@ -1,0 +1,272 @@
+// Row-wise HBM-bound kernels: LayerNorm, GraphConv edge epilogue (LayerNorm + residual + dst segment sum),
+// row gather.  One 64-lane wavefront per row; a lane owns VEC contiguous elements per 64*VEC chunk, so every
+// global access is a full-width coalesced vector load/store (16 B per lane for bf16 at VEC=8).
+//
+// Reference semantics: torch.nn.LayerNorm (eps inside sqrt, biased variance, affine) as instantiated by
+// layer_kernels.LayerNorm (models/src/anemoi/models/layers/utils.py:107-121); GraphConv's
+// "edge_mlp(...) + edge_attr" followed by scatter-sum (models/src/anemoi/models/layers/conv.py:73-81).
+#include "common.h"
+
+namespace anemoi {
+
+constexpr int kRowWaves = 4;   // waves (rows) per block
+constexpr int kMaxChunksLimit = 8;  // register-resident chunks per lane (template CH): D <= 64*VEC*CH
+
+// Load a row into registers as float: x[lane*VEC + t*64*VEC + j], t < nchunks.
+template <typename T, int VEC, int CH>
+__device__ __forceinline__ void load_row(const T* __restrict__ p, int D, int lane, float (&r)[CH][VEC]) {
+#pragma unroll
+  for (int t = 0; t < CH; ++t) {
+    const int c = (t * 64 + lane) * VEC;
+    if (c < D) {
+      load_vec<T, VEC>(p + c, r[t]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) r[t][j] = 0.f;
+    }
+  }
+}
+
+// In-register LayerNorm of one row held across the wave: two-pass (mean, then centred variance).
+template <typename T, int VEC, int CH>
+__device__ __forceinline__ void normalise_row(float (&r)[CH][VEC], int D, int lane, const T* __restrict__ gamma,
+                                              const T* __restrict__ beta, float eps) {
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < CH; ++t)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s += r[t][j];
+  const float mean = wave_sum(s) / (float)D;
+  float ss = 0.f;
+#pragma unroll
+  for (int t = 0; t < CH; ++t) {
+    const int c = (t * 64 + lane) * VEC;
+    if (c < D) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float dlt = r[t][j] - mean;
+        ss = fmaf(dlt, dlt, ss);
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)D + eps);
+#pragma unroll
+  for (int t = 0; t < CH; ++t) {
+    const int c = (t * 64 + lane) * VEC;
+    if (c < D) {
+      float g[VEC], b[VEC];
+      load_vec<T, VEC>(gamma + c, g);
+      if (beta != nullptr) {
+        load_vec<T, VEC>(beta + c, b);
+      } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) b[j] = 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) r[t][j] = fmaf((r[t][j] - mean) * rstd, g[j], b[j]);
+    }
+  }
+}
+
+template <typename T, int VEC, int CH>
+__device__ __forceinline__ void store_row(T* __restrict__ p, int D, int lane, const float (&r)[CH][VEC]) {
+#pragma unroll
+  for (int t = 0; t < CH; ++t) {
+    const int c = (t * 64 + lane) * VEC;
+    if (c < D) store_vec<T, VEC>(p + c, r[t]);
+  }
+}
+
+template <typename T, int VEC, int CH>
+__global__ __launch_bounds__(64 * kRowWaves) void layernorm_fwd_kernel(const T* __restrict__ x, int64_t ldx,
+                                                                       const T* __restrict__ gamma,
+                                                                       const T* __restrict__ beta, T* __restrict__ y,
+                                                                       int64_t ldy, int n_rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int rowi = blockIdx.x * kRowWaves + (threadIdx.x >> 6);
+  if (rowi >= n_rows) return;
+  float r[CH][VEC];
+  load_row<T, VEC, CH>(x + (int64_t)rowi * ldx, D, lane, r);
+  normalise_row<T, VEC, CH>(r, D, lane, gamma, beta, eps);
+  store_row<T, VEC, CH>(y + (int64_t)rowi * ldy, D, lane, r);
+}
+
+// e_new = LN(z) + e_old (LN optional) ; agg[d] = sum over the in-edges of d (dst-sorted => contiguous rows).
+template <typename T, int VEC, int CH>
+__global__ __launch_bounds__(64 * kRowWaves) void edge_ln_res_segsum_kernel(
+    const T* __restrict__ z, int64_t ldz, const T* __restrict__ e_old, int64_t lde, const T* __restrict__ gamma,
+    const T* __restrict__ beta, float eps, const int32_t* __restrict__ colptr, T* __restrict__ e_new, int64_t ldn,
+    T* __restrict__ agg, int64_t ldagg, int n_dst, int D) {
+  const int lane = threadIdx.x & 63;
+  const int d = __builtin_amdgcn_readfirstlane(blockIdx.x * kRowWaves + (threadIdx.x >> 6));
+  if (d >= n_dst) return;
+  const int beg = __builtin_amdgcn_readfirstlane(colptr[d]);
+  const int end = __builtin_amdgcn_readfirstlane(colptr[d + 1]);
+  float sum[CH][VEC];
+#pragma unroll
+  for (int t = 0; t < CH; ++t)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) sum[t][j] = 0.f;
+  for (int m = beg; m < end; ++m) {
+    float r[CH][VEC], eo[CH][VEC];
+    load_row<T, VEC, CH>(z + (int64_t)m * ldz, D, lane, r);
+    load_row<T, VEC, CH>(e_old + (int64_t)m * lde, D, lane, eo);
+    if (gamma != nullptr) normalise_row<T, VEC, CH>(r, D, lane, gamma, beta, eps);
+#pragma unroll
+    for (int t = 0; t < CH; ++t)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        r[t][j] += eo[t][j];
+      }
+    store_row<T, VEC, CH>(e_new + (int64_t)m * ldn, D, lane, r);
+    // accumulate what was actually stored (storage precision), matching scatter(sum) over the stored e_new
+#pragma unroll
+    for (int t = 0; t < CH; ++t)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) sum[t][j] += to_float(from_float<T>(r[t][j]));
+  }
+  store_row<T, VEC, CH>(agg + (int64_t)d * ldagg, D, lane, sum);
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(64 * kRowWaves) void gather_rows_kernel(const T* __restrict__ x, int64_t ldx,
+                                                                     const int32_t* __restrict__ idx,
+                                                                     T* __restrict__ out, int64_t ldo, int n_out, int D) {
+  const int lane = threadIdx.x & 63;
+  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * kRowWaves + (threadIdx.x >> 6));
+  if (i >= n_out) return;
+  const int s = __builtin_amdgcn_readfirstlane(idx[i]);
+  for (int c = lane * VEC; c < D; c += 64 * VEC) {
+    *reinterpret_cast<Vec<T, VEC>*>(out + (int64_t)i * ldo + c) = *reinterpret_cast<const Vec<T, VEC>*>(x + (int64_t)s * ldx + c);
+  }
+}
+
+// Pick the widest vector width (in elements) such that rows stay 16-byte-or-narrower aligned and D % VEC == 0.
+template <typename T>
+static int pick_vec(int D, std::initializer_list<int64_t> lds, std::initializer_list<const void*> ptrs) {
+  int vec = 16 / (int)sizeof(T);  // 16-byte accesses
+  auto ok = [&](int v) {
+    if (D % v) return false;
+    for (int64_t ld : lds)
+      if (ld % v) return false;
+    for (const void* p : ptrs)
+      if (p && (reinterpret_cast<uintptr_t>(p) % (v * sizeof(T)))) return false;
+    return true;
+  };
+  while (vec > 1 && !ok(vec)) vec >>= 1;
+  return vec;
+}
+
+// smallest power-of-two chunk count covering D, or 0 if the row does not fit in registers
+static int pick_chunks(int D, int vec) {
+  for (int ch = 1; ch <= kMaxChunksLimit; ch *= 2)
+    if (D <= 64 * vec * ch) return ch;
+  return 0;
+}
+
+#define ALL_VEC_CH(M) \
+  M(1, 1) M(1, 2) M(1, 4) M(1, 8) M(2, 1) M(2, 2) M(2, 4) M(2, 8) M(4, 1) M(4, 2) M(4, 4) M(4, 8) M(8, 1) M(8, 2) M(8, 4) M(8, 8)
+
+template <typename T>
+static int layernorm_launch(const void* x, int64_t ldx, const void* gamma, const void* beta, void* y, int64_t ldy,
+                            int n_rows, int D, float eps, hipStream_t st) {
+  const int vec = pick_vec<T>(D, {ldx, ldy}, {x, y, gamma, beta});
+  const int ch = pick_chunks(D, vec);
+  ANEMOI_REQUIRE(ch > 0, "layernorm_fwd: D=%d too large for the register-resident row (max %d at vector width %d)", D, 64 * vec * kMaxChunksLimit, vec);
+  const dim3 grid((n_rows + kRowWaves - 1) / kRowWaves), block(64 * kRowWaves);
+#define LN_CASE(V, C)                                                                                                   \
+  case V * 16 + C:                                                                                                      \
+    hipLaunchKernelGGL((layernorm_fwd_kernel<T, V, C>), grid, block, 0, st, (const T*)x, ldx, (const T*)gamma,          \
+                       (const T*)beta, (T*)y, ldy, n_rows, D, eps);                                                     \
+    break;
+  switch (vec * 16 + ch) {
+    ALL_VEC_CH(LN_CASE)
+    default: set_error("layernorm_fwd: bad vector width"); return ANEMOI_E_INVALID;
+  }
+#undef LN_CASE
+  return check_launch("layernorm_fwd_kernel");
+}
+
+template <typename T>
+static int edge_launch(const void* z, int64_t ldz, const void* e_old, int64_t lde, const void* gamma, const void* beta,
+                       float eps, const int32_t* colptr, void* e_new, int64_t ldn, void* agg, int64_t ldagg, int n_dst,
+                       int D, hipStream_t st) {
+  const int vec = pick_vec<T>(D, {ldz, lde, ldn, ldagg}, {z, e_old, e_new, agg, gamma, beta});
+  const int ch = pick_chunks(D, vec);
+  ANEMOI_REQUIRE(ch > 0, "edge_ln_residual_segment_sum_fwd: D=%d too large (max %d)", D, 64 * vec * kMaxChunksLimit);
+  const dim3 grid((n_dst + kRowWaves - 1) / kRowWaves), block(64 * kRowWaves);
+#define E_CASE(V, C)                                                                                                    \
+  case V * 16 + C:                                                                                                      \
+    hipLaunchKernelGGL((edge_ln_res_segsum_kernel<T, V, C>), grid, block, 0, st, (const T*)z, ldz, (const T*)e_old,     \
+                       lde, (const T*)gamma, (const T*)beta, eps, colptr, (T*)e_new, ldn, (T*)agg, ldagg, n_dst, D);    \
+    break;
+  switch (vec * 16 + ch) {
+    ALL_VEC_CH(E_CASE)
+    default: set_error("edge_ln_residual_segment_sum_fwd: bad vector width"); return ANEMOI_E_INVALID;
+  }
+#undef E_CASE
+  return check_launch("edge_ln_res_segsum_kernel");
+}
+
+template <typename T>
+static int gather_launch(const void* x, int64_t ldx, const int32_t* idx, void* out, int64_t ldo, int n_out, int D,
+                         hipStream_t st) {
+  const int vec = pick_vec<T>(D, {ldx, ldo}, {x, out});
+  const dim3 grid((n_out + kRowWaves - 1) / kRowWaves), block(64 * kRowWaves);
+#define G_CASE(V)                                                                                                       \
+  case V:                                                                                                               \
+    hipLaunchKernelGGL((gather_rows_kernel<T, V>), grid, block, 0, st, (const T*)x, ldx, idx, (T*)out, ldo, n_out, D);  \
+    break;
+  switch (vec) {
+    G_CASE(1) G_CASE(2) G_CASE(4) G_CASE(8)
+    default: set_error("gather_rows: bad vector width"); return ANEMOI_E_INVALID;
+  }
+#undef G_CASE
+  return check_launch("gather_rows_kernel");
+}
+
+}  // namespace anemoi
+
+using namespace anemoi;
+
+extern "C" int anemoi_layernorm_fwd(const void* x, int64_t ldx, const void* gamma, const void* beta, void* y, int64_t ldy,
+                                    int32_t n_rows, int32_t D, float eps, anemoi_dtype_t dtype, void* stream) {
+  ANEMOI_REQUIRE(n_rows >= 0 && D > 0 && ldx >= D && ldy >= D, "layernorm_fwd: bad sizes n_rows=%d D=%d", n_rows, D);
+  if (n_rows == 0) return ANEMOI_OK;
+  ANEMOI_REQUIRE(x && y && gamma, "layernorm_fwd: null pointer");
+  switch (dtype) {
+    case ANEMOI_F32: return layernorm_launch<float>(x, ldx, gamma, beta, y, ldy, n_rows, D, eps, as_stream(stream));
+    case ANEMOI_BF16: return layernorm_launch<bf16_t>(x, ldx, gamma, beta, y, ldy, n_rows, D, eps, as_stream(stream));
+    case ANEMOI_F16: return layernorm_launch<f16_t>(x, ldx, gamma, beta, y, ldy, n_rows, D, eps, as_stream(stream));
+    default: set_error("unknown dtype"); return ANEMOI_E_INVALID;
+  }
+}
+
+extern "C" int anemoi_edge_ln_residual_segment_sum_fwd(const void* z, int64_t ldz, const void* e_old, int64_t lde,
+                                                       const void* gamma, const void* beta, float eps,
+                                                       const int32_t* colptr, void* e_new, int64_t ldn, void* agg,
+                                                       int64_t ldagg, int32_t n_dst, int32_t D, anemoi_dtype_t dtype,
+                                                       void* stream) {
+  ANEMOI_REQUIRE(n_dst >= 0 && D > 0 && ldz >= D && lde >= D && ldn >= D && ldagg >= D, "edge_ln_residual_segment_sum_fwd: bad sizes");
+  if (n_dst == 0) return ANEMOI_OK;
+  ANEMOI_REQUIRE(z && e_old && e_new && agg && colptr, "edge_ln_residual_segment_sum_fwd: null pointer");
+  switch (dtype) {
+    case ANEMOI_F32: return edge_launch<float>(z, ldz, e_old, lde, gamma, beta, eps, colptr, e_new, ldn, agg, ldagg, n_dst, D, as_stream(stream));
+    case ANEMOI_BF16: return edge_launch<bf16_t>(z, ldz, e_old, lde, gamma, beta, eps, colptr, e_new, ldn, agg, ldagg, n_dst, D, as_stream(stream));
+    case ANEMOI_F16: return edge_launch<f16_t>(z, ldz, e_old, lde, gamma, beta, eps, colptr, e_new, ldn, agg, ldagg, n_dst, D, as_stream(stream));
+    default: set_error("unknown dtype"); return ANEMOI_E_INVALID;
+  }
+}
+
+extern "C" int anemoi_gather_rows(const void* x, int64_t ldx, const int32_t* idx, void* out, int64_t ldo, int32_t n_out,
+                                  int32_t D, anemoi_dtype_t dtype, void* stream) {
+  ANEMOI_REQUIRE(n_out >= 0 && D > 0 && ldx >= D && ldo >= D, "gather_rows: bad sizes");
+  if (n_out == 0) return ANEMOI_OK;
+  ANEMOI_REQUIRE(x && idx && out, "gather_rows: null pointer");
+  switch (dtype) {
+    case ANEMOI_F32: return gather_launch<float>(x, ldx, idx, out, ldo, n_out, D, as_stream(stream));
+    case ANEMOI_BF16: return gather_launch<bf16_t>(x, ldx, idx, out, ldo, n_out, D, as_stream(stream));
+    case ANEMOI_F16: return gather_launch<f16_t>(x, ldx, idx, out, ldo, n_out, D, as_stream(stream));
+    default: set_error("unknown dtype"); return ANEMOI_E_INVALID;
+  }
+}

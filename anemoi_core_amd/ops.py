@@ -1,0 +1,291 @@
+"""Tensor-level entry points of the MI355X kernels (thin wrappers over the C ABI, include/anemoi_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; every function checks its
+arguments, allocates the output with torch, and enqueues one kernel through ctypes.  All tensors must live
+on a ROCm device — there is no CPU / eager fallback (a CPU tensor raises).
+
+The op-level mirror of the reference boundary is at the bottom:
+``anemoi_amd::graph_transformer_attention`` and ``graph_transformer_attention_conv`` follow
+``anemoi::graph_transformer_attention`` / ``graph_transformer_attention_conv``
+(reference models/src/anemoi/models/triton/gt.py:390-428, 564-576).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from . import _lib
+
+_DT = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16, torch.float16: _lib.F16}
+
+
+def _dt(t: Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise ValueError(f"unsupported dtype {t.dtype}; supported: float32, bfloat16, float16") from None
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(*ts: Optional[Tensor]) -> None:
+    dev = None
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "anemoi_core_amd kernels run on an MI355X (ROCm) device only; got a tensor on "
+                f"'{t.device}'. There is no CPU fallback in the product path."
+            )
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"tensors on different devices: {dev} vs {t.device}")
+
+
+def _rows(t: Optional[Tensor], name: str, dtype=None) -> tuple[int, int]:
+    """(data_ptr, leading dimension) of a 2-D row-major view whose last dim is contiguous."""
+    if t is None:
+        return 0, 0
+    if t.dim() != 2:
+        raise ValueError(f"{name}: expected a 2-D tensor, got shape {tuple(t.shape)}")
+    if t.shape[1] > 1 and t.stride(1) != 1:
+        raise ValueError(f"{name}: last dimension must be contiguous (strides {t.stride()})")
+    if dtype is not None and t.dtype != dtype:
+        raise ValueError(f"{name}: dtype {t.dtype} does not match {dtype}")
+    ld = t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
+    return t.data_ptr(), ld
+
+
+def _vec(t: Optional[Tensor], name: str, n: int, dtype) -> int:
+    if t is None:
+        return 0
+    if t.dim() != 1 or t.shape[0] != n or not t.is_contiguous() or t.dtype != dtype:
+        raise ValueError(f"{name}: expected contiguous [{n}] {dtype}, got {tuple(t.shape)} {t.dtype}")
+    return t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------ static graph structure
+@dataclass(frozen=True)
+class CSC:
+    """dst-sorted (CSC) adjacency of a static graph, int32, built once (the reference rebuilds it on every
+    call: layers/block.py:779-785, triton/utils.py:25-70)."""
+
+    row: Tensor  # [M] int32 source node of every edge, CSC order
+    dst: Tensor  # [M] int32 destination node of every edge, CSC order
+    colptr: Tensor  # [n_dst + 1] int32
+    n_src: int
+    n_dst: int
+    perm: Optional[Tensor] = None  # original -> CSC edge order when the input was not dst-sorted
+
+    @property
+    def num_edges(self) -> int:
+        return self.row.shape[0]
+
+
+def build_csc(edge_index: Tensor, size: tuple[int, int], edges_are_dst_sorted: bool = True, check: bool = False) -> CSC:
+    """edge_index [2, M] (src, dst) any integer dtype -> CSC.  Pure index bookkeeping (torch ops; works on any
+    device so that the host logic is testable without a GPU)."""
+    n_src, n_dst = int(size[0]), int(size[1])
+    if edge_index.dim() != 2 or edge_index.shape[0] != 2:
+        raise ValueError(f"edge_index must be [2, M], got {tuple(edge_index.shape)}")
+    if max(n_src, n_dst, edge_index.shape[1]) >= 2**31:
+        raise ValueError("graph too large for int32 indices")
+    src, dst = edge_index[0].long(), edge_index[1].long()
+    perm = None
+    if not edges_are_dst_sorted:
+        perm = torch.sort(dst, stable=True)[1]  # sort_edge_index_by_dst (distributed/khop_edges.py:37-40)
+        src, dst = src[perm], dst[perm]
+    elif check and dst.numel() > 1 and not bool((dst[1:] >= dst[:-1]).all()):
+        raise ValueError("edge_index is not sorted by destination node")
+    colptr = torch.zeros(n_dst + 1, dtype=torch.long, device=edge_index.device)
+    if dst.numel():
+        colptr[1:] = torch.cumsum(torch.bincount(dst, minlength=n_dst), 0)
+    return CSC(row=src.to(torch.int32).contiguous(), dst=dst.to(torch.int32).contiguous(),
+               colptr=colptr.to(torch.int32).contiguous(), n_src=n_src, n_dst=n_dst, perm=perm)
+
+
+# ------------------------------------------------------------------------------------------ kernels
+def gt_attention(q: Tensor, k: Tensor, v: Tensor, e: Optional[Tensor], csc: CSC, num_heads: int,
+                 addend: Optional[Tensor] = None, return_lse: bool = False):
+    """out[d] = softmax-attention over in-edges (+ addend).  q/out/addend [n_dst, D]; k, v [n_src, D]; e [M, D]."""
+    _dev(q, k, v, e, addend, csc.row)
+    D = q.shape[1]
+    if D % num_heads:
+        raise ValueError(f"channels {D} not divisible by heads {num_heads}")
+    if q.shape[0] != csc.n_dst or k.shape[0] != csc.n_src or v.shape[0] != csc.n_src:
+        raise ValueError(f"node counts {q.shape[0]}/{k.shape[0]}/{v.shape[0]} do not match the graph ({csc.n_dst}, {csc.n_src})")
+    if e is not None and e.shape[0] != csc.num_edges:
+        raise ValueError(f"edge tensor has {e.shape[0]} rows, graph has {csc.num_edges} edges")
+    out = torch.empty((csc.n_dst, D), dtype=q.dtype, device=q.device)
+    lse = torch.empty((csc.n_dst, num_heads), dtype=torch.float32, device=q.device) if return_lse else None
+    (qp, ldq), (kp, ldk), (vp, ldv) = _rows(q, "q"), _rows(k, "k", q.dtype), _rows(v, "v", q.dtype)
+    ep, lde = _rows(e, "e", q.dtype)
+    ap, lda = _rows(addend, "addend", q.dtype)
+    rc = _lib.load().anemoi_gt_attention_fwd(qp, ldq, kp, ldk, vp, ldv, ep, lde, csc.row.data_ptr(), csc.colptr.data_ptr(),
+                                             ap, lda, out.data_ptr(), D, lse.data_ptr() if return_lse else 0,
+                                             csc.n_dst, csc.n_src, num_heads, D // num_heads, _dt(q), _stream())
+    _lib.check(rc, "gt_attention_fwd")
+    return (out, lse) if return_lse else out
+
+
+def edge_feature_pad(fe: int) -> int:
+    return 4 * ((fe + 1 + 3) // 4)
+
+
+def pack_edge_features(edge_attr: Tensor) -> Tensor:
+    """[M, Fe] (any float dtype) -> fp32 [M, fe_pad] = [edge_attr | 1 | 0...] for the fused-edge attention."""
+    _dev(edge_attr)
+    M, fe = edge_attr.shape
+    fe_pad = edge_feature_pad(fe)
+    out = torch.empty((M, fe_pad), dtype=torch.float32, device=edge_attr.device)
+    p, ld = _rows(edge_attr, "edge_attr")
+    _lib.check(_lib.load().anemoi_pack_edge_features(p, ld, out.data_ptr(), M, fe, fe_pad, _dt(edge_attr), _stream()), "pack_edge_features")
+    return out
+
+
+def gt_attention_fused_edge(q: Tensor, k: Tensor, v: Tensor, edge_feat: Tensor, w_edge: Tensor, b_edge: Optional[Tensor],
+                            csc: CSC, num_heads: int, addend: Optional[Tensor] = None, return_lse: bool = False):
+    """Attention with lin_edge fused: edge_feat = pack_edge_features(edge_attr) fp32 [M, fe_pad];
+    w_edge [D, Fe], b_edge [D] in q.dtype."""
+    _dev(q, k, v, edge_feat, w_edge, b_edge, addend, csc.row)
+    D = q.shape[1]
+    fe = w_edge.shape[1]
+    fe_pad = edge_feature_pad(fe)
+    if D % num_heads:
+        raise ValueError(f"channels {D} not divisible by heads {num_heads}")
+    if edge_feat.dtype != torch.float32 or tuple(edge_feat.shape) != (csc.num_edges, fe_pad) or not edge_feat.is_contiguous():
+        raise ValueError(f"edge_feat must be contiguous fp32 [{csc.num_edges}, {fe_pad}], got {tuple(edge_feat.shape)} {edge_feat.dtype}")
+    if tuple(w_edge.shape) != (D, fe) or not w_edge.is_contiguous() or w_edge.dtype != q.dtype:
+        raise ValueError(f"w_edge must be contiguous [{D}, {fe}] {q.dtype}")
+    if q.shape[0] != csc.n_dst or k.shape[0] != csc.n_src or v.shape[0] != csc.n_src:
+        raise ValueError("node counts do not match the graph")
+    out = torch.empty((csc.n_dst, D), dtype=q.dtype, device=q.device)
+    lse = torch.empty((csc.n_dst, num_heads), dtype=torch.float32, device=q.device) if return_lse else None
+    (qp, ldq), (kp, ldk), (vp, ldv) = _rows(q, "q"), _rows(k, "k", q.dtype), _rows(v, "v", q.dtype)
+    ap, lda = _rows(addend, "addend", q.dtype)
+    rc = _lib.load().anemoi_gt_attention_fused_edge_fwd(
+        qp, ldq, kp, ldk, vp, ldv, edge_feat.data_ptr(), fe, fe_pad, w_edge.data_ptr(), _vec(b_edge, "b_edge", D, q.dtype),
+        csc.row.data_ptr(), csc.colptr.data_ptr(), ap, lda, out.data_ptr(), D, lse.data_ptr() if return_lse else 0,
+        csc.n_dst, csc.n_src, num_heads, D // num_heads, _dt(q), _stream())
+    _lib.check(rc, "gt_attention_fused_edge_fwd")
+    return (out, lse) if return_lse else out
+
+
+def layer_norm(x: Tensor, weight: Tensor, bias: Optional[Tensor], eps: float = 1e-5) -> Tensor:
+    """LayerNorm over the last dim of a [..., D] tensor (fp32 statistics)."""
+    _dev(x, weight, bias)
+    D = x.shape[-1]
+    x2 = x.reshape(-1, D)
+    if x2.shape[1] > 1 and x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    y = torch.empty((x2.shape[0], D), dtype=x.dtype, device=x.device)
+    p, ld = _rows(x2, "x")
+    rc = _lib.load().anemoi_layernorm_fwd(p, ld, _vec(weight, "weight", D, x.dtype), _vec(bias, "bias", D, x.dtype), y.data_ptr(), D,
+                                          x2.shape[0], D, float(eps), _dt(x), _stream())
+    _lib.check(rc, "layernorm_fwd")
+    return y.view(x.shape)
+
+
+def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, *, act: Optional[str] = None,
+           residual: Optional[Tensor] = None, x2: Optional[Tensor] = None, g1: Optional[Tensor] = None,
+           idx1: Optional[Tensor] = None, g2: Optional[Tensor] = None, idx2: Optional[Tensor] = None,
+           out: Optional[Tensor] = None) -> Tensor:
+    """y = act([x | x2] @ weight^T + bias + g1[idx1] + g2[idx2]) + residual.  x [N, K1], x2 [N, K2], weight [O, K1+K2]."""
+    _dev(x, weight, bias, residual, x2, g1, idx1, g2, idx2, out)
+    N, K1 = x.shape
+    K2 = 0 if x2 is None else x2.shape[1]
+    O = weight.shape[0]
+    if weight.shape[1] != K1 + K2:
+        raise ValueError(f"weight is {tuple(weight.shape)}, expected [{O}, {K1 + K2}]")
+    if act not in (None, "gelu"):
+        raise ValueError(f"unsupported activation {act!r}")
+    for name, t in (("x2", x2), ("residual", residual)):
+        if t is not None and t.shape[0] != N:
+            raise ValueError(f"{name} has {t.shape[0]} rows, expected {N}")
+    if residual is not None and residual.shape[1] != O:
+        raise ValueError("residual width does not match the output width")
+    for name, g, idx in (("g1", g1, idx1), ("g2", g2, idx2)):
+        if (g is None) != (idx is None):
+            raise ValueError(f"{name} and its index must be given together")
+        if g is not None and (g.shape[1] != O or idx.dtype != torch.int32 or idx.shape != (N,) or not idx.is_contiguous()):
+            raise ValueError(f"{name}: table must be [*, {O}] and index contiguous int32 [{N}]")
+    y = out if out is not None else torch.empty((N, O), dtype=x.dtype, device=x.device)
+    dt = x.dtype
+    (xp, ldx), (x2p, ldx2), (wp, ldw) = _rows(x, "x"), _rows(x2, "x2", dt), _rows(weight, "weight", dt)
+    (g1p, ldg1), (g2p, ldg2), (rp, ldr), (yp, ldy) = _rows(g1, "g1", dt), _rows(g2, "g2", dt), _rows(residual, "residual", dt), _rows(y, "out", dt)
+    rc = _lib.load().anemoi_linear_fwd(xp, ldx, K1, x2p, ldx2, K2, wp, ldw, _vec(bias, "bias", O, dt), g1p, ldg1,
+                                       idx1.data_ptr() if idx1 is not None else 0, g2p, ldg2,
+                                       idx2.data_ptr() if idx2 is not None else 0, rp, ldr, yp, ldy, N, O,
+                                       _lib.ACT_GELU if act == "gelu" else _lib.ACT_NONE, _dt(x), _stream())
+    _lib.check(rc, "linear_fwd")
+    return y
+
+
+def edge_ln_residual_segment_sum(z: Tensor, e_old: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], eps: float,
+                                 csc: CSC) -> tuple[Tensor, Tensor]:
+    """e_new = LayerNorm(z) + e_old;  agg[d] = sum of e_new over the in-edges of d.  Returns (e_new, agg)."""
+    _dev(z, e_old, gamma, beta, csc.colptr)
+    M, D = z.shape
+    if M != csc.num_edges or tuple(e_old.shape) != (M, D):
+        raise ValueError("edge tensors do not match the graph")
+    e_new = torch.empty((M, D), dtype=z.dtype, device=z.device)
+    agg = torch.empty((csc.n_dst, D), dtype=z.dtype, device=z.device)
+    (zp, ldz), (ep, lde) = _rows(z, "z"), _rows(e_old, "e_old", z.dtype)
+    rc = _lib.load().anemoi_edge_ln_residual_segment_sum_fwd(
+        zp, ldz, ep, lde, _vec(gamma, "gamma", D, z.dtype), _vec(beta, "beta", D, z.dtype), float(eps), csc.colptr.data_ptr(),
+        e_new.data_ptr(), D, agg.data_ptr(), D, csc.n_dst, D, _dt(z), _stream())
+    _lib.check(rc, "edge_ln_residual_segment_sum_fwd")
+    return e_new, agg
+
+
+def gather_rows(x: Tensor, idx: Tensor) -> Tensor:
+    """out[i] = x[idx[i]] (idx int32)."""
+    _dev(x, idx)
+    if idx.dtype != torch.int32 or idx.dim() != 1 or not idx.is_contiguous():
+        raise ValueError("idx must be contiguous int32 [n]")
+    D = x.shape[1]
+    out = torch.empty((idx.shape[0], D), dtype=x.dtype, device=x.device)
+    p, ld = _rows(x, "x")
+    _lib.check(_lib.load().anemoi_gather_rows(p, ld, idx.data_ptr(), out.data_ptr(), D, idx.shape[0], D, _dt(x), _stream()), "gather_rows")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ reference op mirror
+@torch.library.custom_op("anemoi_amd::graph_transformer_attention", mutates_args=(), device_types="cuda")
+def graph_transformer_attention(q: Tensor, k: Tensor, v: Tensor, e: Tensor, row: Tensor, colptr: Tensor, rowptr: Tensor,
+                                edge_ids: Tensor, edge_dst: Tensor) -> tuple[Tensor, Tensor, Tensor]:
+    """Same signature and outputs as the reference's ``anemoi::graph_transformer_attention``
+    (triton/gt.py:390-428): q [N_dst,H,C], k,v [N_src,H,C], e [M,H,C] in CSC order, int64 row/colptr;
+    returns (out in q.dtype, out_saved fp32, m = logsumexp fp32).  rowptr/edge_ids/edge_dst (reverse CSR)
+    are only needed by the backward pass and ignored here."""
+    N_dst, H, Cc = q.shape
+    q2, k2, v2, e2 = (t.contiguous().view(t.shape[0], H * Cc) for t in (q, k, v, e))
+    csc = CSC(row=row.to(torch.int32).contiguous(), dst=edge_dst.to(torch.int32).contiguous(),
+              colptr=colptr.to(torch.int32).contiguous(), n_src=k.shape[0], n_dst=N_dst)
+    out, m = gt_attention(q2, k2, v2, e2, csc, H, return_lse=True)
+    out = out.view(N_dst, H, Cc)
+    return out, out.float() if out.dtype != torch.float32 else out.clone(), m
+
+
+@graph_transformer_attention.register_fake
+def _graph_transformer_attention_fake(q, k, v, e, row, colptr, rowptr, edge_ids, edge_dst):
+    N_dst, H, Cc = q.shape
+    return (torch.empty((N_dst, H, Cc), device=q.device, dtype=q.dtype),
+            torch.empty((N_dst, H, Cc), device=q.device, dtype=torch.float32),
+            torch.empty((N_dst, H), device=q.device, dtype=torch.float32))
+
+
+def graph_transformer_attention_conv(query: Tensor, key: Tensor, value: Tensor, edges: Tensor, csc: tuple[Tensor, Tensor],
+                                     reverse: tuple[Tensor, Tensor, Tensor]) -> Tensor:
+    """Drop-in for the reference's ``graph_transformer_attention_conv`` (triton/gt.py:564-576)."""
+    row, colptr = csc
+    rowptr, edge_ids, edge_dst = reverse
+    out, _saved, _m = graph_transformer_attention(query, key, value, edges, row, colptr, rowptr, edge_ids, edge_dst)
+    return out

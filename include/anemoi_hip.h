@@ -1,0 +1,105 @@
+/*
+ * anemoi_hip.h — C ABI of libanemoi_hip.so: the MI355X (gfx950) kernels behind the
+ * anemoi-models encoder-processor-decoder hot path.
+ *
+ * The reference (ecmwf/anemoi-core) is pure Python: it has no FFI of its own.  Its kernel boundary
+ * is the registered PyTorch op  anemoi::graph_transformer_attention(q,k,v,e,row,colptr,...)
+ * (models/src/anemoi/models/triton/gt.py:390-428) plus the torch.nn layers chosen through
+ * ``layer_kernels`` (models/src/anemoi/models/layers/utils.py:87-142).  Each entry point below names
+ * the reference interface it replaces.  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; all pointers are DEVICE pointers unless stated otherwise;
+ *  - row-major matrices with an explicit leading dimension ``ld*`` counted in ELEMENTS;
+ *  - ``dtype`` selects the storage type of every floating tensor of the call (accumulation is
+ *    always fp32); indices are int32 (the reference uses int64 at its op boundary, gt.py:413-414,
+ *    the host wrapper converts once because the graph is static; N, M < 2^31);
+ *  - ``stream`` is a hipStream_t passed as void*; kernels are enqueued, never synchronised;
+ *  - return value 0 = success, otherwise a negative ANEMOI_E_* code; anemoi_hip_last_error()
+ *    returns a thread-local message.  Nothing is allocated or freed by the library.
+ */
+#ifndef ANEMOI_HIP_H
+#define ANEMOI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ANEMOI_HIP_ABI_VERSION 1
+
+typedef enum { ANEMOI_F32 = 0, ANEMOI_BF16 = 1, ANEMOI_F16 = 2 } anemoi_dtype_t;
+typedef enum { ANEMOI_ACT_NONE = 0, ANEMOI_ACT_GELU = 1 } anemoi_act_t;
+
+#define ANEMOI_OK 0
+#define ANEMOI_E_INVALID (-1)   /* bad argument (shape, dtype, alignment, null pointer) */
+#define ANEMOI_E_UNSUPPORTED (-2)
+#define ANEMOI_E_LAUNCH (-3)    /* hipGetLastError() != hipSuccess after the launch */
+
+int anemoi_hip_abi_version(void);
+const char* anemoi_hip_last_error(void);
+
+/* Fused graph-transformer edge attention, forward.
+ * Replaces: anemoi::graph_transformer_attention / _gt_fwd (triton/gt.py:81-179, 390-428) and
+ * GraphTransformerConv (layers/conv.py:84-147).
+ *   for every destination node d, head h, over the in-edges e=(s->d) in CSC order:
+ *     score = <q[d,h,:], k[s,h,:] + E[e,h,:]> / sqrt(C);  a = softmax_e(score)
+ *     out[d,h,:] = sum_e a * (v[s,h,:] + E[e,h,:])  (+ addend[d,h,:] if addend != NULL)
+ *     lse[d,h]   = max + log(sum exp)               (if lse != NULL; 0 for empty d)
+ * q,out,addend: [n_dst, H*C]; k,v: [n_src, H*C]; e: [M, H*C] in CSC (dst-sorted) order or NULL
+ * (no edge term); row[M] = source id per edge; colptr[n_dst+1].  Zero-in-degree d -> out = addend or 0. */
+int anemoi_gt_attention_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                            const void* e, int64_t lde, const int32_t* row, const int32_t* colptr,
+                            const void* addend, int64_t ldadd, void* out, int64_t ldo, float* lse,
+                            int32_t n_dst, int32_t n_src, int32_t H, int32_t C, anemoi_dtype_t dtype, void* stream);
+
+/* Same op with ``lin_edge`` fused: E[e] = edge_attr[e] @ w_edge^T + b_edge is never materialised.
+ * Replaces: lin_edge(...) + the op above (layers/block.py:623-635 + triton/gt.py:81-179).
+ * edge_feat: fp32 [M, fe_pad] with fe_pad = 4*ceil((Fe+1)/4): columns [0,Fe) = edge_attr, column Fe = 1.0
+ * (carries the bias), the rest 0; w_edge: ``dtype`` [H*C, Fe] (ld = Fe); b_edge: ``dtype`` [H*C] or NULL. */
+int anemoi_gt_attention_fused_edge_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                                       const float* edge_feat, int32_t fe, int32_t fe_pad, const void* w_edge,
+                                       const void* b_edge, const int32_t* row, const int32_t* colptr, const void* addend,
+                                       int64_t ldadd, void* out, int64_t ldo, float* lse, int32_t n_dst, int32_t n_src,
+                                       int32_t H, int32_t C, anemoi_dtype_t dtype, void* stream);
+
+/* Pack edge attributes for the fused op: out fp32 [M, fe_pad] = [edge_attr | 1 | 0...]. */
+int anemoi_pack_edge_features(const void* edge_attr, int64_t ld, float* out, int32_t M, int32_t fe, int32_t fe_pad,
+                              anemoi_dtype_t dtype, void* stream);
+
+/* LayerNorm over the last dimension (eps inside the sqrt, affine; beta may be NULL).
+ * Replaces: torch.nn.LayerNorm / AutocastLayerNorm via layer_kernels.LayerNorm
+ * (layers/utils.py:107-121, layers/normalization.py:19-31).  x,y: [n_rows, D]. */
+int anemoi_layernorm_fwd(const void* x, int64_t ldx, const void* gamma, const void* beta, void* y, int64_t ldy,
+                         int32_t n_rows, int32_t D, float eps, anemoi_dtype_t dtype, void* stream);
+
+/* Linear layer with fused epilogue.  Replaces torch.nn.Linear (+ GELU + residual add) as used by
+ * get_qkve / projection / MLP (layers/block.py:623-635,1268-1271; layers/mlp.py:158-169).
+ *   y[n, o] = act( sum_k A[n,k] * w[o,k] + bias[o] + g1[idx1[n], o] + g2[idx2[n], o] ) + residual[n, o]
+ * A = [x | x2] concatenated along K (x: [n_rows,K1], x2: [n_rows,K2] or NULL with K2=0);  w: [O, K1+K2]
+ * row-major (torch layout);  bias, g1/idx1, g2/idx2, residual optional (NULL).  The gather-add terms
+ * serve GraphConv's first edge-MLP layer (layers/conv.py:73-76: cat[x_i, x_j, e] @ W^T is split into
+ * two node-level products gathered per edge and one edge-level product). */
+int anemoi_linear_fwd(const void* x, int64_t ldx, int32_t K1, const void* x2, int64_t ldx2, int32_t K2, const void* w,
+                      int64_t ldw, const void* bias, const void* g1, int64_t ldg1, const int32_t* idx1, const void* g2,
+                      int64_t ldg2, const int32_t* idx2, const void* residual, int64_t ldr, void* y, int64_t ldy,
+                      int32_t n_rows, int32_t O, anemoi_act_t act, anemoi_dtype_t dtype, void* stream);
+
+/* GraphConv edge epilogue + aggregation, one pass over the dst-sorted edges (no atomics).
+ * Replaces: MLP.layer_norm + "+ edge_attr" + scatter(sum) (layers/conv.py:73-81, layers/mlp.py:176-178).
+ *   e_new[m,:] = LayerNorm(z[m,:]) + e_old[m,:];   agg[d,:] = sum_{m in in(d)} e_new[m,:]
+ * z, e_old, e_new: [M, D]; agg: [n_dst, D]; gamma/beta: [D] (gamma NULL -> no LayerNorm). */
+int anemoi_edge_ln_residual_segment_sum_fwd(const void* z, int64_t ldz, const void* e_old, int64_t lde,
+                                            const void* gamma, const void* beta, float eps, const int32_t* colptr,
+                                            void* e_new, int64_t ldn, void* agg, int64_t ldagg, int32_t n_dst,
+                                            int32_t D, anemoi_dtype_t dtype, void* stream);
+
+/* Row gather: out[i,:] = x[idx[i],:].  Packs the halo send buffer (distributed/primitives.py:455). */
+int anemoi_gather_rows(const void* x, int64_t ldx, const int32_t* idx, void* out, int64_t ldo, int32_t n_out, int32_t D,
+                       anemoi_dtype_t dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ANEMOI_HIP_H */

@@ -1,0 +1,70 @@
+"""CPU checks of the C-ABI boundary: the library builds/loads and exports every symbol include/anemoi_hip.h declares
+(no compute calls: there is no GPU here), and the ctypes signatures agree with the header."""
+import os
+import re
+
+import pytest
+import torch
+
+from anemoi_core_amd import _lib
+
+HEADER = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "anemoi_hip.h")
+
+
+def header_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    out = {}
+    for m in re.finditer(r"^(?:int|const char\*)\s+(anemoi_\w+)\s*\((.*?)\);", text, flags=re.S | re.M):
+        args = m.group(2).strip()
+        out[m.group(1)] = 0 if args == "void" else len([a for a in args.split(",") if a.strip()])
+    return out
+
+
+def test_header_and_binding_agree():
+    decl = header_functions()
+    assert len(decl) >= 9
+    assert set(decl) == set(_lib.SIGNATURES), set(decl) ^ set(_lib.SIGNATURES)
+    for name, nargs in decl.items():
+        assert len(_lib.SIGNATURES[name][0]) == nargs, name
+
+
+def test_library_loads_and_exports_all_symbols():
+    if not os.path.exists(_lib.LIB_PATH):
+        from anemoi_core_amd.build import build_library
+
+        build_library(verbose=False)
+    lib = _lib.load()
+    assert lib.anemoi_hip_abi_version() == _lib.ABI_VERSION
+    for name in header_functions():
+        assert hasattr(lib, name), name
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setenv("ANEMOI_HIP_LIB", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.HipLibraryError, match="no CPU / eager fallback"):
+        _lib.load()
+    monkeypatch.setattr(_lib, "_lib", None)
+
+
+def test_cpu_tensors_are_rejected():
+    from anemoi_core_amd import ops
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.linear(torch.randn(4, 8), torch.randn(3, 8))
+
+
+def test_build_csc_host_logic():
+    from anemoi_core_amd import ops
+
+    ei = torch.tensor([[3, 1, 2, 0, 4], [2, 0, 2, 1, 0]])
+    csc = ops.build_csc(ei, (5, 4), edges_are_dst_sorted=False)
+    assert csc.colptr.tolist() == [0, 2, 3, 5, 5]
+    assert csc.row.tolist() == [1, 4, 0, 3, 2]  # stable within a destination
+    assert csc.dst.tolist() == [0, 0, 1, 2, 2]
+    assert csc.perm.tolist() == [1, 4, 3, 0, 2]
+    with pytest.raises(ValueError):
+        ops.build_csc(ei, (5, 4), edges_are_dst_sorted=True, check=True)
+    empty = ops.build_csc(torch.zeros(2, 0, dtype=torch.long), (3, 2))
+    assert empty.colptr.tolist() == [0, 0, 0] and empty.num_edges == 0
