@@ -80,14 +80,24 @@ __device__ __forceinline__ void store_row(T* __restrict__ p, int D, int lane, co
 template <typename T, int VEC, int CH>
 __global__ __launch_bounds__(64 * kRowWaves) void layernorm_fwd_kernel(const T* __restrict__ x, int64_t ldx,
                                                                        const T* __restrict__ gamma,
-                                                                       const T* __restrict__ beta, T* __restrict__ y,
-                                                                       int64_t ldy, int n_rows, int D, float eps) {
+                                                                       const T* __restrict__ beta,
+                                                                       const T* __restrict__ residual, int64_t ldr,
+                                                                       T* __restrict__ y, int64_t ldy, int n_rows,
+                                                                       int D, float eps) {
   const int lane = threadIdx.x & 63;
   const int rowi = blockIdx.x * kRowWaves + (threadIdx.x >> 6);
   if (rowi >= n_rows) return;
   float r[CH][VEC];
   load_row<T, VEC, CH>(x + (int64_t)rowi * ldx, D, lane, r);
   normalise_row<T, VEC, CH>(r, D, lane, gamma, beta, eps);
+  if (residual != nullptr) {
+    float rs[CH][VEC];
+    load_row<T, VEC, CH>(residual + (int64_t)rowi * ldr, D, lane, rs);
+#pragma unroll
+    for (int t = 0; t < CH; ++t)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) r[t][j] += rs[t][j];
+  }
   store_row<T, VEC, CH>(y + (int64_t)rowi * ldy, D, lane, r);
 }
 
@@ -168,16 +178,16 @@ static int pick_chunks(int D, int vec) {
   M(1, 1) M(1, 2) M(1, 4) M(1, 8) M(2, 1) M(2, 2) M(2, 4) M(2, 8) M(4, 1) M(4, 2) M(4, 4) M(4, 8) M(8, 1) M(8, 2) M(8, 4) M(8, 8)
 
 template <typename T>
-static int layernorm_launch(const void* x, int64_t ldx, const void* gamma, const void* beta, void* y, int64_t ldy,
-                            int n_rows, int D, float eps, hipStream_t st) {
-  const int vec = pick_vec<T>(D, {ldx, ldy}, {x, y, gamma, beta});
+static int layernorm_launch(const void* x, int64_t ldx, const void* gamma, const void* beta, const void* residual,
+                            int64_t ldr, void* y, int64_t ldy, int n_rows, int D, float eps, hipStream_t st) {
+  const int vec = pick_vec<T>(D, {ldx, ldy, residual ? ldr : (int64_t)0}, {x, y, gamma, beta, residual});
   const int ch = pick_chunks(D, vec);
   ANEMOI_REQUIRE(ch > 0, "layernorm_fwd: D=%d too large for the register-resident row (max %d at vector width %d)", D, 64 * vec * kMaxChunksLimit, vec);
   const dim3 grid((n_rows + kRowWaves - 1) / kRowWaves), block(64 * kRowWaves);
 #define LN_CASE(V, C)                                                                                                   \
   case V * 16 + C:                                                                                                      \
     hipLaunchKernelGGL((layernorm_fwd_kernel<T, V, C>), grid, block, 0, st, (const T*)x, ldx, (const T*)gamma,          \
-                       (const T*)beta, (T*)y, ldy, n_rows, D, eps);                                                     \
+                       (const T*)beta, (const T*)residual, ldr, (T*)y, ldy, n_rows, D, eps);                            \
     break;
   switch (vec * 16 + ch) {
     ALL_VEC_CH(LN_CASE)
@@ -229,15 +239,16 @@ static int gather_launch(const void* x, int64_t ldx, const int32_t* idx, void* o
 
 using namespace anemoi;
 
-extern "C" int anemoi_layernorm_fwd(const void* x, int64_t ldx, const void* gamma, const void* beta, void* y, int64_t ldy,
-                                    int32_t n_rows, int32_t D, float eps, anemoi_dtype_t dtype, void* stream) {
-  ANEMOI_REQUIRE(n_rows >= 0 && D > 0 && ldx >= D && ldy >= D, "layernorm_fwd: bad sizes n_rows=%d D=%d", n_rows, D);
+extern "C" int anemoi_layernorm_fwd(const void* x, int64_t ldx, const void* gamma, const void* beta, const void* residual,
+                                    int64_t ldr, void* y, int64_t ldy, int32_t n_rows, int32_t D, float eps,
+                                    anemoi_dtype_t dtype, void* stream) {
+  ANEMOI_REQUIRE(n_rows >= 0 && D > 0 && ldx >= D && ldy >= D && (!residual || ldr >= D), "layernorm_fwd: bad sizes n_rows=%d D=%d", n_rows, D);
   if (n_rows == 0) return ANEMOI_OK;
   ANEMOI_REQUIRE(x && y && gamma, "layernorm_fwd: null pointer");
   switch (dtype) {
-    case ANEMOI_F32: return layernorm_launch<float>(x, ldx, gamma, beta, y, ldy, n_rows, D, eps, as_stream(stream));
-    case ANEMOI_BF16: return layernorm_launch<bf16_t>(x, ldx, gamma, beta, y, ldy, n_rows, D, eps, as_stream(stream));
-    case ANEMOI_F16: return layernorm_launch<f16_t>(x, ldx, gamma, beta, y, ldy, n_rows, D, eps, as_stream(stream));
+    case ANEMOI_F32: return layernorm_launch<float>(x, ldx, gamma, beta, residual, ldr, y, ldy, n_rows, D, eps, as_stream(stream));
+    case ANEMOI_BF16: return layernorm_launch<bf16_t>(x, ldx, gamma, beta, residual, ldr, y, ldy, n_rows, D, eps, as_stream(stream));
+    case ANEMOI_F16: return layernorm_launch<f16_t>(x, ldx, gamma, beta, residual, ldr, y, ldy, n_rows, D, eps, as_stream(stream));
     default: set_error("unknown dtype"); return ANEMOI_E_INVALID;
   }
 }

@@ -1,0 +1,100 @@
+"""Model-parallel data movement on ``torch.distributed`` (backend "nccl" = RCCL over xGMI on the GPU box, "gloo"
+in the CPU tests).  Forward-only restatement of the reference's ``distributed/primitives.py`` / ``graph.py``
+entry points that sit on the hot path: shard (local slice), gather (all-gather of unequal shards) and the halo
+exchange (variable-count all-to-all: primitives.py:422-460).
+
+MI355X notes: xGMI is point-to-point, so the halo exchange is ONE ``all_to_all_single`` on a packed send buffer
+(each peer link carries only its own rows, all 7 links in parallel) rather than a ring collective, and the
+mapper needs only the rows its edges touch rather than the reference's all-gather of every source row
+(khop_edges.py:386-392) — see ``exchange_rows``.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+from .shapes import comm_rank, comm_size
+
+
+def shard_tensor(x: Tensor, dim: int, shard_sizes: Sequence[int], group) -> Tensor:
+    """Local slice of a replicated tensor (no communication): graph.py:66-103 / primitives.py:24-57."""
+    if comm_size(group) == 1:
+        return x
+    start = sum(shard_sizes[: comm_rank(group)])
+    return x.narrow(dim, start, shard_sizes[comm_rank(group)]).contiguous()
+
+
+def gather_tensor(x: Tensor, dim: int, shard_sizes: Sequence[int], group) -> Tensor:
+    """All-gather shards of possibly unequal size along ``dim``: primitives.py:60-183."""
+    world = comm_size(group)
+    if world == 1:
+        return x
+    x = x.contiguous()
+    if dim != 0:
+        x = x.transpose(0, dim).contiguous()
+    if len(set(shard_sizes)) == 1:
+        out = x.new_empty((sum(shard_sizes),) + tuple(x.shape[1:]))
+        dist.all_gather_into_tensor(out, x, group=group)
+    else:
+        pad = max(shard_sizes)
+        buf = x.new_zeros((pad,) + tuple(x.shape[1:]))
+        buf[: x.shape[0]] = x
+        outs = x.new_empty((world * pad,) + tuple(x.shape[1:]))
+        dist.all_gather_into_tensor(outs, buf, group=group)
+        out = torch.cat([outs[r * pad: r * pad + n] for r, n in enumerate(shard_sizes)], dim=0)
+    if dim != 0:
+        out = out.transpose(0, dim).contiguous()
+    return out
+
+
+def all_to_all_rows(send: Tensor, send_counts: Sequence[int], recv_counts: Sequence[int], group) -> Tensor:
+    """Variable-count all-to-all over dim 0 of a packed [sum(send_counts), ...] buffer."""
+    recv = send.new_empty((sum(recv_counts),) + tuple(send.shape[1:]))
+    if dist.get_backend(group) == "gloo" and send.dim() > 1:
+        # gloo's all_to_all_single wants flattened element counts expressed in rows: supported for contiguous rows
+        pass
+    dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts), group=group)
+    return recv
+
+
+def halo_exchange(x: Tensor, send_index: Tensor, send_counts: Sequence[int], recv_counts: Sequence[int], group,
+                  gather_fn=None) -> Tensor:
+    """[n_local, D] -> [n_local + n_halo, D]: pack x[send_index] (one gather kernel), one all_to_all_single, append.
+
+    ``send_index``: concatenation over peers of the local row ids to send (int32 on device for the HIP gather).
+    ``gather_fn(x, idx)`` packs the send buffer (ops.gather_rows on the GPU)."""
+    if comm_size(group) == 1:
+        return x
+    packed = gather_fn(x, send_index) if gather_fn is not None else x.index_select(0, send_index.long())
+    recv = all_to_all_rows(packed, send_counts, recv_counts, group)
+    return torch.cat([x, recv], dim=0)
+
+
+def exchange_rows(x_local: Tensor, want_global_ids: Tensor, shard_sizes: Sequence[int], group, gather_fn=None,
+                  plan: Optional[dict] = None):
+    """Needed-rows exchange: every rank holds a contiguous shard of a [N, D] table and obtains the rows
+    ``want_global_ids`` (ascending global ids, any owner).  Two all-to-alls at plan time (ids), one per call (rows).
+    Returns (rows [len(want), D], plan) — pass ``plan`` back in to skip the id exchange (static graph)."""
+    world, rank = comm_size(group), comm_rank(group)
+    if world == 1:
+        rows = gather_fn(x_local, want_global_ids.to(torch.int32)) if gather_fn is not None else x_local.index_select(0, want_global_ids.long())
+        return rows, plan
+    if plan is None:
+        bounds = torch.cumsum(torch.tensor(shard_sizes, dtype=torch.long, device=want_global_ids.device), 0)
+        owner = torch.searchsorted(bounds, want_global_ids.long(), right=True)
+        recv_counts = torch.bincount(owner, minlength=world)
+        send_counts = torch.empty_like(recv_counts)
+        dist.all_to_all_single(send_counts, recv_counts, group=group)
+        recv_counts_l, send_counts_l = recv_counts.tolist(), send_counts.tolist()
+        # tell every owner which of its rows we want (ids are ascending, hence grouped by owner already)
+        starts = torch.cat([bounds.new_zeros(1), bounds[:-1]])
+        req_local = want_global_ids.long() - starts[owner]
+        asked = req_local.new_empty(sum(send_counts_l))
+        dist.all_to_all_single(asked, req_local.contiguous(), output_split_sizes=send_counts_l, input_split_sizes=recv_counts_l, group=group)
+        plan = dict(send_index=asked.to(torch.int32).contiguous(), send_counts=send_counts_l, recv_counts=recv_counts_l)
+    packed = gather_fn(x_local, plan["send_index"]) if gather_fn is not None else x_local.index_select(0, plan["send_index"].long())
+    rows = all_to_all_rows(packed, plan["send_counts"], plan["recv_counts"], group)
+    return rows, plan

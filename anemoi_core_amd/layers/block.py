@@ -1,0 +1,313 @@
+"""Message-passing blocks — mirror of reference layers/block.py (GraphTransformer{Mapper,Processor}Block :482-1273,
+GraphConv{Processor,Mapper}Block :293-479): same constructor keywords, forward signatures and state_dict keys, so a
+checkpoint of the reference loads unchanged.  The forward pass is a short chain of fused HIP kernels:
+
+  GT processor block (7 launches):  LN -> [q|k|v|self] GEMM -> edge attention (lin_edge fused, + self term)
+                                    -> projection GEMM (+ skip) -> LN -> MLP-1 GEMM (+GELU) -> MLP-2 GEMM (+ skip)
+
+instead of the reference's ~25 eager ops with [M, H, C] temporaries.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Union
+
+import torch
+from torch import Tensor, nn
+
+from .. import ops
+from ..distributed import primitives as comm
+from ..distributed.halo import HaloInfo, build_halo_info
+from ..distributed.partition import build_graph_partition_from_shard_info
+from ..distributed.shapes import BipartiteGraphShardInfo, GraphShardInfo, comm_rank, comm_size, model_is_distributed
+from .conv import GraphConv
+from .graphcache import get_csc, get_edge_features
+from .kernels import check_inference
+from .mlp import MLP
+from .utils import compute_mlp_hidden_dim
+
+ANEMOI_DEBUG_SHARDING = os.environ.get("ANEMOI_DEBUG_SHARDING", "") != ""
+
+
+class _FusedWeights:
+    """Concatenated projection weights ([Wq;Wk;Wv;Ws] ...) rebuilt only when a parameter changes."""
+
+    def __init__(self):
+        self._cache = {}
+
+    def get(self, tag: str, linears: list) -> tuple[Tensor, Tensor]:
+        ps = [p for lin in linears for p in (lin.weight, lin.bias) if p is not None]
+        sig = tuple((p.data_ptr(), p._version, p.dtype, str(p.device)) for p in ps)
+        hit = self._cache.get(tag)
+        if hit is not None and hit[0] == sig:
+            return hit[1], hit[2]
+        with torch.no_grad():
+            w = torch.cat([lin.weight for lin in linears], dim=0).contiguous()
+            b = torch.cat([lin.bias if lin.bias is not None else lin.weight.new_zeros(lin.out_features) for lin in linears]).contiguous()
+        self._cache[tag] = (sig, w, b)
+        return w, b
+
+
+class BaseBlock(nn.Module):
+    """Base class for network blocks."""
+
+
+# ============================================================================================ GraphTransformer blocks
+class GraphTransformerBaseBlock(BaseBlock):
+    def __init__(self, *, in_channels: int, hidden_dim: int, out_channels: int, num_heads: int, edge_dim: int,
+                 bias: bool = True, qk_norm: bool = False, mlp_implementation: str = "mlp", update_src_nodes: bool = False,
+                 layer_kernels, attn_channels: Optional[int] = None, graph_attention_backend: str = "hip",
+                 edge_pre_mlp: bool = False, **kwargs) -> None:
+        super().__init__()
+        self.update_src_nodes = update_src_nodes
+        self.attn_channels = out_channels if attn_channels is None else attn_channels
+        if self.attn_channels <= 0:
+            raise ValueError(f"attn_channels must be > 0, got {self.attn_channels}")
+        if self.attn_channels % num_heads != 0:
+            raise ValueError(f"attn_channels ({self.attn_channels}) must be divisible by num_heads ({num_heads}) in {self.__class__.__name__}.")
+        self.out_channels_conv = self.attn_channels // num_heads
+        self.num_heads = num_heads
+        self.qk_norm = qk_norm
+
+        Linear, LayerNorm = layer_kernels.Linear, layer_kernels.LayerNorm
+        A = num_heads * self.out_channels_conv
+        self.lin_key = Linear(in_channels, A)
+        self.lin_query = Linear(in_channels, A)
+        self.lin_value = Linear(in_channels, A)
+        self.lin_self = Linear(in_channels, A, bias=bias)
+        self.lin_edge = Linear(edge_dim, A)
+        self.projection = Linear(self.attn_channels, out_channels)
+        if self.qk_norm:
+            self.q_norm = layer_kernels.QueryNorm(self.out_channels_conv)
+            self.k_norm = layer_kernels.KeyNorm(self.out_channels_conv)
+        self.layer_norm_attention = LayerNorm(normalized_shape=in_channels)
+        self.layer_norm_mlp_dst = LayerNorm(normalized_shape=out_channels)
+        self.node_dst_mlp = MLP(in_features=out_channels, hidden_dim=hidden_dim, out_features=out_channels,
+                                layer_kernels=layer_kernels, n_extra_layers=0, layer_norm=False,
+                                mlp_implementation=mlp_implementation)
+        if edge_pre_mlp:  # build_feedforward_layer -> Sequential(Linear, GELU): keys edge_pre_mlp.0.* (mlp.py:55-95)
+            self.edge_pre_mlp = nn.Sequential(Linear(edge_dim, edge_dim), layer_kernels.Activation())
+        else:
+            self.edge_pre_mlp = nn.Identity()
+        # the reference's "triton" / "pyg" both map to the one HIP implementation
+        if graph_attention_backend not in ("hip", "triton", "pyg"):
+            raise ValueError(f"Backend '{graph_attention_backend}' not supported for GraphTransformerBlock")
+        self.graph_attention_backend = "hip"
+        self._fused = _FusedWeights()
+
+    # -- pieces ---------------------------------------------------------------------------------------------
+    def _attention(self, query: Tensor, key: Tensor, value: Tensor, x_r: Tensor, edge_attr: Tensor, csc: ops.CSC) -> Tensor:
+        """(attention output + x_r) [N_dst, A]; q/k/v may be column slices of a fused projection buffer."""
+        H, C = self.num_heads, self.out_channels_conv
+        if self.qk_norm:  # per-head LayerNorm over C, no bias (block.py:655-660)
+            query = self.q_norm(query.reshape(-1, H, C)).view(-1, H * C)
+            key = self.k_norm(key.reshape(-1, H, C)).view(-1, H * C)
+        if isinstance(self.edge_pre_mlp, nn.Identity):
+            feat = get_edge_features(edge_attr, csc.perm)
+        else:
+            lin = self.edge_pre_mlp[0]
+            ea = edge_attr if csc.perm is None else edge_attr.index_select(0, csc.perm)
+            ea = ops.linear(ea.to(lin.weight.dtype), lin.weight, lin.bias, act="gelu")
+            feat = ops.pack_edge_features(ea)
+        return ops.gt_attention_fused_edge(query, key, value, feat, self.lin_edge.weight, self.lin_edge.bias, csc, H, addend=x_r)
+
+    def _post_attention(self, attn_plus_self: Tensor, x_skip: Tensor) -> Tensor:
+        out = ops.linear(attn_plus_self, self.projection.weight, self.projection.bias, residual=x_skip)
+        ln = self.layer_norm_mlp_dst
+        h = ops.layer_norm(out, ln.weight, ln.bias, ln.eps)
+        return self.node_dst_mlp(h, residual=out)
+
+    @staticmethod
+    def _unsupported_cond(cond):
+        if cond is not None:
+            raise NotImplementedError("conditional LayerNorm (cond=...) is scope row f3 (next)")
+
+
+class GraphTransformerMapperBlock(GraphTransformerBaseBlock):
+    """Bipartite block: LN_src / LN_dst, q & self from dst, k & v from src, MLP on dst (block.py:870-1029)."""
+
+    def __init__(self, *, in_channels: int, hidden_dim: int, out_channels: int, num_heads: int, edge_dim: int,
+                 bias: bool = True, qk_norm: bool = False, mlp_implementation: str = "mlp", update_src_nodes: bool = False,
+                 layer_kernels, shard_strategy: str = "edges", graph_attention_backend: str = "hip",
+                 edge_pre_mlp: bool = False, **kwargs) -> None:
+        super().__init__(in_channels=in_channels, hidden_dim=hidden_dim, out_channels=out_channels, edge_dim=edge_dim,
+                         layer_kernels=layer_kernels, num_heads=num_heads, bias=bias, qk_norm=qk_norm,
+                         mlp_implementation=mlp_implementation, update_src_nodes=update_src_nodes,
+                         graph_attention_backend=graph_attention_backend, edge_pre_mlp=edge_pre_mlp, **kwargs)
+        LayerNorm = layer_kernels.LayerNorm
+        self.layer_norm_attention_src = LayerNorm(normalized_shape=in_channels)
+        self.layer_norm_attention_dest = self.layer_norm_attention  # alias: both keys appear in the state_dict
+        if self.update_src_nodes:
+            self.layer_norm_mlp_src = LayerNorm(normalized_shape=out_channels)
+            self.node_src_mlp = MLP(in_features=out_channels, hidden_dim=hidden_dim, out_features=out_channels,
+                                    layer_kernels=layer_kernels, n_extra_layers=0, layer_norm=False,
+                                    mlp_implementation=mlp_implementation)
+        else:
+            self.layer_norm_mlp_src = nn.Identity()
+            self.node_src_mlp = nn.Identity()
+        if shard_strategy not in ("edges", "heads"):
+            raise ValueError(f"Invalid shard strategy '{shard_strategy}'")
+        self.shard_strategy = shard_strategy
+
+    def forward(self, x, edge_attr: Tensor, edge_index: Tensor, shard_info: BipartiteGraphShardInfo, batch_size: int,
+                size, model_comm_group=None, cond=None, edges_are_dst_sorted: bool = True, **layer_kwargs):
+        self._unsupported_cond(cond)
+        if self.shard_strategy == "heads" and model_is_distributed(model_comm_group):
+            raise NotImplementedError("shard_strategy='heads' (Ulysses all-to-all) is scope row f2 (next); use 'edges'")
+        x_src, x_dst = x
+        check_inference(x_src, x_dst, edge_attr)
+        size = (size, size) if isinstance(size, int) else tuple(size)
+        csc = get_csc(edge_index, size, edges_are_dst_sorted)
+        A = self.attn_channels
+        ln_s, ln_d = self.layer_norm_attention_src, self.layer_norm_attention_dest
+        xs_n = ops.layer_norm(x_src, ln_s.weight, ln_s.bias, ln_s.eps)
+        xd_n = ops.layer_norm(x_dst, ln_d.weight, ln_d.bias, ln_d.eps)
+        w_qs, b_qs = self._fused.get("qs", [self.lin_query, self.lin_self])
+        w_kv, b_kv = self._fused.get("kv", [self.lin_key, self.lin_value])
+        qs = ops.linear(xd_n, w_qs, b_qs)
+        kv = ops.linear(xs_n, w_kv, b_kv)
+        out = self._attention(qs[:, :A], kv[:, :A], kv[:, A:], qs[:, A:], edge_attr, csc)
+        nodes_new_dst = self._post_attention(out, x_dst)
+        if self.update_src_nodes:
+            ln = self.layer_norm_mlp_src
+            nodes_new_src = self.node_src_mlp(ops.layer_norm(x_src, ln.weight, ln.bias, ln.eps), residual=x_src)
+        else:
+            nodes_new_src = x_src
+        return (nodes_new_src, nodes_new_dst), edge_attr
+
+
+class GraphTransformerProcessorBlock(GraphTransformerBaseBlock):
+    """Hidden-mesh block (block.py:1032-1273).  With a model-parallel group the LayerNorm'd rows of cut edges are
+    exchanged once per layer (halo), k/v are computed on local+halo rows and attention runs on the relabelled graph."""
+
+    def __init__(self, *, in_channels: int, hidden_dim: int, out_channels: int, num_heads: int, edge_dim: int,
+                 bias: bool = True, qk_norm: bool = False, mlp_implementation: str = "mlp", update_src_nodes: bool = False,
+                 layer_kernels, shard_strategy: str = "edges", graph_attention_backend: str = "hip",
+                 edge_pre_mlp: bool = False, **kwargs) -> None:
+        super().__init__(in_channels=in_channels, hidden_dim=hidden_dim, out_channels=out_channels, edge_dim=edge_dim,
+                         layer_kernels=layer_kernels, num_heads=num_heads, bias=bias, qk_norm=qk_norm,
+                         mlp_implementation=mlp_implementation, update_src_nodes=update_src_nodes,
+                         graph_attention_backend=graph_attention_backend, edge_pre_mlp=edge_pre_mlp, **kwargs)
+        if shard_strategy not in ("edges", "heads"):
+            raise ValueError(f"Invalid shard strategy '{shard_strategy}'")
+        self.shard_strategy = shard_strategy
+        self._cached_halo = None  # (specs, HaloPlan)
+
+    def _halo_plan(self, x: Tensor, edge_index: Tensor, shard_info: GraphShardInfo, batch_size: int, group, shared: Optional[dict]):
+        if batch_size != 1:
+            raise ValueError("GraphTransformerProcessorBlock halo exchange requires batch_size=1 when model sharding is enabled.")
+        specs = (comm_size(group), comm_rank(group), tuple(shard_info.nodes or ()), tuple(shard_info.edges or ()),
+                 edge_index.data_ptr(), edge_index._version)
+        if shared is not None and shared.get("specs") == specs:
+            return shared["plan"]
+        if self._cached_halo is not None and self._cached_halo[0] == specs:
+            return self._cached_halo[1]
+        assert shard_info.edges_are_sharded(), "Halo strategy requires edges to be sharded"
+        bip = BipartiteGraphShardInfo(src_nodes=shard_info.nodes, dst_nodes=shard_info.nodes, edges=shard_info.edges)
+        partition = build_graph_partition_from_shard_info(edge_index, (x, x), bip, group)
+        plan = HaloPlan(build_halo_info(partition, edge_index, comm_rank(group), edges_are_local=True, debug=ANEMOI_DEBUG_SHARDING))
+        self._cached_halo = (specs, plan)
+        if shared is not None:
+            shared["specs"], shared["plan"] = specs, plan
+        return plan
+
+    def forward(self, x: Tensor, edge_attr: Tensor, edge_index: Tensor, shard_info: GraphShardInfo, batch_size: int,
+                size, model_comm_group=None, cond=None, edges_are_dst_sorted: bool = True, halo_cache: Optional[dict] = None,
+                **kwargs):
+        self._unsupported_cond(cond)
+        check_inference(x, edge_attr)
+        A = self.attn_channels
+        ln = self.layer_norm_attention
+        xn = ops.layer_norm(x, ln.weight, ln.bias, ln.eps)
+        if model_is_distributed(model_comm_group):
+            if self.shard_strategy != "edges":
+                raise NotImplementedError("shard_strategy='heads' (Ulysses all-to-all) is scope row f2 (next); use 'edges'")
+            plan = self._halo_plan(x, edge_index, shard_info, batch_size, model_comm_group, halo_cache)
+            x_plus_halo = comm.halo_exchange(xn, plan.send_index, plan.send_counts, plan.recv_counts, model_comm_group,
+                                             gather_fn=ops.gather_rows)
+            w_qs, b_qs = self._fused.get("qs", [self.lin_query, self.lin_self])
+            w_kv, b_kv = self._fused.get("kv", [self.lin_key, self.lin_value])
+            qs = ops.linear(xn, w_qs, b_qs)
+            kv = ops.linear(x_plus_halo, w_kv, b_kv)
+            q, k, v, x_r = qs[:, :A], kv[:, :A], kv[:, A:], qs[:, A:]
+            csc = get_csc(plan.edge_index_local, (plan.info.total_nodes, plan.info.num_local_nodes), True)
+        else:
+            n = x.shape[0]
+            w, b = self._fused.get("qkvs", [self.lin_query, self.lin_key, self.lin_value, self.lin_self])
+            qkvs = ops.linear(xn, w, b)
+            q, k, v, x_r = qkvs[:, :A], qkvs[:, A:2 * A], qkvs[:, 2 * A:3 * A], qkvs[:, 3 * A:]
+            csc = get_csc(edge_index, (n, n), edges_are_dst_sorted)
+        out = self._attention(q, k, v, x_r, edge_attr, csc)
+        return self._post_attention(out, x), edge_attr
+
+
+class HaloPlan:
+    """HaloInfo + the device-side buffers the exchange needs (built once, reused by every layer and step)."""
+
+    def __init__(self, info: HaloInfo):
+        self.info = info
+        dev = info.edge_index_local.device
+        idx = torch.cat(list(info.send_indices)) if len(info.send_indices) else torch.zeros(0, dtype=torch.long, device=dev)
+        self.send_index = idx.to(torch.int32).contiguous()
+        self.send_counts = list(info.send_counts)
+        self.recv_counts = list(info.recv_counts)
+        self.edge_index_local = info.edge_index_local
+
+
+# ============================================================================================ GraphConv (GNN) blocks
+class GraphConvBaseBlock(BaseBlock):
+    def __init__(self, *, in_channels: int, out_channels: int, num_chunks: int, mlp_extra_layers: int = 0,
+                 mlp_hidden_ratio: float = 1.0, mlp_implementation: str = "mlp", update_src_nodes: bool = True,
+                 layer_kernels, edge_dim: Optional[int] = None, **kwargs) -> None:
+        super().__init__()
+        hidden_dim = compute_mlp_hidden_dim(out_channels, mlp_hidden_ratio)
+        if edge_dim:
+            self.emb_edges = MLP(in_features=edge_dim, hidden_dim=hidden_dim, out_features=out_channels,
+                                 layer_kernels=layer_kernels, n_extra_layers=mlp_extra_layers + 1,
+                                 mlp_implementation=mlp_implementation)
+        else:
+            self.emb_edges = None
+        self.update_src_nodes = update_src_nodes
+        self.num_chunks = num_chunks  # memory chunking is unnecessary with 288 GB of HBM; kept for API compatibility
+        self.node_mlp = MLP(in_features=2 * in_channels, hidden_dim=hidden_dim, out_features=out_channels,
+                            layer_kernels=layer_kernels, n_extra_layers=mlp_extra_layers + 1,
+                            mlp_implementation=mlp_implementation)
+        self.conv = GraphConv(in_channels=in_channels, out_channels=out_channels, layer_kernels=layer_kernels,
+                              mlp_extra_layers=mlp_extra_layers, mlp_implementation=mlp_implementation)
+
+
+class GraphConvProcessorBlock(GraphConvBaseBlock):
+    def forward(self, x: Tensor, edge_attr: Tensor, edge_index: Tensor, shard_info: GraphShardInfo, model_comm_group=None,
+                size=None, **layer_kwargs):
+        check_inference(x, edge_attr)
+        if self.emb_edges is not None:
+            edge_attr = self.emb_edges(edge_attr)
+        if model_is_distributed(model_comm_group):  # block.py:375: all node rows are needed as sources
+            x_in = comm.gather_tensor(x, 0, shard_info.nodes, model_comm_group)
+            n_loc = x.shape[0]
+            d0 = sum(shard_info.nodes[: comm_rank(model_comm_group)])
+            out_full, edges_new = self._conv_sharded(x_in, x, d0, edge_attr, edge_index)
+            out = out_full
+            assert out.shape[0] == n_loc
+        else:
+            out, edges_new = self.conv(x, edge_attr, edge_index, size=size)
+        nodes_new = self.node_mlp(x, x2=out, residual=x)
+        return nodes_new, edges_new
+
+    def _conv_sharded(self, x_all: Tensor, x_loc: Tensor, d0: int, edge_attr: Tensor, edge_index: Tensor):
+        # local edges carry GLOBAL ids: sources index the gathered table, destinations are shifted to local rows
+        ei = torch.stack([edge_index[0], edge_index[1] - d0])
+        return self.conv((x_all, x_loc), edge_attr, ei, size=(x_all.shape[0], x_loc.shape[0]))
+
+
+class GraphConvMapperBlock(GraphConvBaseBlock):
+    def forward(self, x, edge_attr: Tensor, edge_index: Tensor, shard_info: BipartiteGraphShardInfo, model_comm_group=None,
+                size=None, **layer_kwargs):
+        x_src, x_dst = x
+        check_inference(x_src, x_dst, edge_attr)
+        if model_is_distributed(model_comm_group):
+            raise NotImplementedError("sharded GNN mappers are not implemented yet (GraphTransformer mappers are)")
+        out, edges_new = self.conv((x_src, x_dst), edge_attr, edge_index, size=size)
+        nodes_new_dst = self.node_mlp(x_dst, x2=out, residual=x_dst)
+        nodes_new_src = self.node_mlp(x_src, x2=x_src, residual=x_src) if self.update_src_nodes else x_src
+        return (nodes_new_src, nodes_new_dst), edges_new

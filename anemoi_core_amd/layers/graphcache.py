@@ -1,0 +1,60 @@
+"""Static-graph caches.  The reference recomputes CSC / reverse-CSR (an argsort over M), dst-degree partitions
+(host syncs) and ``torch.unique`` relabelling on EVERY forward although the graph never changes (SURVEY.md §7
+"legitimate wins"); here each structure is derived once per (edge_index tensor, size) and reused by all layers."""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from .. import ops
+
+
+class _LRU:
+    def __init__(self, maxsize: int = 16):
+        self.maxsize = maxsize
+        self.data: OrderedDict = OrderedDict()
+
+    def get(self, key, anchor: Tensor, build):
+        hit = self.data.get(key)
+        # the key holds (data_ptr, version, shape); the anchor tensor is kept alive in the entry, so its storage
+        # cannot be recycled for another tensor while the entry exists
+        if hit is not None:
+            self.data.move_to_end(key)
+            return hit[1]
+        val = build()
+        self.data[key] = (anchor, val)
+        self.data.move_to_end(key)
+        while len(self.data) > self.maxsize:
+            self.data.popitem(last=False)
+        return val
+
+
+_csc_cache = _LRU()
+_feat_cache = _LRU()
+
+
+def _key(t: Tensor, *extra):
+    return (t.data_ptr(), t._version, tuple(t.shape), str(t.device), t.dtype, *extra)
+
+
+def get_csc(edge_index: Tensor, size: tuple, edges_are_dst_sorted: bool = True) -> ops.CSC:
+    size = (int(size[0]), int(size[1]))
+    return _csc_cache.get(_key(edge_index, size, bool(edges_are_dst_sorted)), edge_index,
+                          lambda: ops.build_csc(edge_index, size, edges_are_dst_sorted))
+
+
+def get_edge_features(edge_attr: Tensor, perm: Optional[Tensor] = None) -> Tensor:
+    """Packed fp32 edge features for the fused attention (depends on edge_attr only, shared by all layers)."""
+    def build():
+        ea = edge_attr if perm is None else edge_attr.index_select(0, perm)
+        return ops.pack_edge_features(ea)
+
+    return _feat_cache.get(_key(edge_attr, None if perm is None else perm.data_ptr()), edge_attr, build)
+
+
+def clear() -> None:
+    _csc_cache.data.clear()
+    _feat_cache.data.clear()

@@ -1,0 +1,56 @@
+"""``layer_kernels`` building blocks backed by the HIP library.
+
+The reference lets a config swap the Linear / LayerNorm / Activation classes through ``layer_kernels`` ``_target_``
+strings (models/src/anemoi/models/layers/utils.py:87-142).  These classes are those plug-ins for MI355X: they subclass
+the torch modules (identical parameters, initialisation and state_dict keys) and override ``forward`` with one fused
+kernel launch.  They also work stand-alone inside the unmodified reference blocks.
+"""
+from __future__ import annotations
+
+import torch
+from torch import Tensor, nn
+
+from .. import ops
+
+
+def check_inference(*tensors: Tensor) -> None:
+    """Forward-only for now: the backward kernels are SURVEY.md §8 row f1 ("next")."""
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        raise NotImplementedError(
+            "anemoi_core_amd implements the forward pass only (backward kernels are the next scope row); "
+            "run under torch.no_grad() / torch.inference_mode()."
+        )
+
+
+class Linear(nn.Linear):
+    """torch.nn.Linear parameters, MFMA forward (bias fused)."""
+
+    def forward(self, x: Tensor) -> Tensor:  # noqa: D102
+        check_inference(x, self.weight)
+        y = ops.linear(x.reshape(-1, x.shape[-1]), self.weight, self.bias)
+        return y.view(*x.shape[:-1], self.out_features)
+
+
+class LayerNorm(nn.LayerNorm):
+    """torch.nn.LayerNorm parameters (1-D normalized_shape), one-pass wave-per-row forward with fp32 statistics."""
+
+    def __init__(self, normalized_shape, eps: float = 1e-5, elementwise_affine: bool = True, bias: bool = True, **kw):
+        super().__init__(normalized_shape, eps=eps, elementwise_affine=elementwise_affine, bias=bias, **kw)
+        if len(self.normalized_shape) != 1 or not elementwise_affine:
+            raise NotImplementedError("only affine LayerNorm over the last dimension is supported")
+
+    def forward(self, x: Tensor, residual: Tensor | None = None) -> Tensor:  # noqa: D102
+        check_inference(x, self.weight)
+        return ops.layer_norm(x, self.weight, self.bias, self.eps, residual)
+
+
+class AutocastLayerNorm(LayerNorm):
+    """Reference layers/normalization.py:19-31: output in the input dtype — always true for the HIP kernel."""
+
+
+class GELU(nn.GELU):
+    """Exact (erf) GELU marker module.  MLP / blocks fuse it into the preceding Linear's epilogue; there is no
+    stand-alone GELU launch in the product path."""
+
+    def forward(self, x: Tensor) -> Tensor:  # noqa: D102
+        raise NotImplementedError("GELU is fused into the preceding Linear (anemoi_core_amd.layers.mlp.MLP)")

@@ -1,0 +1,263 @@
+"""Mappers (encoder data->hidden, decoder hidden->data) — mirror of reference layers/mapper.py
+(GraphTransformerBaseMapper :142-477, Forward :480-597, Backward :600-704, GNN mappers :707-1087): same constructor
+keywords, forward signatures and state_dict keys.
+
+Differences that do not change results:
+ * the reference's dst-range chunk loop (``num_chunks``, mapper.py:365-381) exists to bound activation memory on
+   smaller GPUs; with 288 GB of HBM the whole bipartite graph is processed in one pass (``num_chunks`` is accepted and
+   ignored);
+ * when sharded, only the source rows this rank's edges touch are fetched (local gather if the source table is
+   replicated, a needed-rows all-to-all if it is sharded) instead of all-gathering every source row
+   (khop_edges.py:386-392); unconnected sources are never embedded (as in the reference, khop_edges.py:474-500);
+ * slicing / ``unique`` / relabelling of the static graph is done once and cached.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import Tensor, nn
+
+from .. import ops
+from ..distributed import primitives as comm
+from ..distributed.partition import (
+    build_graph_partition_from_shard_info,
+    ensure_edges_are_dst_sorted,
+    local_bipartite_graph,
+    shard_edges_1hop,
+)
+from ..distributed.shapes import BipartiteGraphShardInfo, comm_rank, comm_size, model_is_distributed
+from .block import GraphConvMapperBlock, GraphTransformerMapperBlock
+from .kernels import check_inference
+from .mlp import MLP
+from .utils import compute_mlp_hidden_dim, load_layer_kernels
+
+
+class BaseMapper(nn.Module):
+    def __init__(self, *, in_channels_src: int, in_channels_dst: int, hidden_dim: int, out_channels_dst: Optional[int] = None,
+                 cpu_offload: bool = False, gradient_checkpointing: bool = True, layer_kernels=None, **kwargs) -> None:
+        super().__init__()
+        self.in_channels_src = in_channels_src
+        self.in_channels_dst = in_channels_dst
+        self.hidden_dim = hidden_dim
+        self.out_channels_dst = out_channels_dst
+        self.gradient_checkpointing = gradient_checkpointing
+        self.layer_factory = load_layer_kernels(layer_kernels)
+        if cpu_offload:
+            raise NotImplementedError("cpu_offload is a training memory feature; not needed with 288 GB of HBM")
+
+
+class _LocalGraphCache:
+    """Per-mapper cache of the rank-local bipartite graph (static)."""
+
+    def __init__(self):
+        self.key = None
+        self.val = None
+
+    def get(self, key, build):
+        if self.key != key:
+            self.val = build()
+            self.key = key
+        return self.val
+
+
+class GraphTransformerBaseMapper(BaseMapper):
+    def __init__(self, *, in_channels_src: int, in_channels_dst: int, hidden_dim: int, out_channels_dst: Optional[int] = None,
+                 num_chunks: int, num_heads: int, mlp_hidden_ratio: float, edge_dim: int, attn_channels: Optional[int] = None,
+                 qk_norm: bool = False, mlp_implementation: str = "mlp", cpu_offload: bool = False, layer_kernels=None,
+                 shard_strategy: str = "edges", graph_attention_backend: str = "hip", edge_pre_mlp: bool = False, **kwargs) -> None:
+        super().__init__(in_channels_src=in_channels_src, in_channels_dst=in_channels_dst, hidden_dim=hidden_dim,
+                         out_channels_dst=out_channels_dst, cpu_offload=cpu_offload, layer_kernels=layer_kernels, **kwargs)
+        self.num_chunks = num_chunks
+        assert shard_strategy in ["heads", "edges"], (
+            f"Invalid shard strategy '{shard_strategy}' for {self.__class__.__name__}. Supported strategies are 'heads' and 'edges'."
+        )
+        self.shard_strategy = shard_strategy
+        self.proc = GraphTransformerMapperBlock(
+            in_channels=hidden_dim, hidden_dim=compute_mlp_hidden_dim(hidden_dim, mlp_hidden_ratio), out_channels=hidden_dim,
+            attn_channels=attn_channels, num_heads=num_heads, edge_dim=edge_dim, qk_norm=qk_norm,
+            mlp_implementation=mlp_implementation, layer_kernels=self.layer_factory, shard_strategy=shard_strategy,
+            graph_attention_backend=graph_attention_backend, edge_pre_mlp=edge_pre_mlp,
+        )
+        self.emb_nodes_dst = self.layer_factory.Linear(self.in_channels_dst, self.hidden_dim)
+        self._local = _LocalGraphCache()
+        self._plan = None
+
+    # subclasses: pre_process(x_src_compact, x_dst) -> embedded pair, post_process(x_dst)
+    def _local_graph(self, x, shard_info, edge_attr, edge_index, group):
+        """Rank-local (dst range, edges, compact sources) — index work only, cached for the static graph."""
+        world, rank = comm_size(group), comm_rank(group)
+        key = (edge_index.data_ptr(), edge_index._version, edge_attr.data_ptr(), edge_attr._version, world, rank,
+               tuple(shard_info.src_nodes or ()), tuple(shard_info.dst_nodes or ()), tuple(shard_info.edges or ()),
+               x[0].shape[0], x[1].shape[0])
+
+        def build():
+            partition = build_graph_partition_from_shard_info(edge_index, x, shard_info, group)
+            if shard_info.edges_are_sharded():  # edge_index already holds this rank's edges (global ids)
+                dr = partition.dst_range(rank)
+                loc = edge_index.long()
+                src_ids, inv = torch.unique(loc[0], return_inverse=True)
+                ei_local = torch.stack([inv, loc[1] - dr.start])
+                ea_local = edge_attr
+            else:
+                lg = local_bipartite_graph(edge_index, partition, rank)
+                src_ids, ei_local = lg.src_ids, lg.edge_index_local
+                ea_local = edge_attr[lg.edge_range[0]: lg.edge_range[1]]
+                dr = slice(*lg.dst_range)
+            n_src_total = partition.num_nodes[0]
+            all_connected = src_ids.shape[0] == n_src_total
+            return dict(partition=partition, dst_range=(dr.start, dr.stop), src_ids=src_ids, src_ids32=src_ids.to(torch.int32).contiguous(),
+                        edge_index=ei_local.contiguous(), edge_attr=ea_local, all_connected=all_connected,
+                        anchors=(edge_index, edge_attr))
+
+        return self._local.get(key, build)
+
+    def forward(self, x, batch_size: int, shard_info: BipartiteGraphShardInfo, edge_attr: Tensor, edge_index: Tensor,
+                model_comm_group=None, keep_x_dst_sharded: bool = False, edges_are_dst_sorted: bool = True, cond=None, **kwargs):
+        if cond is not None:
+            raise NotImplementedError("conditional LayerNorm (cond=...) is scope row f3 (next)")
+        if self.shard_strategy == "heads" and model_is_distributed(model_comm_group):
+            raise NotImplementedError("shard_strategy='heads' (Ulysses all-to-all) is scope row f2 (next); use 'edges'")
+        x_src, x_dst = x
+        check_inference(x_src, x_dst, edge_attr)
+        edge_attr, edge_index = ensure_edges_are_dst_sorted(
+            edge_attr, edge_index, edges_are_sharded=shard_info.edges_are_sharded(), model_comm_group=model_comm_group,
+            edges_are_dst_sorted=edges_are_dst_sorted)
+        g = self._local_graph(x, shard_info, edge_attr, edge_index, model_comm_group)
+        d0, d1 = g["dst_range"]
+        sharded = model_is_distributed(model_comm_group)
+        if sharded and not shard_info.dst_is_sharded():
+            x_dst = x_dst[d0:d1]
+        # source rows this rank needs
+        if sharded and shard_info.src_is_sharded():
+            x_src_c, self._plan = comm.exchange_rows(x_src, g["src_ids"], shard_info.src_nodes, model_comm_group,
+                                                     gather_fn=ops.gather_rows, plan=self._plan)
+        elif g["all_connected"]:
+            x_src_c = x_src
+        else:
+            x_src_c = ops.gather_rows(x_src, g["src_ids32"])
+        xs, xd = self.pre_process((x_src_c, x_dst))
+        (_, x_dst_out), _ = self.proc((xs, xd), g["edge_attr"], g["edge_index"], shard_info, batch_size,
+                                      (xs.shape[0], xd.shape[0]), model_comm_group, edges_are_dst_sorted=True, **kwargs)
+        out_dst = self.post_process(x_dst_out)
+        if sharded and not keep_x_dst_sharded:
+            out_dst = comm.gather_tensor(out_dst, 0, g["partition"].dst_splits, model_comm_group)
+        return out_dst
+
+
+class GraphTransformerForwardMapper(GraphTransformerBaseMapper):
+    """Graph Transformer Mapper from data -> hidden."""
+
+    def __init__(self, *, out_channels_dst: Optional[int] = None, **kwargs) -> None:
+        assert out_channels_dst is None, "GraphTransformerForwardMapper does not support out_channels_dst."
+        super().__init__(out_channels_dst=None, **kwargs)
+        self.emb_nodes_src = self.layer_factory.Linear(self.in_channels_src, self.hidden_dim)
+
+    def pre_process(self, x):
+        x_src, x_dst = x
+        return (ops.linear(x_src, self.emb_nodes_src.weight, self.emb_nodes_src.bias),
+                ops.linear(x_dst, self.emb_nodes_dst.weight, self.emb_nodes_dst.bias))
+
+    def post_process(self, x_dst, **kwargs):
+        return x_dst
+
+    def forward(self, x, batch_size: int, shard_info: BipartiteGraphShardInfo, edge_attr: Tensor, edge_index: Tensor,
+                model_comm_group=None, keep_x_dst_sharded: bool = True, **kwargs):
+        x_dst = super().forward(x, batch_size, shard_info, edge_attr, edge_index, model_comm_group, keep_x_dst_sharded, **kwargs)
+        return x[0], x_dst
+
+
+class GraphTransformerBackwardMapper(GraphTransformerBaseMapper):
+    """Graph Transformer Mapper from hidden -> data."""
+
+    def __init__(self, *, out_channels_dst: Optional[int] = None, initialise_data_extractor_zero: bool = False, **kwargs) -> None:
+        super().__init__(out_channels_dst=out_channels_dst, **kwargs)
+        self.node_data_extractor = nn.Sequential(self.layer_factory.LayerNorm(self.hidden_dim),
+                                                 self.layer_factory.Linear(self.hidden_dim, self.out_channels_dst))
+        if initialise_data_extractor_zero:
+            for module in self.node_data_extractor.modules():
+                if isinstance(module, nn.Linear):
+                    nn.init.constant_(module.weight, 0.0)
+                    if module.bias is not None:
+                        nn.init.constant_(module.bias, 0.0)
+
+    def pre_process(self, x):
+        x_src, x_dst = x
+        return x_src, ops.linear(x_dst, self.emb_nodes_dst.weight, self.emb_nodes_dst.bias)
+
+    def post_process(self, x_dst):
+        ln, lin = self.node_data_extractor[0], self.node_data_extractor[1]
+        return ops.linear(ops.layer_norm(x_dst, ln.weight, ln.bias, ln.eps), lin.weight, lin.bias)
+
+
+# ============================================================================================ GNN mappers
+class GNNBaseMapper(BaseMapper):
+    def __init__(self, *, in_channels_src: int, in_channels_dst: int, hidden_dim: int, out_channels_dst: Optional[int] = None,
+                 num_chunks: int, mlp_extra_layers: int, edge_dim: int, mlp_hidden_ratio: float = 1.0,
+                 mlp_implementation: str = "mlp", cpu_offload: bool = False, layer_kernels=None, **kwargs) -> None:
+        super().__init__(in_channels_src=in_channels_src, in_channels_dst=in_channels_dst, hidden_dim=hidden_dim,
+                         out_channels_dst=out_channels_dst, cpu_offload=cpu_offload, layer_kernels=layer_kernels, **kwargs)
+        self._mlp_hidden_dim = compute_mlp_hidden_dim(hidden_dim, mlp_hidden_ratio)
+        self._mlp_kw = dict(layer_kernels=self.layer_factory, n_extra_layers=mlp_extra_layers + 1, mlp_implementation=mlp_implementation)
+        self.emb_edges = MLP(in_features=edge_dim, hidden_dim=self._mlp_hidden_dim, out_features=hidden_dim, **self._mlp_kw)
+        self._block_kw = dict(in_channels=hidden_dim, out_channels=hidden_dim, layer_kernels=self.layer_factory,
+                              mlp_extra_layers=mlp_extra_layers, mlp_hidden_ratio=mlp_hidden_ratio,
+                              mlp_implementation=mlp_implementation, num_chunks=num_chunks)
+
+    def mapper_forward(self, x, batch_size, shard_info, edge_attr, edge_index, model_comm_group=None,
+                       keep_x_dst_sharded: bool = False, edges_are_dst_sorted: bool = True, **kwargs):
+        if model_is_distributed(model_comm_group):
+            raise NotImplementedError("sharded GNN mappers are not implemented yet (GraphTransformer mappers are)")
+        x_src, x_dst = x
+        check_inference(x_src, x_dst, edge_attr)
+        edge_attr, edge_index = ensure_edges_are_dst_sorted(edge_attr, edge_index, edges_are_sharded=False,
+                                                           edges_are_dst_sorted=edges_are_dst_sorted)
+        size = (x_src.shape[0], x_dst.shape[0])
+        edge_attr = self.emb_edges(edge_attr)
+        x_src, x_dst = self.pre_process((x_src, x_dst))
+        (x_src, x_dst), edge_attr = self.proc((x_src, x_dst), edge_attr, edge_index, shard_info, model_comm_group, size=size, **kwargs)
+        return x_src, self.post_process(x_dst)
+
+    def forward(self, x, batch_size: int, shard_info: BipartiteGraphShardInfo, edge_attr: Tensor, edge_index: Tensor,
+                model_comm_group=None, keep_x_dst_sharded: bool = False, edges_are_dst_sorted: bool = True, **kwargs):
+        return self.mapper_forward(x, batch_size, shard_info, edge_attr, edge_index, model_comm_group, keep_x_dst_sharded,
+                                   edges_are_dst_sorted, **kwargs)
+
+
+class GNNForwardMapper(GNNBaseMapper):
+    """Graph Neural Network Mapper data -> hidden."""
+
+    def __init__(self, **kwargs) -> None:
+        super().__init__(**kwargs)
+        self.proc = GraphConvMapperBlock(update_src_nodes=True, **self._block_kw)
+        self.emb_nodes_src = MLP(in_features=self.in_channels_src, hidden_dim=self._mlp_hidden_dim, out_features=self.hidden_dim, **self._mlp_kw)
+        self.emb_nodes_dst = MLP(in_features=self.in_channels_dst, hidden_dim=self._mlp_hidden_dim, out_features=self.hidden_dim, **self._mlp_kw)
+
+    def pre_process(self, x):
+        return self.emb_nodes_src(x[0]), self.emb_nodes_dst(x[1])
+
+    def post_process(self, x_dst, **kwargs):
+        return x_dst
+
+
+class GNNBackwardMapper(GNNBaseMapper):
+    """Graph Neural Network Mapper hidden -> data."""
+
+    def __init__(self, **kwargs) -> None:
+        super().__init__(**kwargs)
+        self.proc = GraphConvMapperBlock(update_src_nodes=False, **self._block_kw)
+        self.node_data_extractor = MLP(in_features=self.hidden_dim, hidden_dim=self._mlp_hidden_dim, out_features=self.out_channels_dst,
+                                       layer_kernels=self.layer_factory, n_extra_layers=self._mlp_kw["n_extra_layers"],
+                                       layer_norm=False, final_activation=False, mlp_implementation=self._mlp_kw["mlp_implementation"])
+
+    def pre_process(self, x):
+        return x
+
+    def post_process(self, x_dst):
+        return self.node_data_extractor(x_dst)
+
+    def forward(self, x, batch_size: int, shard_info: BipartiteGraphShardInfo, edge_attr: Tensor, edge_index: Tensor,
+                model_comm_group=None, keep_x_dst_sharded: bool = False, edges_are_dst_sorted: bool = True, **kwargs) -> Tensor:
+        _, x_dst = super().forward(x, batch_size, shard_info, edge_attr, edge_index, model_comm_group, keep_x_dst_sharded,
+                                   edges_are_dst_sorted=edges_are_dst_sorted, **kwargs)
+        return x_dst

@@ -1,0 +1,189 @@
+"""AnemoiModelEncProcDec — mirror of the reference glue (models/src/anemoi/models/models/encoder_processor_decoder.py
+:33-340 and models/base.py:38-395) for the graph (GraphTransformer / GNN) model family: same constructor arguments,
+``forward(x: {name: [B,T,E,N,V]}, model_comm_group=None, grid_shard_sizes=None)`` and state_dict keys
+(``encoder.<ds>.*``, ``processor.*``, ``decoder.<ds>.*``, ``node_attributes.*``, ``*_graph_provider.*``).
+
+``model_config`` is the reference's nested config (attribute dict).  ``_target_`` strings may name either this
+package's classes or the reference's ``anemoi.models.layers.*`` classes (rewritten to the MI355X implementations), so an
+existing config selects the HIP path without edits.  Residual = SkipConnection (step), boundings: ReluBounding only.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import Tensor, nn
+
+from ..distributed.primitives import shard_tensor
+from ..distributed.shapes import BipartiteGraphShardInfo, GraphShardInfo, comm_size, get_shard_sizes
+from ..layers.graph import NamedNodesAttributes
+from ..layers.graph_provider import create_graph_provider
+from ..utils.config import DotDict, instantiate
+
+_REF_PREFIX = "anemoi.models.layers."
+_OUR_PREFIX = "anemoi_core_amd.layers."
+
+
+def _retarget(cfg) -> dict:
+    cfg = dict(cfg)
+    t = cfg.get("_target_", "")
+    if isinstance(t, str) and t.startswith(_REF_PREFIX):
+        cfg["_target_"] = _OUR_PREFIX + t[len(_REF_PREFIX):]
+    return cfg
+
+
+def _graph_views(graph_data):
+    """Accept the synthetic generator's ``SyntheticGraph`` or a HeteroData-like object (``g[name].x``,
+    ``g[(src,'to',dst)].edge_index / edge_length / edge_dirs``)."""
+    if hasattr(graph_data, "enc_edge_index"):  # SyntheticGraph
+        g = graph_data
+        nodes = {"data": torch.as_tensor(g.data_latlon), "hidden": torch.as_tensor(g.hidden_latlon)}
+        mk = lambda ei, ea: {"edge_index": torch.as_tensor(ei), "edge_length": torch.as_tensor(ea[:, :1]), "edge_dirs": torch.as_tensor(ea[:, 1:])}  # noqa: E731
+        edges = {("data", "to", "hidden"): mk(g.enc_edge_index, g.enc_edge_attr),
+                 ("hidden", "to", "hidden"): mk(g.proc_edge_index, g.proc_edge_attr),
+                 ("hidden", "to", "data"): mk(g.dec_edge_index, g.dec_edge_attr)}
+        return nodes, edges
+
+    class _Edges(dict):
+        def __missing__(self, key):
+            return graph_data[key]
+
+    nodes = {name: torch.as_tensor(graph_data[name].x) for name in graph_data.node_types}
+    return nodes, _Edges()
+
+
+class AnemoiModelEncProcDec(nn.Module):
+    def __init__(self, *, model_config, data_indices: dict, statistics: Optional[dict] = None, n_step_input: int,
+                 n_step_output: int, graph_data) -> None:
+        super().__init__()
+        model_config = model_config if isinstance(model_config, DotDict) else DotDict(model_config)
+        mc = model_config.model
+        self.data_indices = data_indices
+        self.statistics = statistics
+        self.n_step_input = n_step_input
+        self.n_step_output = n_step_output
+        self.dataset_names = list(data_indices.keys())
+        self._graph_name_hidden = mc.model.hidden_nodes_name
+        self.num_channels = mc.num_channels
+        self.latent_skip = mc.model.latent_skip
+        if not isinstance(self._graph_name_hidden, str):
+            raise NotImplementedError("hierarchical hidden node lists belong to another model family")
+        nodes, edges = _graph_views(graph_data)
+        tp = dict(mc.trainable_parameters)
+        self.node_attributes = NamedNodesAttributes(
+            {**{ds: tp.get("data", 0) for ds in self.dataset_names}, self._graph_name_hidden: tp.get("hidden", 0)},
+            {**{ds: nodes[ds] for ds in self.dataset_names}, self._graph_name_hidden: nodes[self._graph_name_hidden]},
+        )
+        self._calculate_shapes_and_indices(data_indices)
+        self._build_networks(mc, edges)
+        res = mc.get("residual", {}) or {}
+        self._skip_step = int(res.get("step", -1))
+        self._relu_bounding_idx = self._build_boundings(mc.get("bounding", []) or [])
+
+    # -- shapes (models/base.py:96-150) -------------------------------------------------------------------
+    def _calculate_shapes_and_indices(self, data_indices: dict) -> None:
+        self.num_input_channels, self.num_output_channels = {}, {}
+        self._internal_input_idx, self._internal_output_idx = {}, {}
+        self.input_dim, self.target_dim, self.output_dim = {}, {}, {}
+        self.input_dim_latent = self.node_attributes.attr_ndims[self._graph_name_hidden]
+        for ds, idx in data_indices.items():
+            self._internal_input_idx[ds] = list(idx.model.input.prognostic)
+            self._internal_output_idx[ds] = list(idx.model.output.prognostic)
+            self.num_input_channels[ds] = len(idx.model.input)
+            self.num_output_channels[ds] = len(idx.model.output)
+            self.input_dim[ds] = self.n_step_input * self.num_input_channels[ds] + self.node_attributes.attr_ndims[ds]
+            self.target_dim[ds] = self.input_dim[ds]
+            self.output_dim[ds] = self.n_step_output * self.num_output_channels[ds]
+            assert len(self._internal_input_idx[ds]) == len(self._internal_output_idx[ds])
+
+    def _build_networks(self, mc, edges) -> None:
+        hid = self._graph_name_hidden
+        n = self.node_attributes.num_nodes
+        self.encoder_graph_provider, self.encoder = nn.ModuleDict(), nn.ModuleDict()
+        for ds in self.dataset_names:
+            self.encoder_graph_provider[ds] = create_graph_provider(
+                graph=edges[(ds, "to", hid)], edge_attributes=mc.encoder.get("sub_graph_edge_attributes"),
+                src_size=n[ds], dst_size=n[hid], trainable_size=mc.encoder.get("trainable_size", 0))
+            self.encoder[ds] = instantiate(_retarget(mc.encoder), _recursive_=False, in_channels_src=self.input_dim[ds],
+                                           in_channels_dst=self.input_dim_latent, hidden_dim=self.num_channels,
+                                           edge_dim=self.encoder_graph_provider[ds].edge_dim)
+        self.processor_graph_provider = create_graph_provider(
+            graph=edges[(hid, "to", hid)], edge_attributes=mc.processor.get("sub_graph_edge_attributes"),
+            src_size=n[hid], dst_size=n[hid], trainable_size=mc.processor.get("trainable_size", 0))
+        self.processor = instantiate(_retarget(mc.processor), _recursive_=False, num_channels=self.num_channels,
+                                     edge_dim=self.processor_graph_provider.edge_dim)
+        self.decoder_graph_provider, self.decoder = nn.ModuleDict(), nn.ModuleDict()
+        for ds in self.dataset_names:
+            self.decoder_graph_provider[ds] = create_graph_provider(
+                graph=edges[(hid, "to", ds)], edge_attributes=mc.decoder.get("sub_graph_edge_attributes"),
+                src_size=n[hid], dst_size=n[ds], trainable_size=mc.decoder.get("trainable_size", 0))
+            self.decoder[ds] = instantiate(_retarget(mc.decoder), _recursive_=False, in_channels_src=self.num_channels,
+                                           in_channels_dst=self.target_dim[ds], hidden_dim=self.num_channels,
+                                           out_channels_dst=self.output_dim[ds], edge_dim=self.decoder_graph_provider[ds].edge_dim)
+
+    def _build_boundings(self, cfgs) -> dict:
+        out = {ds: [] for ds in self.dataset_names}
+        for c in cfgs:
+            if not str(c.get("_target_", "")).endswith("ReluBounding"):
+                raise NotImplementedError("only ReluBounding is supported at the model edge (scope row f4)")
+            for ds in self.dataset_names:
+                names = self.data_indices[ds].model.output.name_to_index
+                out[ds] += [names[v] for v in c["variables"]]
+        return out
+
+    # -- glue (encoder_processor_decoder.py:98-163) ---------------------------------------------------------
+    def _assemble_input(self, x: Tensor, batch_size: int, shard_sizes, group, ds: str):
+        node_attr = self.node_attributes(ds, batch_size=batch_size)
+        x_skip = x[:, self._skip_step, ...]  # SkipConnection (layers/residual.py:60-81): last input step
+        if shard_sizes is not None:
+            node_attr = shard_tensor(node_attr, 0, shard_sizes, group)
+        B, T, E, N, V = x.shape
+        flat = x.permute(0, 2, 3, 1, 4).reshape(B * E * N, T * V)  # "(batch ensemble grid) (time vars)"
+        return torch.cat((flat, node_attr.to(flat.dtype)), dim=-1), x_skip
+
+    def _assemble_output(self, x_out: Tensor, x_skip: Tensor, batch_size: int, ensemble_size: int, dtype, ds: str) -> Tensor:
+        N = x_out.shape[0] // (batch_size * ensemble_size)
+        x_out = x_out.view(batch_size, ensemble_size, N, self.n_step_output, -1).permute(0, 3, 1, 2, 4).to(dtype=dtype).clone()
+        x_out[..., self._internal_output_idx[ds]] += x_skip.unsqueeze(1)[..., self._internal_input_idx[ds]].to(dtype)
+        if self._relu_bounding_idx[ds]:
+            idx = self._relu_bounding_idx[ds]
+            x_out[..., idx] = torch.relu(x_out[..., idx])
+        return x_out
+
+    def forward(self, x: dict, *, model_comm_group=None, grid_shard_sizes: Optional[dict] = None, **kwargs) -> dict:
+        names = list(x.keys())
+        batch_size = x[names[0]].shape[0]
+        ensemble_size = x[names[0]].shape[2]
+        in_out_sharded = {ds: grid_shard_sizes is not None and grid_shard_sizes.get(ds) is not None for ds in names}
+        if model_comm_group is not None and comm_size(model_comm_group) > 1:
+            assert batch_size == 1, "Only batch size of 1 is supported when model is sharded across GPUs"
+            assert ensemble_size == 1, "Ensemble size per device must be 1 when model is sharded across GPUs"
+        hid = self._graph_name_hidden
+        x_hidden_latent = self.node_attributes(hid, batch_size=batch_size)
+        shard_sizes_hidden = get_shard_sizes(x_hidden_latent, 0, model_comm_group)
+        x_hidden_latent = shard_tensor(x_hidden_latent, 0, shard_sizes_hidden, model_comm_group)
+        latents, skips, data_latents, data_shards = {}, {}, {}, {}
+        for ds in names:
+            shard_sizes_data = grid_shard_sizes[ds] if in_out_sharded[ds] else None
+            x_data_latent, x_skip = self._assemble_input(x[ds], batch_size, shard_sizes_data, model_comm_group, ds)
+            skips[ds], data_shards[ds] = x_skip, shard_sizes_data
+            ea, ei, es = self.encoder_graph_provider[ds].get_edges(batch_size=batch_size, model_comm_group=model_comm_group)
+            info = BipartiteGraphShardInfo(src_nodes=shard_sizes_data, dst_nodes=shard_sizes_hidden, edges=es)
+            x_data_latent, x_latent = self.encoder[ds]((x_data_latent, x_hidden_latent.to(x_data_latent.dtype)), batch_size=batch_size,
+                                                       shard_info=info, edge_attr=ea, edge_index=ei,
+                                                       model_comm_group=model_comm_group, keep_x_dst_sharded=True)
+            data_latents[ds], latents[ds] = x_data_latent, x_latent
+        x_latent = latents[names[0]] if len(names) == 1 else sum(latents.values())
+        ea, ei, es = self.processor_graph_provider.get_edges(batch_size=batch_size, model_comm_group=model_comm_group)
+        x_latent_proc = self.processor(x=x_latent, batch_size=batch_size, shard_info=GraphShardInfo(nodes=shard_sizes_hidden, edges=es),
+                                       edge_attr=ea, edge_index=ei, model_comm_group=model_comm_group)
+        if self.latent_skip:
+            x_latent_proc = x_latent_proc + x_latent
+        out = {}
+        for ds in names:
+            ea, ei, es = self.decoder_graph_provider[ds].get_edges(batch_size=batch_size, model_comm_group=model_comm_group)
+            info = BipartiteGraphShardInfo(src_nodes=shard_sizes_hidden, dst_nodes=data_shards[ds], edges=es)
+            x_out = self.decoder[ds]((x_latent_proc, data_latents[ds]), batch_size=batch_size, shard_info=info, edge_attr=ea,
+                                     edge_index=ei, model_comm_group=model_comm_group, keep_x_dst_sharded=in_out_sharded[ds])
+            out[ds] = self._assemble_output(x_out, skips[ds], batch_size, ensemble_size, x[ds].dtype, ds)
+        return out

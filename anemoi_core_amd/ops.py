@@ -178,17 +178,20 @@ def gt_attention_fused_edge(q: Tensor, k: Tensor, v: Tensor, edge_feat: Tensor, 
     return (out, lse) if return_lse else out
 
 
-def layer_norm(x: Tensor, weight: Tensor, bias: Optional[Tensor], eps: float = 1e-5) -> Tensor:
-    """LayerNorm over the last dim of a [..., D] tensor (fp32 statistics)."""
-    _dev(x, weight, bias)
+def layer_norm(x: Tensor, weight: Tensor, bias: Optional[Tensor], eps: float = 1e-5, residual: Optional[Tensor] = None) -> Tensor:
+    """LayerNorm over the last dim of a [..., D] tensor (fp32 statistics), optionally + residual (same shape)."""
+    _dev(x, weight, bias, residual)
     D = x.shape[-1]
     x2 = x.reshape(-1, D)
     if x2.shape[1] > 1 and x2.stride(1) != 1:
         x2 = x2.contiguous()
     y = torch.empty((x2.shape[0], D), dtype=x.dtype, device=x.device)
     p, ld = _rows(x2, "x")
-    rc = _lib.load().anemoi_layernorm_fwd(p, ld, _vec(weight, "weight", D, x.dtype), _vec(bias, "bias", D, x.dtype), y.data_ptr(), D,
-                                          x2.shape[0], D, float(eps), _dt(x), _stream())
+    if residual is not None and residual.shape != x.shape:
+        raise ValueError("residual shape does not match x")
+    rp, ldr = _rows(None if residual is None else residual.reshape(-1, D), "residual", x.dtype)
+    rc = _lib.load().anemoi_layernorm_fwd(p, ld, _vec(weight, "weight", D, x.dtype), _vec(bias, "bias", D, x.dtype), rp, ldr,
+                                          y.data_ptr(), D, x2.shape[0], D, float(eps), _dt(x), _stream())
     _lib.check(rc, "layernorm_fwd")
     return y.view(x.shape)
 

@@ -68,11 +68,14 @@ int anemoi_gt_attention_fused_edge_fwd(const void* q, int64_t ldq, const void* k
 int anemoi_pack_edge_features(const void* edge_attr, int64_t ld, float* out, int32_t M, int32_t fe, int32_t fe_pad,
                               anemoi_dtype_t dtype, void* stream);
 
-/* LayerNorm over the last dimension (eps inside the sqrt, affine; beta may be NULL).
+/* LayerNorm over the last dimension (eps inside the sqrt, affine; beta may be NULL), optional fused residual:
+ *   y = LayerNorm(x) * gamma + beta (+ residual).
  * Replaces: torch.nn.LayerNorm / AutocastLayerNorm via layer_kernels.LayerNorm
- * (layers/utils.py:107-121, layers/normalization.py:19-31).  x,y: [n_rows, D]. */
-int anemoi_layernorm_fwd(const void* x, int64_t ldx, const void* gamma, const void* beta, void* y, int64_t ldy,
-                         int32_t n_rows, int32_t D, float eps, anemoi_dtype_t dtype, void* stream);
+ * (layers/utils.py:107-121, layers/normalization.py:19-31) and the "MLP(...LayerNorm) + x" tail of the GraphConv
+ * blocks (layers/block.py:391, 469).  x, y, residual: [n_rows, D]. */
+int anemoi_layernorm_fwd(const void* x, int64_t ldx, const void* gamma, const void* beta, const void* residual,
+                         int64_t ldr, void* y, int64_t ldy, int32_t n_rows, int32_t D, float eps, anemoi_dtype_t dtype,
+                         void* stream);
 
 /* Linear layer with fused epilogue.  Replaces torch.nn.Linear (+ GELU + residual add) as used by
  * get_qkve / projection / MLP (layers/block.py:623-635,1268-1271; layers/mlp.py:158-169).

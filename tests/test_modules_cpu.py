@@ -1,0 +1,93 @@
+"""CPU (host-logic) tests of the nn.Module mirror: constructors accept the reference's keywords and the state_dict keys
+and shapes equal the reference's (the golden fixtures hold the reference's own state_dicts) — the drop-in contract of
+SURVEY.md §8(b).  No kernel runs here."""
+import pytest
+import torch
+
+from anemoi_core_amd.layers.block import (
+    GraphConvMapperBlock,
+    GraphConvProcessorBlock,
+    GraphTransformerMapperBlock,
+    GraphTransformerProcessorBlock,
+)
+from anemoi_core_amd.layers.mapper import (
+    GNNBackwardMapper,
+    GNNForwardMapper,
+    GraphTransformerBackwardMapper,
+    GraphTransformerForwardMapper,
+)
+from anemoi_core_amd.layers.processor import GNNProcessor, GraphTransformerProcessor
+from tests.helpers import build_model_from_fixture, lk
+
+
+def assert_same_state_dict(module, ref_params):
+    sd = module.state_dict()
+    assert list(sd.keys()) == list(ref_params.keys()), set(sd) ^ set(ref_params)
+    for k, v in ref_params.items():
+        assert tuple(sd[k].shape) == tuple(v.shape), k
+    module.load_state_dict(ref_params, strict=True)
+
+
+@pytest.mark.parametrize("tag,cls", [("proc_qknorm", GraphTransformerProcessorBlock), ("proc", GraphTransformerProcessorBlock),
+                                     ("map", GraphTransformerMapperBlock), ("map_qknorm_updsrc", GraphTransformerMapperBlock),
+                                     ("gconv_proc", GraphConvProcessorBlock), ("gconv_proc_emb", GraphConvProcessorBlock),
+                                     ("gconv_map", GraphConvMapperBlock), ("gconv_map_updsrc", GraphConvMapperBlock)])
+def test_block_state_dicts_match_reference(golden, tag, cls):
+    c = golden("blocks.pt")[tag]
+    assert_same_state_dict(cls(layer_kernels=lk(), **c["cfg"]), c["params"])
+
+
+@pytest.mark.parametrize("tag,cls", [("gt_processor", GraphTransformerProcessor), ("gt_forward_mapper", GraphTransformerForwardMapper),
+                                     ("gt_backward_mapper", GraphTransformerBackwardMapper), ("gnn_processor", GNNProcessor),
+                                     ("gnn_forward_mapper", GNNForwardMapper), ("gnn_backward_mapper", GNNBackwardMapper)])
+def test_processor_mapper_state_dicts_match_reference(golden, tag, cls):
+    c = golden("proc_mappers.pt")[tag]
+    assert_same_state_dict(cls(**c["cfg"]), c["params"])  # the reference's own constructor kwargs, incl. backend "pyg"
+
+
+@pytest.mark.parametrize("kind", ["gt", "gnn"])
+def test_model_state_dict_matches_reference(golden, kind):
+    c = golden("model_tiny.pt")[kind]
+    model, _ = build_model_from_fixture(c)  # config carries the REFERENCE's _target_ strings
+    assert_same_state_dict(model, c["params"])
+    assert type(model.processor).__module__.startswith("anemoi_core_amd.")
+
+
+def test_mapper_block_layer_norm_alias():
+    blk = GraphTransformerMapperBlock(in_channels=64, hidden_dim=128, out_channels=64, num_heads=4, edge_dim=3, layer_kernels=lk())
+    assert blk.layer_norm_attention_dest is blk.layer_norm_attention  # reference block.py:940-941
+    sd = blk.state_dict()
+    assert "layer_norm_attention.weight" in sd and "layer_norm_attention_dest.weight" in sd
+
+
+def test_constructor_validation_matches_reference():
+    with pytest.raises(ValueError, match="divisible by num_heads"):
+        GraphTransformerProcessorBlock(in_channels=64, hidden_dim=64, out_channels=64, num_heads=5, edge_dim=3, layer_kernels=lk())
+    with pytest.raises(AssertionError, match="divisible by the number of processor chunks"):
+        GraphTransformerProcessor(num_layers=3, num_channels=64, num_chunks=2, num_heads=4, mlp_hidden_ratio=4, edge_dim=3)
+    with pytest.raises(AssertionError, match="does not support out_channels_dst"):
+        GraphTransformerForwardMapper(in_channels_src=3, in_channels_dst=3, hidden_dim=64, out_channels_dst=5, num_chunks=1,
+                                      num_heads=4, mlp_hidden_ratio=4, edge_dim=3)
+    with pytest.raises(NotImplementedError):
+        from anemoi_core_amd.layers.utils import load_layer_kernels
+
+        load_layer_kernels({"Linear": {"_target_": "torch.nn.Bilinear"}})
+
+
+def test_forward_on_cpu_fails_loudly(golden):
+    """No silent CPU fallback: the product modules refuse CPU tensors."""
+    c = golden("blocks.pt")["proc"]
+    blk = GraphTransformerProcessorBlock(layer_kernels=lk(), **c["cfg"]).eval()
+    from anemoi_core_amd.distributed.shapes import GraphShardInfo
+
+    with torch.no_grad(), pytest.raises(RuntimeError, match="no CPU fallback"):
+        blk(c["x"], c["edge_attr"], c["edge_index"], GraphShardInfo(), 1, c["x"].shape[0])
+
+
+def test_training_mode_is_rejected(golden):
+    c = golden("blocks.pt")["proc"]
+    blk = GraphTransformerProcessorBlock(layer_kernels=lk(), **c["cfg"])
+    from anemoi_core_amd.distributed.shapes import GraphShardInfo
+
+    with pytest.raises(NotImplementedError, match="forward pass only"):
+        blk(c["x"].requires_grad_(), c["edge_attr"], c["edge_index"], GraphShardInfo(), 1, c["x"].shape[0])
