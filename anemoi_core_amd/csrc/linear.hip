@@ -165,9 +165,10 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(LinArgs a, int tile
   const T* __restrict__ x2 = (const T*)a.x2;
   const T* __restrict__ w = (const T*)a.w;
   const int K = a.K1 + a.K2;
-  const int nk = K / BK;
+  const int nk = (K + BK - 1) / BK;
 
-  // staging assignment: 1024 16-byte chunks per operand tile, 4 per thread; chunk c -> row c/8, slot c%8
+  // staging assignment: 1024 16-byte chunks per operand tile, 4 per thread; chunk c -> row c/8, slot c%8.
+  // K need not be a multiple of BK: 8-element slots past the end are zero-filled (K1, K2 are multiples of 8).
   int st_row[4], st_slot[4];
   int64_t a_off[4], a2_off[4], w_off[4];
 #pragma unroll
@@ -176,9 +177,10 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(LinArgs a, int tile
     st_row[r] = c >> 3;
     st_slot[r] = c & 7;
     const int m = min(m0 + st_row[r], a.n_rows - 1);  // clamp: rows past the end are computed but never stored
-    a_off[r] = (int64_t)m * a.ldx + st_slot[r] * 8;
-    a2_off[r] = (int64_t)m * a.ldx2 + st_slot[r] * 8;
-    w_off[r] = (int64_t)(n0 + st_row[r]) * a.ldw + st_slot[r] * 8;
+    const int n = min(n0 + st_row[r], a.O - 1);
+    a_off[r] = (int64_t)m * a.ldx;
+    a2_off[r] = (int64_t)m * a.ldx2 - a.K1;
+    w_off[r] = (int64_t)n * a.ldw;
   }
 
   u32x4 ra[4], rw[4];
@@ -186,9 +188,15 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(LinArgs a, int tile
     const int k0 = kt * BK;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const T* ap = (k0 < a.K1) ? (x + a_off[r] + k0) : (x2 + a2_off[r] + (k0 - a.K1));
-      ra[r] = *reinterpret_cast<const u32x4*>(ap);
-      rw[r] = *reinterpret_cast<const u32x4*>(w + w_off[r] + k0);
+      const int kg = k0 + st_slot[r] * 8;
+      u32x4 va = u32x4{0u, 0u, 0u, 0u}, vw = va;
+      if (kg < K) {
+        const T* ap = (kg < a.K1) ? (x + a_off[r] + kg) : (x2 + a2_off[r] + kg);
+        va = *reinterpret_cast<const u32x4*>(ap);
+        vw = *reinterpret_cast<const u32x4*>(w + w_off[r] + kg);
+      }
+      ra[r] = va;
+      rw[r] = vw;
     }
   };
   auto s_store = [&](int buf) {
@@ -249,6 +257,7 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(LinArgs a, int tile
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
       const int n = n0 + wc * 64 + ni * 16 + (lane >> 4) * 4;
+      if (n >= a.O) continue;  // O % 4 == 0: a 4-column group is entirely inside or outside
       float vv[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
       float t[4];
       if (bias) {
@@ -286,7 +295,7 @@ static bool al(const void* p, size_t a) { return p == nullptr || (reinterpret_ca
 template <typename T>
 static bool mfma_eligible(const LinArgs& a) {
   if (sizeof(T) != 2) return false;
-  if (a.K1 % BK || a.K2 % BK || (a.K1 + a.K2) < BK || a.O % BN) return false;
+  if (a.K1 % 8 || a.K2 % 8 || a.O % 4) return false;
   if (a.ldx % 8 || a.ldw % 8 || (a.x2 && a.ldx2 % 8)) return false;                         // 16-byte operand rows
   if (a.ldy % 4 || (a.residual && a.ldr % 4) || (a.g1 && a.ldg1 % 4) || (a.g2 && a.ldg2 % 4)) return false;  // 8-byte epilogue
   return al(a.x, 16) && al(a.x2, 16) && al(a.w, 16) && al(a.y, 8) && al(a.residual, 8) && al(a.bias, 8) && al(a.g1, 8) && al(a.g2, 8);
@@ -301,7 +310,7 @@ static int launch_generic(const LinArgs& a, hipStream_t st) {
 
 template <typename T>
 static int launch_mfma(const LinArgs& a, hipStream_t st) {
-  const int tiles_m = (a.n_rows + BM - 1) / BM, tiles_n = a.O / BN;
+  const int tiles_m = (a.n_rows + BM - 1) / BM, tiles_n = (a.O + BN - 1) / BN;
   const int num_tiles = tiles_m * tiles_n;
   static bool attr_set = false;
   if (!attr_set) {

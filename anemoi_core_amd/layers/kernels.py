@@ -54,3 +54,25 @@ class GELU(nn.GELU):
 
     def forward(self, x: Tensor) -> Tensor:  # noqa: D102
         raise NotImplementedError("GELU is fused into the preceding Linear (anemoi_core_amd.layers.mlp.MLP)")
+
+
+class PaddedLinear:
+    """Apply an ``nn.Linear`` whose in_features is not a multiple of 8 on the MFMA path: 16-bit operand rows must be
+    16-byte aligned, so the K dimension of both the input and a cached copy of the weight is zero-padded to a multiple
+    of 8 (exact: the extra products are 0).  fp32 inputs take the generic kernel and need no padding."""
+
+    def __init__(self):
+        self._sig = None
+        self._w = None
+
+    def __call__(self, x: Tensor, lin: nn.Linear, **kw) -> Tensor:
+        K = x.shape[-1]
+        pad = (-K) % 8
+        if pad == 0 or x.dtype == torch.float32:
+            return ops.linear(x, lin.weight, lin.bias, **kw)
+        sig = (lin.weight.data_ptr(), lin.weight._version, lin.weight.dtype, str(lin.weight.device))
+        if self._sig != sig:
+            with torch.no_grad():
+                self._w = torch.nn.functional.pad(lin.weight, (0, pad)).contiguous()
+            self._sig = sig
+        return ops.linear(torch.nn.functional.pad(x, (0, pad)), self._w, lin.bias, **kw)

@@ -28,7 +28,7 @@ from ..distributed.partition import (
 )
 from ..distributed.shapes import BipartiteGraphShardInfo, comm_rank, comm_size, model_is_distributed
 from .block import GraphConvMapperBlock, GraphTransformerMapperBlock
-from .kernels import check_inference
+from .kernels import PaddedLinear, check_inference
 from .mlp import MLP
 from .utils import compute_mlp_hidden_dim, load_layer_kernels
 
@@ -82,6 +82,7 @@ class GraphTransformerBaseMapper(BaseMapper):
         self.emb_nodes_dst = self.layer_factory.Linear(self.in_channels_dst, self.hidden_dim)
         self._local = _LocalGraphCache()
         self._plan = None
+        self._emb_src, self._emb_dst = PaddedLinear(), PaddedLinear()
 
     # subclasses: pre_process(x_src_compact, x_dst) -> embedded pair, post_process(x_dst)
     def _local_graph(self, x, shard_info, edge_attr, edge_index, group):
@@ -155,8 +156,7 @@ class GraphTransformerForwardMapper(GraphTransformerBaseMapper):
 
     def pre_process(self, x):
         x_src, x_dst = x
-        return (ops.linear(x_src, self.emb_nodes_src.weight, self.emb_nodes_src.bias),
-                ops.linear(x_dst, self.emb_nodes_dst.weight, self.emb_nodes_dst.bias))
+        return self._emb_src(x_src, self.emb_nodes_src), self._emb_dst(x_dst, self.emb_nodes_dst)
 
     def post_process(self, x_dst, **kwargs):
         return x_dst
@@ -183,7 +183,7 @@ class GraphTransformerBackwardMapper(GraphTransformerBaseMapper):
 
     def pre_process(self, x):
         x_src, x_dst = x
-        return x_src, ops.linear(x_dst, self.emb_nodes_dst.weight, self.emb_nodes_dst.bias)
+        return x_src, self._emb_dst(x_dst, self.emb_nodes_dst)
 
     def post_process(self, x_dst):
         ln, lin = self.node_data_extractor[0], self.node_data_extractor[1]

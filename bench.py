@@ -1,0 +1,257 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: AnemoiModelEncProcDec forward on the O96 GraphTransformer configuration.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one full forward (encoder -> 16 processor layers -> decoder) over one synthetic ERA5-shaped input that
+is already resident in HBM.  metric = forward nodes*channels / s = N_data * num_channels / t_forward (BASELINE.json,
+SURVEY.md §8d).  At N > 1 the hidden mesh is sharded across the ranks (halo all-to-all per processor layer, needed-rows
+exchange in the decoder): the total work is fixed -> "scaling": "strong".
+
+Rank 0 prints ONE JSON line.  Extra objects: "roofline" (dominant kernel, measured live with HIP events on the launch
+stream) and, at N = 1, "cpu_baseline" (the oracle timed on the host cores on a bounded sample) and "kernels".
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--data-grid", default="o96")
+    ap.add_argument("--hidden-res", type=int, default=5)
+    ap.add_argument("--layers", type=int, default=16)
+    ap.add_argument("--channels", type=int, default=512)
+    ap.add_argument("--heads", type=int, default=16)
+    ap.add_argument("--vars", type=int, default=84, help="variables per data node (ERA5-like)")
+    ap.add_argument("--kind", default="gt", choices=["gt", "gnn"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true", help="do not capture the forward in a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def build(args, device):
+    from anemoi_core_amd.graphs.synthetic import build_synthetic_graph
+    from anemoi_core_amd.models import AnemoiModelEncProcDec
+    from anemoi_core_amd.models.configs import make_data_indices, model_config
+
+    g = build_synthetic_graph(args.data_grid, args.hidden_res)
+    torch.manual_seed(0)
+    model = AnemoiModelEncProcDec(
+        model_config=model_config(args.kind, args.channels, args.layers, args.heads, 8),
+        data_indices=make_data_indices(args.vars, args.vars), statistics={"data": None},
+        n_step_input=2, n_step_output=1, graph_data=g,
+    ).eval()
+    gen = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 2, 1, g.num_data, args.vars, generator=gen)
+    return g, model, x
+
+
+def time_kernels(model, g, args, dtype, device):
+    """Per-kernel timings of ONE processor layer at the benchmark shapes, HIP events on the launch stream."""
+    from anemoi_core_amd import ops
+    from anemoi_core_amd.layers.graphcache import get_csc, get_edge_features
+
+    blk = model.processor.proc[0]
+    N, D, H = g.num_hidden, args.channels, args.heads
+    M = g.proc_edge_index.shape[1]
+    ea, ei, _ = model.processor_graph_provider.get_edges(batch_size=1)
+    csc = get_csc(ei, (N, N), True)
+    feat = get_edge_features(ea, None)
+    fe = ea.shape[1]
+    x = torch.randn(N, D, device=device).to(dtype)
+    w4, b4 = blk._fused.get("qkvs", [blk.lin_query, blk.lin_key, blk.lin_value, blk.lin_self])
+    qkvs = ops.linear(x, w4, b4)
+    hid = blk.node_dst_mlp.mlp[0].out_features
+    h = torch.randn(N, hid, device=device).to(dtype)
+    es = dtype.itemsize if hasattr(dtype, "itemsize") else torch.tensor([], dtype=dtype).element_size()
+    ln = blk.layer_norm_attention
+    cases = {
+        "layernorm": (lambda: ops.layer_norm(x, ln.weight, ln.bias, ln.eps), "hbm", 2 * N * D * es),
+        "linear_qkvs(512->2048)": (lambda: ops.linear(x, w4, b4), "mfma", 2.0 * N * D * 4 * D),
+        "gt_attention_fused_edge": (lambda: ops.gt_attention_fused_edge(qkvs[:, :D], qkvs[:, D:2 * D], qkvs[:, 2 * D:3 * D], feat, blk.lin_edge.weight,
+                                                                        blk.lin_edge.bias, csc, H, addend=qkvs[:, 3 * D:]), "hbm",
+                                    es * 5 * N * D + 4 * M * feat.shape[1] + 4 * (M + N + 1)),  # q,k,v,self read + out write + feat + idx
+        "linear_proj(512->512)+res": (lambda: ops.linear(x, blk.projection.weight, blk.projection.bias, residual=x), "mfma", 2.0 * N * D * D),
+        "linear_mlp1(512->2048)+gelu": (lambda: ops.linear(x, blk.node_dst_mlp.mlp[0].weight, blk.node_dst_mlp.mlp[0].bias, act="gelu"), "mfma", 2.0 * N * D * hid),
+        "linear_mlp2(2048->512)+res": (lambda: ops.linear(h, blk.node_dst_mlp.mlp[2].weight, blk.node_dst_mlp.mlp[2].bias, residual=x), "mfma", 2.0 * N * hid * D),
+    }
+    out = {}
+    for name, (fn, bound, work) in cases.items():
+        for _ in range(5):
+            fn()
+        reps = 50
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        if bound == "hbm":
+            ach, peak, unit = work / us / 1e3, HBM_PEAK_GBS, "GB/s"
+        else:
+            ach, peak, unit = work / us / 1e6, MFMA_BF16_PEAK_TFLOPS, "TFLOP/s"
+        out[name] = {"us": round(us, 2), "bound": bound, "achieved": round(ach, 1), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
+                     "work": work}
+    return out
+
+
+def cpu_baseline(model_fp32_params, cfg, g, x, layers_sample):
+    """The oracle (CPU restatement of the reference, parity-pinned) on the host cores: encoder + ``layers_sample``
+    processor layers + decoder are timed once each, the full forward is t_enc + L * t_layer + t_dec."""
+    from oracle import gt_oracle as O
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    p = model_fp32_params
+    H, L = cfg["num_heads"], cfg["num_layers"]
+    t = torch.from_numpy
+    with torch.no_grad():
+        B, T, E, N, V = x.shape
+        x_data = torch.cat([x[0, :, 0].permute(1, 0, 2).reshape(N, T * V), O.node_attributes(p, "data")], -1)
+        x_hid = O.node_attributes(p, "hidden")
+        enc_ea = O.provider_edge_attr(p, "encoder_graph_provider.data", t(g.enc_edge_attr))
+        proc_ea = O.provider_edge_attr(p, "processor_graph_provider", t(g.proc_edge_attr))
+        dec_ea = O.provider_edge_attr(p, "decoder_graph_provider.data", t(g.dec_edge_attr))
+        t0 = time.perf_counter()
+        lat = O.gt_forward_mapper(p, "encoder.data", x_data, x_hid, enc_ea, t(g.enc_edge_index), H)
+        t_enc = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        h = lat
+        for i in range(layers_sample):
+            h = O.gt_processor_block(p, f"processor.proc.{i}", h, proc_ea, t(g.proc_edge_index), H)
+        t_layer = (time.perf_counter() - t0) / layers_sample
+        t0 = time.perf_counter()
+        O.gt_backward_mapper(p, "decoder.data", h, x_data, dec_ea, t(g.dec_edge_index), H)
+        t_dec = time.perf_counter() - t0
+    t_full = t_enc + L * t_layer + t_dec
+    return {"value": N * cfg["num_channels"] / t_full, "unit": "nodes*channels/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32 on {cores} host threads: encoder ({t_enc:.2f}s) + {layers_sample} of {L} processor layers "
+                      f"({t_layer:.3f}s each) + decoder ({t_dec:.2f}s), same O96 graph/inputs; full forward = enc + {L}*layer + dec = {t_full:.2f}s",
+            "seconds_forward": round(t_full, 3)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (ROCm) device; there is no CPU fallback for the product path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=device)
+        group = dist.group.WORLD
+    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
+
+    g, model, x = build(args, device)
+    params_fp32 = {k: v.detach().clone() for k, v in model.state_dict().items()} if rank == 0 else None
+    model = model.to(device).to(dtype)
+    x_dev = x.to(device).to(dtype)
+    inp = {"data": x_dev}
+
+    def step():
+        return model(inp, model_comm_group=group)["data"]
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    graph = None
+    with torch.inference_mode():
+        for _ in range(max(2, args.warmup // 2)):  # builds the static caches, sizes the allocator
+            out = step()
+        sync_all()
+        if not args.no_graph:
+            try:  # capture the whole forward (kernels are enqueued on torch's current stream through the C ABI)
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    step()
+                torch.cuda.current_stream().wait_stream(s)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    out = step()
+            except Exception as e:  # noqa: BLE001
+                if rank == 0:
+                    print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+                graph = None
+                torch.cuda.synchronize()
+        run = graph.replay if graph is not None else step
+        for _ in range(args.warmup):
+            run()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        sync_all()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms = elapsed / args.steps * 1e3
+    value = g.num_data * args.channels / (ms * 1e-3)
+
+    if rank == 0:
+        res = {
+            "metric": "forward nodes*channels/sec on O96 GraphTransformer",
+            "value": value, "unit": "nodes*channels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic (seeded N(0,1) inputs, random-init weights, own O96/icosphere topology generator)",
+            "config": {"workload": f"AnemoiModelEncProcDec forward, {args.data_grid.upper()} data grid ({g.num_data} nodes, {args.vars} vars x 2 steps) -> "
+                                   f"icosphere res {args.hidden_res} hidden mesh ({g.num_hidden} nodes, {g.proc_edge_index.shape[1]} edges), "
+                                   f"{'GraphTransformer' if args.kind == 'gt' else 'GNN'} processor {args.layers} layers x {args.channels} ch x {args.heads} heads, "
+                                   f"enc {g.enc_edge_index.shape[1]} / dec {g.dec_edge_index.shape[1]} edges, batch 1",
+                       "parallelism": f"hidden mesh sharded over {world} GPU(s), halo all-to-all per layer" if world > 1 else "single GPU",
+                       "hip_graph": graph is not None},
+        }
+        if world == 1 and args.kind == "gt" and not args.no_kernel_timing:
+            with torch.inference_mode():
+                ks = time_kernels(model, g, args, dtype, device)
+            res["kernels"] = ks
+            L = args.layers
+            layer_us = sum(v["us"] for v in ks.values()) + ks["layernorm"]["us"]  # two LayerNorms per layer
+            dom = max((k for k in ks if ks[k]["bound"] == "mfma"), key=lambda k: ks[k]["us"])
+            attn = ks["gt_attention_fused_edge"]
+            res["roofline"] = {"kernel": "linear_mfma_kernel", "shape": dom, "bound": "mfma", "achieved": ks[dom]["achieved"], "peak": MFMA_BF16_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": ks[dom]["frac"], "traffic": None,
+                               "note": f"dominant kernel class by time; one processor layer = {layer_us:.0f} us of kernels x {L} layers",
+                               "gather_scatter": {"kernel": "gt_attn_fused_edge_fwd_kernel", "bound": "hbm", "achieved": attn["achieved"], "peak": HBM_PEAK_GBS,
+                                                  "unit": "GB/s", "frac": attn["frac"], "traffic": None}}
+        if world == 1 and args.kind == "gt" and not args.no_cpu_baseline:
+            cfg = {"num_heads": args.heads, "num_layers": args.layers, "num_channels": args.channels}
+            res["cpu_baseline"] = cpu_baseline(params_fp32, cfg, g, x, layers_sample=2)
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
