@@ -40,15 +40,9 @@ __device__ __forceinline__ float from_float<float>(float v) {
 }
 template <>
 __device__ __forceinline__ bf16_t from_float<bf16_t>(float v) {
-  // round-to-nearest-even, NaN preserved (same rule as torch's float -> bfloat16)
-  uint32_t u = __float_as_uint(v);
+  // hardware round-to-nearest-even conversion (v_cvt_pk_bf16_f32 on gfx950), same rule as torch's float -> bfloat16
   bf16_t r;
-  if ((u & 0x7fffffffu) > 0x7f800000u) {
-    r.x = (uint16_t)((u >> 16) | 0x40);
-  } else {
-    u += 0x7fffu + ((u >> 16) & 1u);
-    r.x = (uint16_t)(u >> 16);
-  }
+  r.x = __builtin_bit_cast(uint16_t, (__bf16)v);
   return r;
 }
 template <>
@@ -101,7 +95,19 @@ __device__ __forceinline__ float group_sum(float x) {
 
 __device__ __forceinline__ float wave_sum(float x) { return group_sum<64>(x); }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, below fp32 resolution of the surrounding arithmetic):
+// one v_rcp, one v_exp and five FMAs instead of libm's branchy erff in the GEMM epilogue.
+__device__ __forceinline__ float fast_erf(float x) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float r = 1.0f - p * t * __expf(-ax * ax);
+  return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f)); }
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 

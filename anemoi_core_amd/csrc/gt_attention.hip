@@ -106,32 +106,59 @@ struct WLayout {
 };
 
 template <typename T, int VEC, int LPH, int FE_PAD>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void gt_attn_fused_edge_fwd_kernel(
+__global__ __launch_bounds__(64 * kWavesPerBlock, 5) void gt_attn_fused_edge_fwd_kernel(
     const T* __restrict__ q, int64_t ldq, const T* __restrict__ k, int64_t ldk, const T* __restrict__ v, int64_t ldv,
-    const float* __restrict__ feat, int fe, const T* __restrict__ w_edge, const T* __restrict__ b_edge,
-    const int32_t* __restrict__ row, const int32_t* __restrict__ colptr, const T* __restrict__ addend, int64_t ldadd,
-    T* __restrict__ out, int64_t ldo, float* __restrict__ lse, int n_dst, int H, float scale, int dst_per_wave) {
+    const float* __restrict__ feat, const float* __restrict__ w_packed, const int32_t* __restrict__ row,
+    const int32_t* __restrict__ colptr, const T* __restrict__ addend, int64_t ldadd, T* __restrict__ out, int64_t ldo,
+    float* __restrict__ lse, int n_dst, int H, float scale) {
   using L = WLayout<VEC, FE_PAD>;
   extern __shared__ __attribute__((aligned(16))) float w_lds[];  // [64][kChunk]
   const int lane = threadIdx.x & 63;
   const int c0 = lane * VEC;
 
-  // Stage W' once per block: element (channel c, feature f) -> w_lds[(c / VEC) * kChunk + (c % VEC) * FE_PAD + f].
-  for (int i = threadIdx.x; i < 64 * VEC * FE_PAD; i += blockDim.x) {
-    const int c = i / FE_PAD, f = i % FE_PAD;
-    float val = 0.f;
-    if (f < fe) val = to_float(w_edge[(int64_t)c * fe + f]);
-    else if (f == fe && b_edge != nullptr) val = to_float(b_edge[c]);
-    w_lds[(c / VEC) * L::kChunk + (c % VEC) * FE_PAD + f] = val;
+  // Stage W' = [W_e | b_e | 0] (fp32 [D][FE_PAD], packed once on the host side of the ABI) into LDS: all 16-byte
+  // loads are issued before the first write (one memory round trip per workgroup).
+  {
+    constexpr int kQ = FE_PAD / 4;                 // float4 per channel row
+    constexpr int kTotal = 64 * VEC * kQ;          // float4 in the image
+    constexpr int kIter = (kTotal + 64 * kWavesPerBlock - 1) / (64 * kWavesPerBlock);
+    float4 tmp[kIter];
+#pragma unroll
+    for (int it = 0; it < kIter; ++it) {
+      const int idx = threadIdx.x + it * 64 * kWavesPerBlock;
+      tmp[it] = idx < kTotal ? reinterpret_cast<const float4*>(w_packed)[idx] : float4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int it = 0; it < kIter; ++it) {
+      const int idx = threadIdx.x + it * 64 * kWavesPerBlock;
+      if (idx < kTotal) {
+        const int c = idx / kQ, qq = idx % kQ;
+        *reinterpret_cast<float4*>(w_lds + (c / VEC) * L::kChunk + (c % VEC) * FE_PAD + qq * 4) = tmp[it];
+      }
+    }
   }
   __syncthreads();
   const float* wl = w_lds + lane * L::kChunk;
 
-  const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
-  const int d_beg = wave * dst_per_wave;
-  const int d_end = min(n_dst, d_beg + dst_per_wave);
+  // XCD-aware persistent schedule.  Workgroup b runs on XCD b % 8 (observed dispatch order; only speed depends on
+  // it).  Each XCD gets one CONTIGUOUS slice of the destination range, so the K/V rows its waves gather (the mesh
+  // neighbourhood of that slice: nodes are latitude/longitude sorted) stay resident in that XCD's 4 MiB L2 instead of
+  // every L2 pulling every row from the fabric (8x the traffic).  Inside a slice, waves take destinations round-robin.
+  const int xcd = blockIdx.x & 7;
+  const int blocks_in_xcd = (gridDim.x - xcd + 7) >> 3;
+  const int waves_in_xcd = blocks_in_xcd * kWavesPerBlock;
+  const int wave_in_xcd = __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * kWavesPerBlock + (threadIdx.x >> 6));
+  const int per_xcd = (n_dst + 7) >> 3;
+  const int d_lo = xcd * per_xcd;
+  const int d_hi = min(n_dst, d_lo + per_xcd);
 
-  for (int d = d_beg; d < d_end; ++d) {
+  using Raw = Vec<T, VEC>;  // a row slice as loaded (converted to fp32 only when consumed)
+  constexpr int PF = 3;     // edges in flight per wave (modulo-unrolled: no register rotation, counted waits)
+
+  for (int d = d_lo + wave_in_xcd; d < d_hi; d += waves_in_xcd) {
+    // W' lives in LDS and is re-read per destination: without this barrier the compiler hoists all VEC*FE_PAD values
+    // into registers across the loop (256 VGPRs, 1 wave/SIMD) and the kernel becomes latency-bound.
+    asm volatile("" ::: "memory");
     const int beg = __builtin_amdgcn_readfirstlane(colptr[d]);
     const int end = __builtin_amdgcn_readfirstlane(colptr[d + 1]);
 
@@ -155,40 +182,51 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void gt_attn_fused_edge_fwd_ke
     }
     float m = -INFINITY, l = 0.f;
 
-    struct Row {
-      float k[VEC];
-      float v[VEC];
-    } cur, nxt;
-    auto fetch = [&](int ei, Row& r) {
-      const int s = __builtin_amdgcn_readfirstlane(row[ei]);
-      load_vec<T, VEC>(k + (int64_t)s * ldk + c0, r.k);
-      load_vec<T, VEC>(v + (int64_t)s * ldv + c0, r.v);
-    };
-    if (beg < end) fetch(beg, nxt);
-    for (int ei = beg; ei < end; ++ei) {
-      cur = nxt;
-      if (ei + 1 < end) fetch(ei + 1, nxt);
-      const float* a = feat + (int64_t)ei * FE_PAD;  // wave-uniform address -> scalar loads
-      float af[FE_PAD];
+    // Edge loop in chunks of 64: the source ids of a chunk are fetched with ONE coalesced load (lane j holds
+    // row[chunk + j]) and broadcast with v_readlane, so row loads never wait on a dependent scalar load.
+    for (int chunk = beg; chunk < end; chunk += 64) {
+      const int n = min(64, end - chunk);
+      const int my_src = (lane < n) ? row[chunk + lane] : 0;
+      Raw kb[PF], vb[PF];
+      float fb[PF][FE_PAD];
+      auto fetch = [&](int j, Raw& kr, Raw& vr, float (&fr)[FE_PAD]) {
+        const int s = __builtin_amdgcn_readlane(my_src, j);
+        kr = *reinterpret_cast<const Raw*>(k + (int64_t)s * ldk + c0);
+        vr = *reinterpret_cast<const Raw*>(v + (int64_t)s * ldv + c0);
+        const float* a = feat + (int64_t)(chunk + j) * FE_PAD;  // wave-uniform address -> scalar loads
 #pragma unroll
-      for (int f = 0; f < FE_PAD; ++f) af[f] = a[f];
-      float dot = 0.f;
+        for (int f = 0; f < FE_PAD; ++f) fr[f] = a[f];
+      };
 #pragma unroll
-      for (int f = 0; f < FE_PAD; ++f) dot = fmaf(af[f], qw[f], dot);
+      for (int st = 0; st < PF; ++st)
+        if (st < n) fetch(st, kb[st], vb[st], fb[st]);
+      for (int j0 = 0; j0 < n; j0 += PF) {
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) dot = fmaf(qv[j], cur.k[j], dot);
-      dot = group_sum<LPH>(dot);
-      const float m_new = fmaxf(m, dot);
-      const float corr = __expf(m - m_new);
-      const float p = __expf(dot - m_new);
-      l = fmaf(l, corr, p);
+        for (int st = 0; st < PF; ++st) {
+          const int j = j0 + st;
+          if (j < n) {
+            float dot = 0.f;
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) acc[j] = fmaf(acc[j], corr, p * cur.v[j]);
+            for (int f = 0; f < FE_PAD; ++f) dot = fmaf(fb[st][f], qw[f], dot);
 #pragma unroll
-      for (int f = 0; f < FE_PAD; ++f) sf[f] = fmaf(sf[f], corr, p * af[f]);
-      m = m_new;
+            for (int jj = 0; jj < VEC; ++jj) dot = fmaf(qv[jj], to_float(kb[st].v[jj]), dot);
+            dot = group_sum<LPH>(dot);
+            const float m_new = fmaxf(m, dot);
+            const float corr = __expf(m - m_new);
+            const float p = __expf(dot - m_new);
+            l = fmaf(l, corr, p);
+#pragma unroll
+            for (int jj = 0; jj < VEC; ++jj) acc[jj] = fmaf(acc[jj], corr, p * to_float(vb[st].v[jj]));
+#pragma unroll
+            for (int f = 0; f < FE_PAD; ++f) sf[f] = fmaf(sf[f], corr, p * fb[st][f]);
+            m = m_new;
+            if (j + PF < n) fetch(j + PF, kb[st], vb[st], fb[st]);
+          }
+        }
+      }
     }
 
+    asm volatile("" ::: "memory");
     const float inv = (end > beg) ? 1.0f / l : 0.f;
     float o[VEC];
 #pragma unroll
@@ -209,6 +247,192 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void gt_attn_fused_edge_fwd_ke
   }
 }
 
+// ---------------------------------------------------------------------------------------------- fused lin_edge, v2
+// Same maths as above with ~3x fewer vector-ALU instructions per edge (the v1 kernel measured VALU-bound: 1.1k VALU
+// instructions per destination at 4 cycles each).  Requires FE_PAD % LPH == 0.
+//  * the FE_PAD edge features are SPLIT across the LPH lanes of a head (FPL = FE_PAD / LPH each): the feature part of
+//    the score needs FPL FMAs per lane (the head butterfly that finishes <q,k> also sums the partials) and the
+//    weighted feature sum FPL FMAs; the per-lane feature slice is a vector load (no scalar-load chain);
+//  * <q_h, k_h> uses v_dot2c_f32_{bf16,f16} on the packed 16-bit pairs as loaded (no conversions for K);
+//  * deferred running max: the O(VEC + FPL) rescale of the accumulators only runs (wave-uniform branch) when some
+//    head's score exceeds its running max by more than kDeferThr; otherwise p = exp(s - m_old) <= e^kDeferThr is added
+//    directly (fp32 accumulators; exact same value after the final division).
+constexpr float kDeferThr = 8.0f;
+
+template <typename T, int VEC>
+__device__ __forceinline__ float dot_rows(const Vec<T, VEC>& a, const Vec<T, VEC>& b) {
+  float acc = 0.f;
+  if constexpr (sizeof(T) == 2 && (VEC % 2 == 0)) {
+    const uint32_t* pa = reinterpret_cast<const uint32_t*>(&a);
+    const uint32_t* pb = reinterpret_cast<const uint32_t*>(&b);
+#pragma unroll
+    for (int i = 0; i < VEC / 2; ++i) {
+      if constexpr (std::is_same<T, bf16_t>::value) {
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+        acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, pa[i]), __builtin_bit_cast(bf2, pb[i]), acc, false);
+      } else {
+        typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+        acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, pa[i]), __builtin_bit_cast(h2, pb[i]), acc, false);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc = fmaf(to_float(a.v[i]), to_float(b.v[i]), acc);
+  }
+  return acc;
+}
+
+template <typename T, int VEC, int LPH, int FE_PAD>
+__global__ __launch_bounds__(64 * kWavesPerBlock, 4) void gt_attn_fused_edge_v2_kernel(
+    const T* __restrict__ q, int64_t ldq, const T* __restrict__ k, int64_t ldk, const T* __restrict__ v, int64_t ldv,
+    const float* __restrict__ feat, const float* __restrict__ w_packed, const int32_t* __restrict__ row,
+    const int32_t* __restrict__ colptr, const T* __restrict__ addend, int64_t ldadd, T* __restrict__ out, int64_t ldo,
+    float* __restrict__ lse, int n_dst, int H, float scale) {
+  using L = WLayout<VEC, FE_PAD>;
+  constexpr int FPL = FE_PAD / LPH;
+  extern __shared__ __attribute__((aligned(16))) float w_lds[];  // [64][kChunk]
+  const int lane = threadIdx.x & 63;
+  const int c0 = lane * VEC;
+  const int fi = lane % LPH;  // which feature slice of the head this lane owns
+
+  {
+    constexpr int kQ = FE_PAD / 4;
+    constexpr int kTotal = 64 * VEC * kQ;
+    constexpr int kIter = (kTotal + 64 * kWavesPerBlock - 1) / (64 * kWavesPerBlock);
+    float4 tmp[kIter];
+#pragma unroll
+    for (int it = 0; it < kIter; ++it) {
+      const int idx = threadIdx.x + it * 64 * kWavesPerBlock;
+      tmp[it] = idx < kTotal ? reinterpret_cast<const float4*>(w_packed)[idx] : float4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int it = 0; it < kIter; ++it) {
+      const int idx = threadIdx.x + it * 64 * kWavesPerBlock;
+      if (idx < kTotal) {
+        const int c = idx / kQ, qq = idx % kQ;
+        *reinterpret_cast<float4*>(w_lds + (c / VEC) * L::kChunk + (c % VEC) * FE_PAD + qq * 4) = tmp[it];
+      }
+    }
+  }
+  __syncthreads();
+  const float* wl = w_lds + lane * L::kChunk;
+
+  const int xcd = blockIdx.x & 7;
+  const int blocks_in_xcd = (gridDim.x - xcd + 7) >> 3;
+  const int waves_in_xcd = blocks_in_xcd * kWavesPerBlock;
+  const int wave_in_xcd = __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * kWavesPerBlock + (threadIdx.x >> 6));
+  const int per_xcd = (n_dst + 7) >> 3;
+  const int d_lo = xcd * per_xcd;
+  const int d_hi = min(n_dst, d_lo + per_xcd);
+
+  using Raw = Vec<T, VEC>;
+  constexpr int PF = 3;
+
+  for (int d = d_lo + wave_in_xcd; d < d_hi; d += waves_in_xcd) {
+    asm volatile("" ::: "memory");  // keep W' in LDS (see v1)
+    const int beg = __builtin_amdgcn_readfirstlane(colptr[d]);
+    const int end = __builtin_amdgcn_readfirstlane(colptr[d + 1]);
+
+    const Raw q_raw = *reinterpret_cast<const Raw*>(q + (int64_t)d * ldq + c0);
+    float acc[VEC], sf[FPL], qw_own[FPL];
+    {
+      // qw[f] = scale * sum over the head's channels of q[c] * W'[c][f]; every lane keeps only its FPL features
+      float qv[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        qv[j] = to_float(q_raw.v[j]) * scale;
+        acc[j] = 0.f;
+      }
+#pragma unroll
+      for (int t = 0; t < FPL; ++t) qw_own[t] = 0.f;
+#pragma unroll
+      for (int f = 0; f < FE_PAD; ++f) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) t = fmaf(qv[j], wl[j * FE_PAD + f], t);
+        t = group_sum<LPH>(t);
+        if (fi == f / FPL) qw_own[f % FPL] = t;  // compile-time f: one v_cndmask per feature
+      }
+#pragma unroll
+      for (int t = 0; t < FPL; ++t) sf[t] = 0.f;
+    }
+    float m = -INFINITY, l = 0.f;
+
+    for (int chunk = beg; chunk < end; chunk += 64) {
+      const int n = min(64, end - chunk);
+      const int my_src = (lane < n) ? row[chunk + lane] : 0;
+      Raw kb[PF], vb[PF];
+      float fb[PF][FPL];
+      auto fetch = [&](int j, Raw& kr, Raw& vr, float (&fr)[FPL]) {
+        const int s = __builtin_amdgcn_readlane(my_src, j);
+        kr = *reinterpret_cast<const Raw*>(k + (int64_t)s * ldk + c0);
+        vr = *reinterpret_cast<const Raw*>(v + (int64_t)s * ldv + c0);
+        const float* a = feat + (int64_t)(chunk + j) * FE_PAD + fi * FPL;
+#pragma unroll
+        for (int t = 0; t < FPL; ++t) fr[t] = a[t];
+      };
+#pragma unroll
+      for (int st = 0; st < PF; ++st)
+        if (st < n) fetch(st, kb[st], vb[st], fb[st]);
+      for (int j0 = 0; j0 < n; j0 += PF) {
+#pragma unroll
+        for (int st = 0; st < PF; ++st) {
+          const int j = j0 + st;
+          if (j < n) {
+            float dot = dot_rows<T, VEC>(q_raw, kb[st]) * scale;
+#pragma unroll
+            for (int t = 0; t < FPL; ++t) dot = fmaf(fb[st][t], qw_own[t], dot);
+            dot = group_sum<LPH>(dot);
+            if (__builtin_amdgcn_ballot_w64(dot > m + kDeferThr) != 0) {  // rare after the first edge
+              const float m_new = fmaxf(m, dot);
+              const float corr = __expf(m - m_new);
+              l *= corr;
+#pragma unroll
+              for (int jj = 0; jj < VEC; ++jj) acc[jj] *= corr;
+#pragma unroll
+              for (int t = 0; t < FPL; ++t) sf[t] *= corr;
+              m = m_new;
+            }
+            const float p = __expf(dot - m);
+            l += p;
+#pragma unroll
+            for (int jj = 0; jj < VEC; ++jj) acc[jj] = fmaf(p, to_float(vb[st].v[jj]), acc[jj]);
+#pragma unroll
+            for (int t = 0; t < FPL; ++t) sf[t] = fmaf(p, fb[st][t], sf[t]);
+            if (j + PF < n) fetch(j + PF, kb[st], vb[st], fb[st]);
+          }
+        }
+      }
+    }
+
+    asm volatile("" ::: "memory");
+    // all-gather the weighted feature sums of the head (FPL per lane -> FE_PAD) and apply W'
+    float sfa[FE_PAD];
+    const int head_base = lane & ~(LPH - 1);
+#pragma unroll
+    for (int g = 0; g < LPH; ++g)
+#pragma unroll
+      for (int t = 0; t < FPL; ++t) sfa[g * FPL + t] = __shfl(sf[t], head_base + g, 64);
+    const float inv = (end > beg) ? 1.0f / l : 0.f;
+    float o[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float t = acc[j];
+#pragma unroll
+      for (int f = 0; f < FE_PAD; ++f) t = fmaf(sfa[f], wl[j * FE_PAD + f], t);
+      o[j] = t * inv;
+    }
+    if (addend != nullptr) {
+      float ad[VEC];
+      load_vec<T, VEC>(addend + (int64_t)d * ldadd + c0, ad);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) o[j] += ad[j];
+    }
+    store_vec<T, VEC>(out + (int64_t)d * ldo + c0, o);
+    if (lse != nullptr && fi == 0) lse[(int64_t)d * H + lane / LPH] = (end > beg) ? m + __logf(l) : 0.f;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- generic path
 // Any (H, C): one thread per (destination, head), serial over edges and channels.  Used for shapes the
 // wave-per-row layout cannot express (D not a multiple of 64, non power-of-two lanes per head — e.g. the
@@ -219,7 +443,7 @@ template <typename T>
 __global__ void gt_attn_fwd_generic_kernel(const T* __restrict__ q, int64_t ldq, const T* __restrict__ k, int64_t ldk,
                                            const T* __restrict__ v, int64_t ldv, const T* __restrict__ e, int64_t lde,
                                            const float* __restrict__ feat, int fe, int fe_pad,
-                                           const T* __restrict__ w_edge, const T* __restrict__ b_edge,
+                                           const float* __restrict__ w_packed,
                                            const int32_t* __restrict__ row, const int32_t* __restrict__ colptr,
                                            const T* __restrict__ addend, int64_t ldadd, T* __restrict__ out,
                                            int64_t ldo, float* __restrict__ lse, int n_dst, int H, int C, float scale) {
@@ -240,8 +464,8 @@ __global__ void gt_attn_fwd_generic_kernel(const T* __restrict__ q, int64_t ldq,
       float ee = 0.f;
       if (e != nullptr) ee = to_float(e[(int64_t)ei * lde + h * C + c]);
       if (feat != nullptr) {
-        ee = b_edge ? to_float(b_edge[h * C + c]) : 0.f;
-        for (int f = 0; f < fe; ++f) ee = fmaf(feat[(int64_t)ei * fe_pad + f], to_float(w_edge[(int64_t)(h * C + c) * fe + f]), ee);
+        ee = 0.f;  // the bias rides on the constant-1 feature column fe
+        for (int f = 0; f < fe_pad; ++f) ee = fmaf(feat[(int64_t)ei * fe_pad + f], w_packed[(int64_t)(h * C + c) * fe_pad + f], ee);
       }
       dot = fmaf(to_float(qp[c]) * scale, to_float(kp[c]) + ee, dot);
     }
@@ -252,8 +476,8 @@ __global__ void gt_attn_fwd_generic_kernel(const T* __restrict__ q, int64_t ldq,
       float ee = 0.f;
       if (e != nullptr) ee = to_float(e[(int64_t)ei * lde + h * C + c]);
       if (feat != nullptr) {
-        ee = b_edge ? to_float(b_edge[h * C + c]) : 0.f;
-        for (int f = 0; f < fe; ++f) ee = fmaf(feat[(int64_t)ei * fe_pad + f], to_float(w_edge[(int64_t)(h * C + c) * fe + f]), ee);
+        ee = 0.f;  // the bias rides on the constant-1 feature column fe
+        for (int f = 0; f < fe_pad; ++f) ee = fmaf(feat[(int64_t)ei * fe_pad + f], w_packed[(int64_t)(h * C + c) * fe_pad + f], ee);
       }
       acc[c] = acc[c] * corr + p * (to_float(vp[c]) + ee);
     }
@@ -266,6 +490,16 @@ __global__ void gt_attn_fwd_generic_kernel(const T* __restrict__ q, int64_t ldq,
     out[(int64_t)d * ldo + h * C + c] = from_float<T>(o);
   }
   if (lse != nullptr) lse[(int64_t)d * H + h] = (end > beg) ? m + logf(l) : 0.f;
+}
+
+// W' = [W_e | b_e | 0] as fp32 [D][fe_pad]
+template <typename T>
+__global__ void pack_edge_weights_kernel(const T* __restrict__ w, const T* __restrict__ b, float* __restrict__ out, int D,
+                                         int fe, int fe_pad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= D * fe_pad) return;
+  const int c = i / fe_pad, f = i % fe_pad;
+  out[i] = f < fe ? to_float(w[(int64_t)c * fe + f]) : ((f == fe && b != nullptr) ? to_float(b[c]) : 0.f);
 }
 
 template <typename T>
@@ -283,7 +517,7 @@ struct AttnArgs {
   int64_t ldq, ldk, ldv, lde;
   const float* feat;
   int fe, fe_pad;
-  const void *w_edge, *b_edge;
+  const float* w_packed;
   const int32_t *row, *colptr;
   const void* addend;
   int64_t ldadd;
@@ -318,13 +552,23 @@ static int launch_fast(const AttnArgs& a) {
     constexpr int FE_PAD = decltype(fe_pad_c)::value;
     using L = WLayout<VEC, FE_PAD>;
     if (L::kFloats * sizeof(float) > 64 * 1024) return 1;  // beyond the default dynamic-LDS limit: generic path
-    int dst_per_wave = a.n_dst >= 32768 ? 8 : (a.n_dst >= 4096 ? 4 : (a.n_dst >= 1024 ? 2 : 1));
-    const int waves = (a.n_dst + dst_per_wave - 1) / dst_per_wave;
-    const dim3 grid((waves + kWavesPerBlock - 1) / kWavesPerBlock);
+    // persistent grid: at most ~6 workgroups per CU (LDS 25 KiB each, 5-6 waves/SIMD by registers); every wave walks
+    // destinations d, d + total_waves, ... so the W' staging is paid once per workgroup
+    const int max_blocks = 256 * 6;
+    int blocks = (a.n_dst + kWavesPerBlock - 1) / kWavesPerBlock;
+    blocks = blocks < max_blocks ? blocks : max_blocks;
+    blocks = (blocks + 7) & ~7;  // a whole number of workgroups per XCD
+    const dim3 grid(blocks);
+    constexpr bool kUseV2 = false;  // v2 (VALU-lean) measured slower than v1 while both are latency-bound; see DESIGN.md
+    if constexpr (kUseV2 && FE_PAD % LPH == 0) {
+      hipLaunchKernelGGL((gt_attn_fused_edge_v2_kernel<T, VEC, LPH, FE_PAD>), grid, block, L::kFloats * sizeof(float),
+                         a.stream, (const T*)a.q, a.ldq, (const T*)a.k, a.ldk, (const T*)a.v, a.ldv, a.feat, a.w_packed,
+                         a.row, a.colptr, (const T*)a.addend, a.ldadd, (T*)a.out, a.ldo, a.lse, a.n_dst, a.H, scale);
+      return check_launch("gt_attn_fused_edge_v2_kernel");
+    }
     hipLaunchKernelGGL((gt_attn_fused_edge_fwd_kernel<T, VEC, LPH, FE_PAD>), grid, block, L::kFloats * sizeof(float),
-                       a.stream, (const T*)a.q, a.ldq, (const T*)a.k, a.ldk, (const T*)a.v, a.ldv, a.feat, a.fe,
-                       (const T*)a.w_edge, (const T*)a.b_edge, a.row, a.colptr, (const T*)a.addend, a.ldadd, (T*)a.out,
-                       a.ldo, a.lse, a.n_dst, a.H, scale, dst_per_wave);
+                       a.stream, (const T*)a.q, a.ldq, (const T*)a.k, a.ldk, (const T*)a.v, a.ldv, a.feat, a.w_packed,
+                       a.row, a.colptr, (const T*)a.addend, a.ldadd, (T*)a.out, a.ldo, a.lse, a.n_dst, a.H, scale);
     return check_launch("gt_attn_fused_edge_fwd_kernel");
   };
   switch (a.fe_pad) {
@@ -357,7 +601,7 @@ static int launch(const AttnArgs& a) {
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   const bool lds_ok = (a.ldq % 8 == 0) && (a.ldk % 8 == 0) && (a.ldv % 8 == 0) && (a.ldo % 8 == 0) &&
                       (a.e == nullptr || a.lde % 8 == 0) && (a.addend == nullptr || a.ldadd % 8 == 0) && al16(a.q) &&
-                      al16(a.k) && al16(a.v) && al16(a.out) && al16(a.e) && al16(a.addend) && al16(a.feat);
+                      al16(a.k) && al16(a.v) && al16(a.out) && al16(a.e) && al16(a.addend) && al16(a.feat) && al16(a.w_packed);
   if (D % 64 == 0 && lds_ok) {
     const int vec = D / 64;
     if (a.C % vec == 0 && pow2(a.C / vec) && a.C / vec <= 16) {
@@ -380,7 +624,7 @@ static int launch(const AttnArgs& a) {
   const float scale = 1.0f / sqrtf((float)a.C);
   hipLaunchKernelGGL((gt_attn_fwd_generic_kernel<T>), dim3((unsigned)((threads + 127) / 128)), dim3(128), 0, a.stream,
                      (const T*)a.q, a.ldq, (const T*)a.k, a.ldk, (const T*)a.v, a.ldv, (const T*)a.e, a.lde, a.feat, a.fe,
-                     a.fe_pad, (const T*)a.w_edge, (const T*)a.b_edge, a.row, a.colptr, (const T*)a.addend, a.ldadd,
+                     a.fe_pad, a.w_packed, a.row, a.colptr, (const T*)a.addend, a.ldadd,
                      (T*)a.out, a.ldo, a.lse, a.n_dst, a.H, a.C, scale);
   return check_launch("gt_attn_fwd_generic_kernel");
 }
@@ -409,24 +653,39 @@ extern "C" int anemoi_gt_attention_fwd(const void* q, int64_t ldq, const void* k
   const int D = H * C;
   ANEMOI_REQUIRE(ldq >= D && ldk >= D && ldv >= D && ldo >= D && (!e || lde >= D) && (!addend || ldadd >= D),
                  "gt_attention_fwd: leading dimension smaller than H*C=%d", D);
-  AttnArgs a{q, k, v, e, ldq, ldk, ldv, lde, nullptr, 0, 0, nullptr, nullptr, row, colptr, addend, ldadd, out, ldo, lse, n_dst, n_src, H, C, as_stream(stream)};
+  AttnArgs a{q, k, v, e, ldq, ldk, ldv, lde, nullptr, 0, 0, nullptr, row, colptr, addend, ldadd, out, ldo, lse, n_dst, n_src, H, C, as_stream(stream)};
   return dispatch(a, dtype);
 }
 
 extern "C" int anemoi_gt_attention_fused_edge_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v,
-                                                  int64_t ldv, const float* edge_feat, int32_t fe, int32_t fe_pad,
-                                                  const void* w_edge, const void* b_edge, const int32_t* row,
-                                                  const int32_t* colptr, const void* addend, int64_t ldadd, void* out,
-                                                  int64_t ldo, float* lse, int32_t n_dst, int32_t n_src, int32_t H,
-                                                  int32_t C, anemoi_dtype_t dtype, void* stream) {
+                                                  int64_t ldv, const float* edge_feat, int32_t fe_pad,
+                                                  const float* w_packed, const int32_t* row, const int32_t* colptr,
+                                                  const void* addend, int64_t ldadd, void* out, int64_t ldo, float* lse,
+                                                  int32_t n_dst, int32_t n_src, int32_t H, int32_t C,
+                                                  anemoi_dtype_t dtype, void* stream) {
   ANEMOI_REQUIRE(n_dst >= 0 && n_src >= 0 && H > 0 && C > 0, "gt_attention_fused_edge_fwd: bad sizes");
   if (n_dst == 0) return ANEMOI_OK;
-  ANEMOI_REQUIRE(q && k && v && out && colptr && edge_feat && w_edge, "gt_attention_fused_edge_fwd: null pointer");
-  ANEMOI_REQUIRE(fe > 0 && fe_pad == 4 * ((fe + 1 + 3) / 4), "gt_attention_fused_edge_fwd: fe_pad must be 4*ceil((fe+1)/4), got fe=%d fe_pad=%d", fe, fe_pad);
+  ANEMOI_REQUIRE(q && k && v && out && colptr && edge_feat && w_packed, "gt_attention_fused_edge_fwd: null pointer");
+  ANEMOI_REQUIRE(fe_pad >= 4 && fe_pad % 4 == 0, "gt_attention_fused_edge_fwd: fe_pad must be a positive multiple of 4, got %d", fe_pad);
   const int D = H * C;
   ANEMOI_REQUIRE(ldq >= D && ldk >= D && ldv >= D && ldo >= D && (!addend || ldadd >= D), "gt_attention_fused_edge_fwd: leading dimension smaller than H*C=%d", D);
-  AttnArgs a{q, k, v, nullptr, ldq, ldk, ldv, 0, edge_feat, fe, fe_pad, w_edge, b_edge, row, colptr, addend, ldadd, out, ldo, lse, n_dst, n_src, H, C, as_stream(stream)};
+  AttnArgs a{q, k, v, nullptr, ldq, ldk, ldv, 0, edge_feat, fe_pad - 1, fe_pad, w_packed, row, colptr, addend, ldadd, out, ldo, lse, n_dst, n_src, H, C, as_stream(stream)};
   return dispatch(a, dtype);
+}
+
+extern "C" int anemoi_pack_edge_weights(const void* w_edge, const void* b_edge, float* out, int32_t D, int32_t fe,
+                                        int32_t fe_pad, anemoi_dtype_t dtype, void* stream) {
+  ANEMOI_REQUIRE(D > 0 && fe > 0 && fe_pad == 4 * ((fe + 1 + 3) / 4), "pack_edge_weights: bad sizes D=%d fe=%d fe_pad=%d", D, fe, fe_pad);
+  ANEMOI_REQUIRE(w_edge && out, "pack_edge_weights: null pointer");
+  const int n = D * fe_pad;
+  const dim3 grid((n + 255) / 256), block(256);
+  switch (dtype) {
+    case ANEMOI_F32: hipLaunchKernelGGL((pack_edge_weights_kernel<float>), grid, block, 0, as_stream(stream), (const float*)w_edge, (const float*)b_edge, out, D, fe, fe_pad); break;
+    case ANEMOI_BF16: hipLaunchKernelGGL((pack_edge_weights_kernel<bf16_t>), grid, block, 0, as_stream(stream), (const bf16_t*)w_edge, (const bf16_t*)b_edge, out, D, fe, fe_pad); break;
+    case ANEMOI_F16: hipLaunchKernelGGL((pack_edge_weights_kernel<f16_t>), grid, block, 0, as_stream(stream), (const f16_t*)w_edge, (const f16_t*)b_edge, out, D, fe, fe_pad); break;
+    default: set_error("unknown dtype"); return ANEMOI_E_INVALID;
+  }
+  return check_launch("pack_edge_weights_kernel");
 }
 
 extern "C" int anemoi_pack_edge_features(const void* edge_attr, int64_t ld, float* out, int32_t M, int32_t fe,

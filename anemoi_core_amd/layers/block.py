@@ -25,6 +25,7 @@ from .graphcache import get_csc, get_edge_features
 from .kernels import check_inference
 from .mlp import MLP
 from .utils import compute_mlp_hidden_dim
+from ..utils.tensors import version
 
 ANEMOI_DEBUG_SHARDING = os.environ.get("ANEMOI_DEBUG_SHARDING", "") != ""
 
@@ -37,7 +38,7 @@ class _FusedWeights:
 
     def get(self, tag: str, linears: list) -> tuple[Tensor, Tensor]:
         ps = [p for lin in linears for p in (lin.weight, lin.bias) if p is not None]
-        sig = tuple((p.data_ptr(), p._version, p.dtype, str(p.device)) for p in ps)
+        sig = tuple((p.data_ptr(), version(p), p.dtype, str(p.device)) for p in ps)
         hit = self._cache.get(tag)
         if hit is not None and hit[0] == sig:
             return hit[1], hit[2]
@@ -46,6 +47,18 @@ class _FusedWeights:
             b = torch.cat([lin.bias if lin.bias is not None else lin.weight.new_zeros(lin.out_features) for lin in linears]).contiguous()
         self._cache[tag] = (sig, w, b)
         return w, b
+
+    def packed_edge(self, lin_edge) -> Tensor:
+        """fp32 [D, fe_pad] image of lin_edge for the fused attention, rebuilt only when the parameters change."""
+        ps = [p for p in (lin_edge.weight, lin_edge.bias) if p is not None]
+        sig = tuple((p.data_ptr(), version(p), p.dtype, str(p.device)) for p in ps)
+        hit = self._cache.get("edge")
+        if hit is not None and hit[0] == sig:
+            return hit[1]
+        with torch.no_grad():
+            w = ops.pack_edge_weights(lin_edge.weight.contiguous(), lin_edge.bias)
+        self._cache["edge"] = (sig, w)
+        return w
 
 
 class BaseBlock(nn.Module):
@@ -109,7 +122,7 @@ class GraphTransformerBaseBlock(BaseBlock):
             ea = edge_attr if csc.perm is None else edge_attr.index_select(0, csc.perm)
             ea = ops.linear(ea.to(lin.weight.dtype), lin.weight, lin.bias, act="gelu")
             feat = ops.pack_edge_features(ea)
-        return ops.gt_attention_fused_edge(query, key, value, feat, self.lin_edge.weight, self.lin_edge.bias, csc, H, addend=x_r)
+        return ops.gt_attention_fused_edge(query, key, value, feat, self._fused.packed_edge(self.lin_edge), csc, H, addend=x_r)
 
     def _post_attention(self, attn_plus_self: Tensor, x_skip: Tensor) -> Tensor:
         out = ops.linear(attn_plus_self, self.projection.weight, self.projection.bias, residual=x_skip)
@@ -197,7 +210,7 @@ class GraphTransformerProcessorBlock(GraphTransformerBaseBlock):
         if batch_size != 1:
             raise ValueError("GraphTransformerProcessorBlock halo exchange requires batch_size=1 when model sharding is enabled.")
         specs = (comm_size(group), comm_rank(group), tuple(shard_info.nodes or ()), tuple(shard_info.edges or ()),
-                 edge_index.data_ptr(), edge_index._version)
+                 edge_index.data_ptr(), version(edge_index))
         if shared is not None and shared.get("specs") == specs:
             return shared["plan"]
         if self._cached_halo is not None and self._cached_halo[0] == specs:

@@ -5,6 +5,7 @@ from collections import defaultdict
 
 import torch
 from torch import Tensor, nn
+from ..utils.tensors import version
 
 
 class TrainableTensor(nn.Module):
@@ -21,7 +22,7 @@ class TrainableTensor(nn.Module):
         """cat[x repeated B times, trainable repeated B times] along features; cached while the inputs are unchanged
         (the result is a pure function of static buffers and parameters)."""
         t = self.trainable
-        key = (x.data_ptr(), x._version, x.dtype, str(x.device), batch_size, None if t is None else (t.data_ptr(), t._version, t.dtype))
+        key = (x.data_ptr(), version(x), x.dtype, str(x.device), batch_size, None if t is None else (t.data_ptr(), version(t), t.dtype))
         if self._cache is not None and self._cache[0] == key:
             return self._cache[1]
         with torch.no_grad():

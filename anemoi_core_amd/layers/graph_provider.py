@@ -13,6 +13,7 @@ from torch import Tensor, nn
 
 from ..distributed.partition import shard_edges_1hop, sort_edge_index_by_dst
 from .graph import TrainableTensor
+from ..utils.tensors import version
 
 
 class StaticGraphProvider(nn.Module):
@@ -56,7 +57,7 @@ class StaticGraphProvider(nn.Module):
     def get_edges(self, batch_size: int, src_coords=None, dst_coords=None, model_comm_group=None, shard_edges: bool = True,
                   act_checkpoint: bool = True):
         edge_attr = self.trainable(self.edge_attr, batch_size)  # cached by TrainableTensor
-        key = (batch_size, shard_edges, id(model_comm_group), edge_attr.data_ptr(), edge_attr._version, edge_attr.dtype)
+        key = (batch_size, shard_edges, id(model_comm_group), edge_attr.data_ptr(), version(edge_attr), edge_attr.dtype)
         hit = self._cache.get("edges")
         if hit is not None and hit[0] == key:
             return hit[1]

@@ -10,6 +10,7 @@ import torch
 from torch import Tensor
 
 from .. import ops
+from ..utils.tensors import version
 
 
 class _LRU:
@@ -37,7 +38,7 @@ _feat_cache = _LRU()
 
 
 def _key(t: Tensor, *extra):
-    return (t.data_ptr(), t._version, tuple(t.shape), str(t.device), t.dtype, *extra)
+    return (t.data_ptr(), version(t), tuple(t.shape), str(t.device), t.dtype, *extra)
 
 
 def get_csc(edge_index: Tensor, size: tuple, edges_are_dst_sorted: bool = True) -> ops.CSC:

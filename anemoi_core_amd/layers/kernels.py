@@ -11,6 +11,7 @@ import torch
 from torch import Tensor, nn
 
 from .. import ops
+from ..utils.tensors import version
 
 
 def check_inference(*tensors: Tensor) -> None:
@@ -70,7 +71,7 @@ class PaddedLinear:
         pad = (-K) % 8
         if pad == 0 or x.dtype == torch.float32:
             return ops.linear(x, lin.weight, lin.bias, **kw)
-        sig = (lin.weight.data_ptr(), lin.weight._version, lin.weight.dtype, str(lin.weight.device))
+        sig = (lin.weight.data_ptr(), version(lin.weight), lin.weight.dtype, str(lin.weight.device))
         if self._sig != sig:
             with torch.no_grad():
                 self._w = torch.nn.functional.pad(lin.weight, (0, pad)).contiguous()

@@ -31,6 +31,7 @@ from .block import GraphConvMapperBlock, GraphTransformerMapperBlock
 from .kernels import PaddedLinear, check_inference
 from .mlp import MLP
 from .utils import compute_mlp_hidden_dim, load_layer_kernels
+from ..utils.tensors import version
 
 
 class BaseMapper(nn.Module):
@@ -88,7 +89,7 @@ class GraphTransformerBaseMapper(BaseMapper):
     def _local_graph(self, x, shard_info, edge_attr, edge_index, group):
         """Rank-local (dst range, edges, compact sources) — index work only, cached for the static graph."""
         world, rank = comm_size(group), comm_rank(group)
-        key = (edge_index.data_ptr(), edge_index._version, edge_attr.data_ptr(), edge_attr._version, world, rank,
+        key = (edge_index.data_ptr(), version(edge_index), edge_attr.data_ptr(), version(edge_attr), world, rank,
                tuple(shard_info.src_nodes or ()), tuple(shard_info.dst_nodes or ()), tuple(shard_info.edges or ()),
                x[0].shape[0], x[1].shape[0])
 

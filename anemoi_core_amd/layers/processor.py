@@ -14,6 +14,7 @@ from ..distributed.primitives import gather_tensor
 from ..distributed.shapes import GraphShardInfo
 from .block import GraphConvProcessorBlock, GraphTransformerProcessorBlock
 from .utils import compute_mlp_hidden_dim, load_layer_kernels
+from ..utils.tensors import version
 
 
 class BaseProcessor(nn.Module):
@@ -78,7 +79,7 @@ class GraphTransformerProcessor(BaseProcessor):
             edges_are_dst_sorted=edges_are_dst_sorted,
         )
         if not shard_info.edges_are_sharded():  # local slice of the dst-sorted edges (no communication), cached
-            key = (edge_index.data_ptr(), edge_index._version, edge_attr.data_ptr(), edge_attr._version, size, id(model_comm_group))
+            key = (edge_index.data_ptr(), version(edge_index), edge_attr.data_ptr(), version(edge_attr), size, id(model_comm_group))
             if self._shard_cache is None or self._shard_cache[0] != key:
                 self._shard_cache = (key, shard_edges_1hop(edge_attr, edge_index, size, size, model_comm_group, edges_are_dst_sorted=True),
                                      (edge_attr, edge_index))

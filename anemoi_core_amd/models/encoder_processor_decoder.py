@@ -95,6 +95,10 @@ class AnemoiModelEncProcDec(nn.Module):
             self.target_dim[ds] = self.input_dim[ds]
             self.output_dim[ds] = self.n_step_output * self.num_output_channels[ds]
             assert len(self._internal_input_idx[ds]) == len(self._internal_output_idx[ds])
+            # device-resident index vectors (non-persistent: the state_dict stays identical to the reference's) so that
+            # the residual scatter involves no host->device copy and the forward is hipGraph-capturable
+            self.register_buffer(f"_in_idx_{ds}", torch.tensor(self._internal_input_idx[ds], dtype=torch.long), persistent=False)
+            self.register_buffer(f"_out_idx_{ds}", torch.tensor(self._internal_output_idx[ds], dtype=torch.long), persistent=False)
 
     def _build_networks(self, mc, edges) -> None:
         hid = self._graph_name_hidden
@@ -144,9 +148,10 @@ class AnemoiModelEncProcDec(nn.Module):
     def _assemble_output(self, x_out: Tensor, x_skip: Tensor, batch_size: int, ensemble_size: int, dtype, ds: str) -> Tensor:
         N = x_out.shape[0] // (batch_size * ensemble_size)
         x_out = x_out.view(batch_size, ensemble_size, N, self.n_step_output, -1).permute(0, 3, 1, 2, 4).to(dtype=dtype).clone()
-        x_out[..., self._internal_output_idx[ds]] += x_skip.unsqueeze(1)[..., self._internal_input_idx[ds]].to(dtype)
+        in_idx, out_idx = getattr(self, f"_in_idx_{ds}"), getattr(self, f"_out_idx_{ds}")
+        x_out.index_add_(-1, out_idx, x_skip.unsqueeze(1).index_select(-1, in_idx).to(dtype))
         if self._relu_bounding_idx[ds]:
-            idx = self._relu_bounding_idx[ds]
+            idx = torch.as_tensor(self._relu_bounding_idx[ds], device=x_out.device)
             x_out[..., idx] = torch.relu(x_out[..., idx])
         return x_out
 

@@ -150,20 +150,33 @@ def pack_edge_features(edge_attr: Tensor) -> Tensor:
     return out
 
 
-def gt_attention_fused_edge(q: Tensor, k: Tensor, v: Tensor, edge_feat: Tensor, w_edge: Tensor, b_edge: Optional[Tensor],
-                            csc: CSC, num_heads: int, addend: Optional[Tensor] = None, return_lse: bool = False):
-    """Attention with lin_edge fused: edge_feat = pack_edge_features(edge_attr) fp32 [M, fe_pad];
-    w_edge [D, Fe], b_edge [D] in q.dtype."""
-    _dev(q, k, v, edge_feat, w_edge, b_edge, addend, csc.row)
-    D = q.shape[1]
-    fe = w_edge.shape[1]
+def pack_edge_weights(w_edge: Tensor, b_edge: Optional[Tensor]) -> Tensor:
+    """lin_edge parameters -> fp32 [D, fe_pad] = [w_edge | b_edge | 0] for the fused-edge attention."""
+    _dev(w_edge, b_edge)
+    D, fe = w_edge.shape
     fe_pad = edge_feature_pad(fe)
+    if not w_edge.is_contiguous():
+        raise ValueError("w_edge must be contiguous [D, Fe]")
+    out = torch.empty((D, fe_pad), dtype=torch.float32, device=w_edge.device)
+    rc = _lib.load().anemoi_pack_edge_weights(w_edge.data_ptr(), _vec(b_edge, "b_edge", D, w_edge.dtype), out.data_ptr(), D, fe, fe_pad,
+                                              _dt(w_edge), _stream())
+    _lib.check(rc, "pack_edge_weights")
+    return out
+
+
+def gt_attention_fused_edge(q: Tensor, k: Tensor, v: Tensor, edge_feat: Tensor, w_packed: Tensor, csc: CSC, num_heads: int,
+                            addend: Optional[Tensor] = None, return_lse: bool = False):
+    """Attention with lin_edge fused: edge_feat = pack_edge_features(edge_attr) fp32 [M, fe_pad];
+    w_packed = pack_edge_weights(lin_edge.weight, lin_edge.bias) fp32 [D, fe_pad]."""
+    _dev(q, k, v, edge_feat, w_packed, addend, csc.row)
+    D = q.shape[1]
+    fe_pad = w_packed.shape[1]
     if D % num_heads:
         raise ValueError(f"channels {D} not divisible by heads {num_heads}")
     if edge_feat.dtype != torch.float32 or tuple(edge_feat.shape) != (csc.num_edges, fe_pad) or not edge_feat.is_contiguous():
         raise ValueError(f"edge_feat must be contiguous fp32 [{csc.num_edges}, {fe_pad}], got {tuple(edge_feat.shape)} {edge_feat.dtype}")
-    if tuple(w_edge.shape) != (D, fe) or not w_edge.is_contiguous() or w_edge.dtype != q.dtype:
-        raise ValueError(f"w_edge must be contiguous [{D}, {fe}] {q.dtype}")
+    if w_packed.dtype != torch.float32 or tuple(w_packed.shape) != (D, fe_pad) or not w_packed.is_contiguous():
+        raise ValueError(f"w_packed must be contiguous fp32 [{D}, {fe_pad}]")
     if q.shape[0] != csc.n_dst or k.shape[0] != csc.n_src or v.shape[0] != csc.n_src:
         raise ValueError("node counts do not match the graph")
     out = torch.empty((csc.n_dst, D), dtype=q.dtype, device=q.device)
@@ -171,7 +184,7 @@ def gt_attention_fused_edge(q: Tensor, k: Tensor, v: Tensor, edge_feat: Tensor, 
     (qp, ldq), (kp, ldk), (vp, ldv) = _rows(q, "q"), _rows(k, "k", q.dtype), _rows(v, "v", q.dtype)
     ap, lda = _rows(addend, "addend", q.dtype)
     rc = _lib.load().anemoi_gt_attention_fused_edge_fwd(
-        qp, ldq, kp, ldk, vp, ldv, edge_feat.data_ptr(), fe, fe_pad, w_edge.data_ptr(), _vec(b_edge, "b_edge", D, q.dtype),
+        qp, ldq, kp, ldk, vp, ldv, edge_feat.data_ptr(), fe_pad, w_packed.data_ptr(),
         csc.row.data_ptr(), csc.colptr.data_ptr(), ap, lda, out.data_ptr(), D, lse.data_ptr() if return_lse else 0,
         csc.n_dst, csc.n_src, num_heads, D // num_heads, _dt(q), _stream())
     _lib.check(rc, "gt_attention_fused_edge_fwd")

@@ -57,12 +57,17 @@ int anemoi_gt_attention_fwd(const void* q, int64_t ldq, const void* k, int64_t l
 /* Same op with ``lin_edge`` fused: E[e] = edge_attr[e] @ w_edge^T + b_edge is never materialised.
  * Replaces: lin_edge(...) + the op above (layers/block.py:623-635 + triton/gt.py:81-179).
  * edge_feat: fp32 [M, fe_pad] with fe_pad = 4*ceil((Fe+1)/4): columns [0,Fe) = edge_attr, column Fe = 1.0
- * (carries the bias), the rest 0; w_edge: ``dtype`` [H*C, Fe] (ld = Fe); b_edge: ``dtype`` [H*C] or NULL. */
+ * (carries the bias), the rest 0 (anemoi_pack_edge_features);  w_packed: fp32 [H*C, fe_pad] = [w_edge | b_edge | 0]
+ * (anemoi_pack_edge_weights).  Both are built once per static graph / parameter version. */
 int anemoi_gt_attention_fused_edge_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
-                                       const float* edge_feat, int32_t fe, int32_t fe_pad, const void* w_edge,
-                                       const void* b_edge, const int32_t* row, const int32_t* colptr, const void* addend,
-                                       int64_t ldadd, void* out, int64_t ldo, float* lse, int32_t n_dst, int32_t n_src,
-                                       int32_t H, int32_t C, anemoi_dtype_t dtype, void* stream);
+                                       const float* edge_feat, int32_t fe_pad, const float* w_packed,
+                                       const int32_t* row, const int32_t* colptr, const void* addend, int64_t ldadd,
+                                       void* out, int64_t ldo, float* lse, int32_t n_dst, int32_t n_src, int32_t H,
+                                       int32_t C, anemoi_dtype_t dtype, void* stream);
+
+/* Pack lin_edge's parameters for the fused op: out fp32 [D, fe_pad] = [w_edge [D,Fe] | b_edge [D] (or 0) | 0...]. */
+int anemoi_pack_edge_weights(const void* w_edge, const void* b_edge, float* out, int32_t D, int32_t fe, int32_t fe_pad,
+                             anemoi_dtype_t dtype, void* stream);
 
 /* Pack edge attributes for the fused op: out fp32 [M, fe_pad] = [edge_attr | 1 | 0...]. */
 int anemoi_pack_edge_features(const void* edge_attr, int64_t ld, float* out, int32_t M, int32_t fe, int32_t fe_pad,
