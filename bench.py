@@ -226,7 +226,10 @@ def main():
         for _ in range(max(2, args.warmup // 2)):  # builds the static caches, sizes the allocator
             out = step()
         sync_all()
-        if not args.no_graph:
+        # hipGraph capture is single-GPU only: capturing RCCL collectives on this stack either aborts the process (the
+        # ProcessGroupNCCL watchdog queries an event while the stream is capturing -> hipErrorStreamCaptureUnsupported)
+        # or hangs (capture_error_mode="thread_local"); measured with tools/nccl_capture_probe.py.  N > 1 runs eagerly.
+        if not args.no_graph and world == 1:
             try:  # capture the whole forward (kernels are enqueued on torch's current stream through the C ABI)
                 s = torch.cuda.Stream()
                 s.wait_stream(torch.cuda.current_stream())

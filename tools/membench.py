@@ -1,7 +1,8 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from anemoi_core_amd import ops
-from tools.gemm_sweep import timeit
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from gemm_sweep import timeit
 N = 10242
 for D in (512, 2048):
     x = torch.randn(N, D, device="cuda").to(torch.bfloat16)
