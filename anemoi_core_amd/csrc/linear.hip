@@ -306,226 +306,59 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(LinArgs a, int tile
   mfma_epilogue<T>(a, acc, m0, n0, wr, wc, lane, smem + wave * 16384);  // 4 x 16 KiB = the 64 KiB of operand stages
 }
 
-// ---------------------------------------------------------------------------------------------- MFMA + LDS-DMA path
-// Same tile geometry, but the operand tiles travel HBM/L2 -> LDS by global_load_lds_dwordx4 (no VGPR round trip, no
-// ds_write pass: at 128x128x64 the ds_write_b128 traffic alone (~80 B/clk/CU) costs more LDS cycles than the MFMAs).
-// The DMA writes lane-linear (wave-uniform base + lane*16), so the XOR swizzle is applied to the per-lane SOURCE
-// address and again on the fragment reads (same involution both sides).  One 1-KiB piece = 8 tile rows; a wave issues
-// 4 A pieces + 4 W pieces per K-tile.  Two LDS stages: the DMA of tile kt+1 is in flight while tile kt is multiplied.
+// ---------------------------------------------------------------------------------------------- persistent ring kernel
+// Main MFMA path (K1, K2 multiples of 64).  Design notes, from measurements on MI355X at [10242 x 512] x [512 -> 2048]:
+//  * operands travel HBM/L2 -> LDS by global_load_lds_dwordx4 (no VGPR round trip / ds_write pass); the DMA writes
+//    lane-linear, so the XOR slot swizzle is applied to the per-lane SOURCE address and again on the fragment reads;
+//  * 256 x 128 output tile per 8-wave workgroup (4 x 2 waves of 64 x 64): half the operand bytes per flop of a 128^2
+//    tile (a CU's vector-memory path moves ~64 B/clk, a 128^2 x 64 step needs 32 KiB for 2 MFLOP);
+//  * one workgroup per CU walks its tiles in a loop and the 3-stage operand ring never drains: the first K-tiles of
+//    tile t+1 are already in flight during the epilogue of tile t.  Waits are COUNTED (vmcnt), the barrier is a raw
+//    s_barrier (a __syncthreads() would drain the DMA queue);
+//  * gfx950 counts stores in vmcnt in issue order: an interior tile leaves exactly 16 stores per wave in the queue, so
+//    the next tile's first K-steps wait with vmcnt(ring + 16) and the stores drain under the MFMAs;
+//  * the epilogue is specialised at compile time (EPI flags): residual / gather rows are fetched up front, the
+//    accumulators go through a wave-private LDS band (swizzled, conflict-free) so that every global access of the
+//    epilogue is a whole 128-byte line.
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
-template <typename T>
-__global__ __launch_bounds__(256, 2) void linear_mfma_glds_kernel(LinArgs a, int tiles_n, int num_tiles) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 stages][A tile | W tile]
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+enum : int { EPI_RES = 1, EPI_GATHER = 2, EPI_GELU = 4 };
 
-  int id = blockIdx.x;
-  {
-    const int q = num_tiles >> 3, r = num_tiles & 7, xcd = id & 7, pos = id >> 3;
-    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
-  }
-  const int m0 = (id / tiles_n) * BM, n0 = (id % tiles_n) * BN;
-
-  const T* __restrict__ x = (const T*)a.x;
-  const T* __restrict__ x2 = (const T*)a.x2;
-  const T* __restrict__ w = (const T*)a.w;
-  const int K = a.K1 + a.K2;
-  const int nk = K / BK;
-
-  // per-lane source offsets of this wave's 4 pieces (rows p*8 + lane/8, physical slot lane%8 -> logical slot by XOR)
-  int64_t a_off[4], a2_off[4], w_off[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (wave * 4 + i) * 8 + (lane >> 3);
-    const int slot = (lane & 7) ^ ((row >> 1) & 7);
-    const int m = min(m0 + row, a.n_rows - 1);
-    const int n = min(n0 + row, a.O - 1);
-    a_off[i] = (int64_t)m * a.ldx + slot * 8;
-    a2_off[i] = (int64_t)m * a.ldx2 + slot * 8 - a.K1;
-    w_off[i] = (int64_t)n * a.ldw + slot * 8;
-  }
-  auto issue = [&](int kt, int buf) {
-    const int k0 = kt * BK;
-    unsigned char* base = smem + buf * 2 * kTileBytes + (wave * 4) * 1024;
-    const bool first = k0 < a.K1;  // block-uniform: K1 is a multiple of BK on this path
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const T* ap = first ? (x + a_off[i] + k0) : (x2 + a2_off[i] + k0);
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)ap, (lds_void_t*)(base + i * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(w + w_off[i] + k0), (lds_void_t*)(base + kTileBytes + i * 1024), 16, 0, 0);
-    }
-  };
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  issue(0, 0);
-  const int frow = lane & 15, fslot = lane >> 4;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // tile kt has landed for every wave; everybody is done reading the other stage
-    if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
-    const unsigned char* As = smem + buf * 2 * kTileBytes;
-    const unsigned char* Ws = As + kTileBytes;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      frag8 fa[4], fw[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        fa[i] = *reinterpret_cast<const frag8*>(As + lds_off(wr * 64 + i * 16 + frow, fslot + 4 * ks));
-        fw[i] = *reinterpret_cast<const frag8*>(Ws + lds_off(wc * 64 + i * 16 + frow, fslot + 4 * ks));
-      }
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16<T>(fw[ni], fa[mi], acc[mi][ni]);
-    }
-  }
-  __syncthreads();  // every wave is done with the operand stages
-  mfma_epilogue<T>(a, acc, m0, n0, wr, wc, lane, smem + wave * 16384);
-}
-
-// ---------------------------------------------------------------------------------------------- MFMA, big tile, 3-stage DMA ring
-// Why a bigger tile: a CU's vector-memory path moves ~64 B/clk; a 128x128x64 step needs 32 KiB of operands for
-// 2*128*128*64 flop, i.e. the operand fetch alone takes as long as the MFMAs (2 workgroups per CU), and 128x128 tiles
-// also ask more than the L2 can deliver chip-wide at the MFMA roof.  WM x WN waves of 64x64 each share one
-// (64*WM) x (64*WN) tile: 256x128 halves the bytes per flop.  Operands arrive by LDS-DMA into a ring of STAGES
-// buffers; a wave waits with a COUNTED vmcnt (the newest tile stays in flight across the barrier) and the barrier is a
-// raw s_barrier (a __syncthreads() would drain the DMA queue: guide, "glds vs register staging").
-template <typename T, int WM, int WN, int STAGES>
-__global__ __launch_bounds__(64 * WM * WN, 1) void linear_mfma_ring_kernel(LinArgs a, int tiles_n, int num_tiles) {
-  constexpr int NW = WM * WN;
-  constexpr int TBM = 64 * WM, TBN = 64 * WN;
-  constexpr int kAPieces = TBM / 8, kWPieces = TBN / 8;       // 1-KiB pieces (8 rows of 64 elements)
-  constexpr int kPPW = (kAPieces + kWPieces) / NW;            // pieces per wave per K-tile
-  static_assert((kAPieces + kWPieces) % NW == 0, "pieces must divide evenly over the waves");
-  constexpr int kStageBytes = (TBM + TBN) * BK * 2;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [STAGES][A tile | W tile]
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wr = wave / WN, wc = wave % WN;
-
-  int id = blockIdx.x;
-  {
-    const int q = num_tiles >> 3, r = num_tiles & 7, xcd = id & 7, pos = id >> 3;
-    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
-  }
-  const int m0 = (id / tiles_n) * TBM, n0 = (id % tiles_n) * TBN;
-
-  const T* __restrict__ x = (const T*)a.x;
-  const T* __restrict__ x2 = (const T*)a.x2;
-  const T* __restrict__ w = (const T*)a.w;
-  const int K = a.K1 + a.K2;
-  const int nk = K / BK;
-
-  // this wave's pieces: global piece p = wave * kPPW + i; p < kAPieces -> A rows, else W rows
-  int64_t off1[kPPW], off2[kPPW];
-  int lds_piece[kPPW];
-  bool is_a[kPPW];
-#pragma unroll
-  for (int i = 0; i < kPPW; ++i) {
-    const int p = wave * kPPW + i;
-    is_a[i] = p < kAPieces;
-    const int pr = is_a[i] ? p : p - kAPieces;
-    const int row = pr * 8 + (lane >> 3);
-    const int slot = (lane & 7) ^ ((row >> 1) & 7);
-    if (is_a[i]) {
-      const int m = min(m0 + row, a.n_rows - 1);
-      off1[i] = (int64_t)m * a.ldx + slot * 8;
-      off2[i] = (int64_t)m * a.ldx2 + slot * 8 - a.K1;
-      lds_piece[i] = pr * 1024;
-    } else {
-      const int n = min(n0 + row, a.O - 1);
-      off1[i] = (int64_t)n * a.ldw + slot * 8;
-      off2[i] = 0;
-      lds_piece[i] = TBM * BK * 2 + pr * 1024;
-    }
-  }
-  auto issue = [&](int kt) {
-    const int k0 = kt * BK;
-    unsigned char* base = smem + (kt % STAGES) * kStageBytes;
-    const bool first = k0 < a.K1;
-#pragma unroll
-    for (int i = 0; i < kPPW; ++i) {
-      const T* src = is_a[i] ? (first ? (x + off1[i] + k0) : (x2 + off2[i] + k0)) : (w + off1[i] + k0);
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(base + lds_piece[i]), 16, 0, 0);
-    }
-  };
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll
-  for (int s = 0; s < STAGES - 1; ++s)
-    if (s < nk) issue(s);
-
-  const int frow = lane & 15, fslot = lane >> 4;
-  for (int kt = 0; kt < nk; ++kt) {
-    // tile kt must have landed; tiles kt+1 .. kt+STAGES-2 may stay in flight
-    if (kt + STAGES - 2 < nk) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * kPPW) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1);  // overwrites the stage read in iteration kt-1 (all waves passed the barrier)
-    const unsigned char* As = smem + (kt % STAGES) * kStageBytes;
-    const unsigned char* Ws = As + TBM * BK * 2;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      frag8 fa[4], fw[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        fa[i] = *reinterpret_cast<const frag8*>(As + lds_off(wr * 64 + i * 16 + frow, fslot + 4 * ks));
-        fw[i] = *reinterpret_cast<const frag8*>(Ws + lds_off(wc * 64 + i * 16 + frow, fslot + 4 * ks));
-      }
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16<T>(fw[ni], fa[mi], acc[mi][ni]);
-    }
-  }
-  __syncthreads();  // every wave is done with the operand stages (NW * 16 KiB <= STAGES * stage bytes)
-  static_assert(NW * 16384 <= STAGES * kStageBytes, "epilogue staging does not fit in the operand ring");
-  mfma_epilogue<T>(a, acc, m0, n0, wr, wc, lane, smem + wave * 16384);
-}
-
-// ---------------------------------------------------------------------------------------------- persistent ring kernel
-// The K sweep of the one-tile-per-workgroup kernels shows a FIXED cost of ~22 us at [10242 x 2048] outputs (pipeline
-// fill + epilogue + store drain, paid once per tile with nothing else running on the CU) against ~2.8 us per 64-deep
-// K-step: at K = 512 the fixed part is half of the run time.  Here one workgroup per CU walks its tiles in a loop and
-// the operand ring never drains: the DMA for the first K-tiles of tile t+1 is issued during the last K-steps of tile
-// t, so its latency hides under the epilogue of tile t, and the epilogue's stores drain under the MFMAs of tile t+1.
-// The K-tiles of all tiles of a workgroup form one sequence g = j*nk + kt; stage(g) = g % STAGES.  The epilogue stages
-// the accumulators (one 16-row band of each wave at a time, 4 KiB per wave) in the stage that was read last, which is
-// exactly the one the ring refills next — after the barrier every wave passes at the start of the next K-step.
-template <typename T>
+// acc[mi][ni][r] = out[m0 + wr*64 + mi*16 + (lane & 15)][n0 + wc*64 + ni*16 + (lane>>4)*4 + r]
+// epi: this wave's 4 KiB LDS slice (16 rows x 256 B); one 16-row band (mi) at a time.
+template <typename T, int EPI>
 __device__ __forceinline__ void mfma_epilogue_band(const LinArgs& a, f32x4 (&acc)[4][4], int m0, int n0, int wr, int wc,
                                                    int lane, unsigned char* epi, bool interior) {
-  // epi: this wave's 4 KiB slice (16 rows x 256 B).  Same swizzle / read-back as mfma_epilogue, band by band.
   const T* __restrict__ bias = (const T*)a.bias;
-  const T* __restrict__ g1 = (const T*)a.g1;
-  const T* __restrict__ g2 = (const T*)a.g2;
-  const T* __restrict__ res = (const T*)a.residual;
   T* __restrict__ y = (T*)a.y;
   using V4 = Vec<T, 4>;
   const int nc = n0 + wc * 64 + (lane & 15) * 4;
-  const bool n_ok = interior || nc < a.O;
+  const bool n_ok = interior || nc < a.O;  // O % 4 == 0: a 4-column group is entirely inside or outside
+  const int mrow0 = m0 + wr * 64 + (lane >> 4);  // + mi*16 + it*4
   float bv[4] = {0.f, 0.f, 0.f, 0.f};
   if (bias != nullptr && n_ok) load_vec<T, 4>(bias + nc, bv);
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
+    // operands of this band that do not depend on the accumulators: issue their loads first
+    V4 rv[4], t1[4], t2[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int m = mrow0 + mi * 16 + it * 4;
+      const bool ok = interior || (n_ok && m < a.n_rows);
+      rv[it] = V4{};
+      t1[it] = V4{};
+      t2[it] = V4{};
+      if constexpr ((EPI & EPI_RES) != 0) {
+        if (ok) rv[it] = *reinterpret_cast<const V4*>((const T*)a.residual + (int64_t)m * a.ldr + nc);
+      }
+      if constexpr ((EPI & EPI_GATHER) != 0) {
+        if (ok) {
+          t1[it] = *reinterpret_cast<const V4*>((const T*)a.g1 + (int64_t)a.idx1[m] * a.ldg1 + nc);
+          if (a.g2 != nullptr) t2[it] = *reinterpret_cast<const V4*>((const T*)a.g2 + (int64_t)a.idx2[m] * a.ldg2 + nc);
+        }
+      }
+    }
     {
       const int row = lane & 15;
 #pragma unroll
@@ -535,54 +368,53 @@ __device__ __forceinline__ void mfma_epilogue_band(const LinArgs& a, f32x4 (&acc
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    f32x4 c[4];
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int row = it * 4 + (lane >> 4);
-      const int m = m0 + wr * 64 + mi * 16 + row;
-      const bool ok = interior || (n_ok && m < a.n_rows);
-      const int slot = (lane & 15) ^ row;
-      const f32x4 c = *reinterpret_cast<const f32x4*>(epi + row * 256 + slot * 16);
-      float vv[4] = {c[0] + bv[0], c[1] + bv[1], c[2] + bv[2], c[3] + bv[3]};
-      V4 t1{}, t2{}, rv{};
-      if (g1 != nullptr && ok) t1 = *reinterpret_cast<const V4*>(g1 + (int64_t)a.idx1[m] * a.ldg1 + nc);
-      if (g2 != nullptr && ok) t2 = *reinterpret_cast<const V4*>(g2 + (int64_t)a.idx2[m] * a.ldg2 + nc);
-      if (res != nullptr && ok) rv = *reinterpret_cast<const V4*>(res + (int64_t)m * a.ldr + nc);
-      if (g1 != nullptr) {
+      c[it] = *reinterpret_cast<const f32x4*>(epi + row * 256 + (((lane & 15) ^ row) << 4));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // band consumed: the next band may overwrite the slice
 #pragma unroll
-        for (int r = 0; r < 4; ++r) vv[r] += to_float(t1.v[r]) + to_float(t2.v[r]);
+    for (int it = 0; it < 4; ++it) {
+      const int m = mrow0 + mi * 16 + it * 4;
+      const bool ok = interior || (n_ok && m < a.n_rows);
+      float vv[4] = {c[it][0] + bv[0], c[it][1] + bv[1], c[it][2] + bv[2], c[it][3] + bv[3]};
+      if constexpr ((EPI & EPI_GATHER) != 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vv[r] += to_float(t1[it].v[r]) + to_float(t2[it].v[r]);
       }
-      if (a.act == ANEMOI_ACT_GELU) {
+      if constexpr ((EPI & EPI_GELU) != 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) vv[r] = gelu_erf(vv[r]);
       }
-      if (res != nullptr) {
+      if constexpr ((EPI & EPI_RES) != 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) vv[r] += to_float(rv.v[r]);
+        for (int r = 0; r < 4; ++r) vv[r] += to_float(rv[it].v[r]);
       }
       if (ok) store_vec<T, 4>(y + (int64_t)m * a.ldy + nc, vv);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // band read before the next band overwrites the slice
   }
 }
 
-template <typename T, int WM, int WN, int STAGES>
+template <typename T, int WM, int WN, int STAGES, int EPI>
 __global__ __launch_bounds__(64 * WM * WN, 1) void linear_mfma_persistent_kernel(LinArgs a, int tiles_n, int num_tiles) {
   constexpr int NW = WM * WN;
   constexpr int TBM = 64 * WM, TBN = 64 * WN;
-  constexpr int kAPieces = TBM / 8, kWPieces = TBN / 8;
-  constexpr int kPPW = (kAPieces + kWPieces) / NW;
-  static_assert((kAPieces + kWPieces) % NW == 0, "pieces must divide evenly over the waves");
+  constexpr int kAPW = TBM / 8 / NW, kWPW = TBN / 8 / NW;  // 1-KiB pieces (8 rows x 64 elements) per wave per K-tile
+  static_assert((TBM / 8) % NW == 0 && (TBN / 8) % NW == 0, "operand pieces must divide evenly over the waves");
+  constexpr int kPPW = kAPW + kWPW;
   constexpr int kStageBytes = (TBM + TBN) * BK * 2;
   static_assert(NW * 4096 <= kStageBytes, "epilogue band staging must fit in one stage");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [STAGES][A tile | W tile]
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / WN, wc = wave % WN;
   const int G = gridDim.x;  // multiple of 8 (or == num_tiles): all tiles of a workgroup map to its XCD's id range
 
-  const T* __restrict__ x = (const T*)a.x;
-  const T* __restrict__ x2 = (const T*)a.x2;
-  const T* __restrict__ w = (const T*)a.w;
+  const char* __restrict__ xb = (const char*)a.x;
+  const char* __restrict__ x2b = (const char*)a.x2;
+  const char* __restrict__ wb = (const char*)a.w;
   const int K = a.K1 + a.K2;
   const int nk = K / BK;
   const int my_tiles = (num_tiles - (int)blockIdx.x + G - 1) / G;
@@ -596,35 +428,26 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void linear_mfma_persistent_kernel
     n0 = (id % tiles_n) * TBN;
   };
 
-  // ---- DMA issue side (runs STAGES-1 K-tiles ahead of the MFMA side, across tile boundaries)
-  int64_t off1[kPPW], off2[kPPW];
-  int lds_piece[kPPW];
-  bool is_a[kPPW];
-#pragma unroll
-  for (int i = 0; i < kPPW; ++i) {
-    const int p = wave * kPPW + i;
-    is_a[i] = p < kAPieces;
-    const int pr = is_a[i] ? p : p - kAPieces;
-    lds_piece[i] = is_a[i] ? pr * 1024 : TBM * BK * 2 + pr * 1024;
-  }
+  // ---- DMA issue side (runs STAGES-1 K-tiles ahead of the MFMA side, across tile boundaries).  Addresses are a
+  // wave-uniform 64-bit base (operand + K offset) plus a per-lane 32-bit byte offset fixed for the tile.
+  uint32_t a_voff[kAPW], a2_voff[kAPW], w_voff[kWPW];
   auto setup_issue_tile = [&](int j) {
     int m0, n0;
     tile_origin(j, m0, n0);
 #pragma unroll
-    for (int i = 0; i < kPPW; ++i) {
-      const int p = wave * kPPW + i;
-      const int pr = is_a[i] ? p : p - kAPieces;
-      const int row = pr * 8 + (lane >> 3);
+    for (int i = 0; i < kAPW; ++i) {
+      const int row = (wave * kAPW + i) * 8 + (lane >> 3);
       const int slot = (lane & 7) ^ ((row >> 1) & 7);
-      if (is_a[i]) {
-        const int m = min(m0 + row, a.n_rows - 1);
-        off1[i] = (int64_t)m * a.ldx + slot * 8;
-        off2[i] = (int64_t)m * a.ldx2 + slot * 8 - a.K1;
-      } else {
-        const int n = min(n0 + row, a.O - 1);
-        off1[i] = (int64_t)n * a.ldw + slot * 8;
-        off2[i] = 0;
-      }
+      const int m = min(m0 + row, a.n_rows - 1);  // rows past the end are computed but never stored
+      a_voff[i] = (uint32_t)(((int64_t)m * a.ldx + slot * 8) * 2);
+      a2_voff[i] = (uint32_t)(((int64_t)m * a.ldx2 + slot * 8) * 2);
+    }
+#pragma unroll
+    for (int i = 0; i < kWPW; ++i) {
+      const int row = (wave * kWPW + i) * 8 + (lane >> 3);
+      const int slot = (lane & 7) ^ ((row >> 1) & 7);
+      const int n = min(n0 + row, a.O - 1);
+      w_voff[i] = (uint32_t)(((int64_t)n * a.ldw + slot * 8) * 2);
     }
   };
   int ig = 0, ikt = 0, ij = 0;  // next K-tile to issue: global index, index within its tile, tile
@@ -632,13 +455,18 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void linear_mfma_persistent_kernel
     if (ig >= total_g) return;
     if (ikt == 0) setup_issue_tile(ij);
     const int k0 = ikt * BK;
-    unsigned char* base = smem + (ig % STAGES) * kStageBytes;
-    const bool first = k0 < a.K1;
+    unsigned char* stage = smem + (ig % STAGES) * kStageBytes;
+    const bool first = k0 < a.K1;  // uniform
+    const char* abase = first ? xb + (int64_t)k0 * 2 : x2b + (int64_t)(k0 - a.K1) * 2;
+    const char* wbase = wb + (int64_t)k0 * 2;
 #pragma unroll
-    for (int i = 0; i < kPPW; ++i) {
-      const T* src = is_a[i] ? (first ? (x + off1[i] + k0) : (x2 + off2[i] + k0)) : (w + off1[i] + k0);
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(base + lds_piece[i]), 16, 0, 0);
-    }
+    for (int i = 0; i < kAPW; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(abase + (first ? a_voff[i] : a2_voff[i])),
+                                       (lds_void_t*)(stage + (wave * kAPW + i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < kWPW; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(wbase + w_voff[i]),
+                                       (lds_void_t*)(stage + TBM * BK * 2 + (wave * kWPW + i) * 1024), 16, 0, 0);
     ++ig;
     if (++ikt == nk) {
       ikt = 0;
@@ -648,13 +476,17 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void linear_mfma_persistent_kernel
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s) issue_next();
 
+  // fragment read offsets inside a stage: row = w*64 + i*16 + (lane&15) -> the swizzle term does not depend on i
   const int frow = lane & 15, fslot = lane >> 4;
+  int a_rd[2], w_rd[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    a_rd[ks] = lds_off(wr * 64 + frow, fslot + 4 * ks);
+    w_rd[ks] = TBM * BK * 2 + lds_off(wc * 64 + frow, fslot + 4 * ks);
+  }
+
   int g = 0;
-  // VM-queue bookkeeping across tiles (gfx950 counts stores in vmcnt, in issue order).  After the epilogue of an
-  // INTERIOR tile exactly kEpiStores stores per wave sit in the queue behind the two prefetched K-tiles, so the first
-  // STAGES-1 K-steps of the next tile wait with vmcnt(ring + kEpiStores): the stores drain under the MFMAs instead of
-  // stalling the wave.  Edge tiles (predicated stores: unknown count) fall back to one full drain.
-  constexpr int kEpiStores = 16;
+  constexpr int kEpiStores = 16;  // stores per wave of an interior tile's epilogue
   bool counted_stores = false, drain_all = false;
   for (int j = 0; j < my_tiles; ++j) {
     int m0, n0;
@@ -666,9 +498,8 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void linear_mfma_persistent_kernel
       for (int jj = 0; jj < 4; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int kt = 0; kt < nk; ++kt, ++g) {
-      // K-tile g must have landed; the STAGES-2 newer tiles may stay in flight.  Stores of the previous epilogue sit
-      // behind them in the queue: drain everything once per tile (their latency has been covered by the epilogue's
-      // own LDS phase and by the DMA that was already in flight).
+      // K-tile g must have landed; the STAGES-2 newer K-tiles (and, right after an interior epilogue, its stores) may
+      // stay in flight
       if (drain_all || g + STAGES - 2 >= total_g) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         drain_all = false;
@@ -681,31 +512,29 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void linear_mfma_persistent_kernel
       }
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      issue_next();
-      const unsigned char* As = smem + (g % STAGES) * kStageBytes;
-      const unsigned char* Ws = As + TBM * BK * 2;
+      issue_next();  // refills the stage read in the previous K-step (every wave has passed the barrier)
+      const unsigned char* st = smem + (g % STAGES) * kStageBytes;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         frag8 fa[4], fw[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          fa[i] = *reinterpret_cast<const frag8*>(As + lds_off(wr * 64 + i * 16 + frow, fslot + 4 * ks));
-          fw[i] = *reinterpret_cast<const frag8*>(Ws + lds_off(wc * 64 + i * 16 + frow, fslot + 4 * ks));
+          fa[i] = *reinterpret_cast<const frag8*>(st + a_rd[ks] + i * 16 * BK * 2);
+          fw[i] = *reinterpret_cast<const frag8*>(st + w_rd[ks] + i * 16 * BK * 2);
         }
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16<T>(fw[ni], fa[mi], acc[mi][ni]);
+          for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16<T>(fw[ni], fa[mi], acc[mi][ni]);  // D^T tile: rows n, cols m
       }
     }
     // epilogue in the stage that was just read (stage (g-1) % STAGES): every wave must be done reading it
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     const bool interior = (m0 + TBM <= a.n_rows) && (n0 + TBN <= a.O);
-    mfma_epilogue_band<T>(a, acc, m0, n0, wr, wc, lane, smem + ((g - 1) % STAGES) * kStageBytes + wave * 4096, interior);
-    // An interior tile issues exactly kEpiStores stores per wave; every load of the epilogue (bias, residual, gather
-    // rows) has been consumed - hence waited for, together with everything older - before the last store is issued.
-    // Edge tiles predicate their stores (unknown count): full drain at the next K-step.
+    mfma_epilogue_band<T, EPI>(a, acc, m0, n0, wr, wc, lane, smem + ((g - 1) % STAGES) * kStageBytes + wave * 4096, interior);
+    // An interior tile issues exactly kEpiStores stores per wave, and every load of its epilogue has been consumed
+    // (waited for, with everything older) before the last store was issued.  Edge tiles predicate their stores.
     if (interior && nk >= STAGES)
       counted_stores = true;
     else
@@ -733,48 +562,51 @@ static int launch_generic(const LinArgs& a, hipStream_t st) {
 }
 
 template <typename T>
-static bool glds_eligible(const LinArgs& a) { return a.K1 % BK == 0 && a.K2 % BK == 0; }
+static bool ring_eligible(const LinArgs& a) {
+  // K-tiles are whole, and the per-lane 32-bit byte offsets of the DMA addressing cover the operands
+  const int64_t lim = (int64_t)1 << 31;
+  return a.K1 % BK == 0 && a.K2 % BK == 0 && (int64_t)a.n_rows * a.ldx * 2 < lim && (int64_t)a.O * a.ldw * 2 < lim &&
+         (a.x2 == nullptr || (int64_t)a.n_rows * a.ldx2 * 2 < lim);
+}
+
+template <typename T, int EPI>
+static int launch_persistent(const LinArgs& a, hipStream_t st) {
+  constexpr int WM = 4, WN = 2, ST = 3;  // 256 x 128 tile, 8 waves, 3-stage ring: 144 KiB LDS, one workgroup per CU
+  constexpr int smem_bytes = ST * (64 * WM + 64 * WN) * BK * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_mfma_persistent_kernel<T, WM, WN, ST, EPI>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+    attr_set = true;
+  }
+  const int tm = (a.n_rows + 64 * WM - 1) / (64 * WM), tn = (a.O + 64 * WN - 1) / (64 * WN);
+  const int nt = tm * tn;
+  const int grid = nt < 256 ? nt : 256;
+  hipLaunchKernelGGL((linear_mfma_persistent_kernel<T, WM, WN, ST, EPI>), dim3(grid), dim3(64 * WM * WN), smem_bytes, st, a, tn, nt);
+  return check_launch("linear_mfma_persistent_kernel");
+}
 
 template <typename T>
 static int launch_mfma(const LinArgs& a, hipStream_t st) {
+  if (ring_eligible<T>(a)) {
+    const int epi = (a.residual ? EPI_RES : 0) | (a.g1 ? EPI_GATHER : 0) | (a.act == ANEMOI_ACT_GELU ? EPI_GELU : 0);
+    switch (epi) {
+      case 0: return launch_persistent<T, 0>(a, st);
+      case 1: return launch_persistent<T, 1>(a, st);
+      case 2: return launch_persistent<T, 2>(a, st);
+      case 3: return launch_persistent<T, 3>(a, st);
+      case 4: return launch_persistent<T, 4>(a, st);
+      case 5: return launch_persistent<T, 5>(a, st);
+      case 6: return launch_persistent<T, 6>(a, st);
+      default: return launch_persistent<T, 7>(a, st);
+    }
+  }
   const int tiles_m = (a.n_rows + BM - 1) / BM, tiles_n = (a.O + BN - 1) / BN;
   const int num_tiles = tiles_m * tiles_n;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_mfma_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kTileBytes);
     attr_set = true;
-  }
-  if (glds_eligible<T>(a) && a.n_rows >= 1024) {
-    // 256x128 tile, 8 waves, 3-stage ring (144 KiB LDS, one workgroup per CU)
-    constexpr int WM = 4, WN = 2, ST = 3;
-    constexpr int smem_bytes = ST * (64 * WM + 64 * WN) * BK * 2;
-    static bool attr3_set = false;
-    if (!attr3_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_mfma_ring_kernel<T, WM, WN, ST>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
-      attr3_set = true;
-    }
-    const int tm = (a.n_rows + 64 * WM - 1) / (64 * WM), tn = (a.O + 64 * WN - 1) / (64 * WN);
-    const int nt = tm * tn;
-    if (nt > 256) {  // more tiles than CUs: persistent workgroups, one per CU, ring kept full across tiles
-      static bool attr4_set = false;
-      if (!attr4_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_mfma_persistent_kernel<T, WM, WN, ST>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
-        attr4_set = true;
-      }
-      hipLaunchKernelGGL((linear_mfma_persistent_kernel<T, WM, WN, ST>), dim3(256), dim3(64 * WM * WN), smem_bytes, st, a, tn, nt);
-      return check_launch("linear_mfma_persistent_kernel");
-    }
-    hipLaunchKernelGGL((linear_mfma_ring_kernel<T, WM, WN, ST>), dim3(nt), dim3(64 * WM * WN), smem_bytes, st, a, tn, nt);
-    return check_launch("linear_mfma_ring_kernel");
-  }
-  if (glds_eligible<T>(a)) {
-    static bool attr2_set = false;
-    if (!attr2_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_mfma_glds_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kTileBytes);
-      attr2_set = true;
-    }
-    hipLaunchKernelGGL((linear_mfma_glds_kernel<T>), dim3(num_tiles), dim3(256), 4 * kTileBytes, st, a, tiles_n, num_tiles);
-    return check_launch("linear_mfma_glds_kernel");
   }
   hipLaunchKernelGGL((linear_mfma_kernel<T>), dim3(num_tiles), dim3(256), 4 * kTileBytes, st, a, tiles_n, num_tiles);
   return check_launch("linear_mfma_kernel");

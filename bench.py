@@ -135,6 +135,59 @@ def time_kernels(model, g, args, dtype, device):
     return out
 
 
+def profile_forward(step, dtype):
+    """One extra EAGER forward with a HIP-event pair (on the launch stream) around every kernel entry point: per kernel
+    family the call count, summed device time and summed ALGORITHMIC work (flops for the GEMMs, bytes for the rest).
+    These are the figures the `roofline` object is built from; profiles/ holds the rocprofv3 --kernel-trace --stats
+    summary of the same command for cross-checking."""
+    from anemoi_core_amd import ops
+
+    es = torch.tensor([], dtype=dtype).element_size()
+    rec = []
+
+    def wrap(name, fn, work):
+        def inner(*a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **kw)
+            e1.record()
+            rec.append((name, work(out, *a, **kw), e0, e1))
+            return out
+        return inner
+
+    def lin_work(out, x, w, bias=None, **kw):
+        K = w.shape[1]
+        fam = "linear_mfma_*" if (x.dtype != torch.float32 and x.shape[1] % 8 == 0 and (kw.get("x2") is None or kw["x2"].shape[1] % 8 == 0) and w.shape[0] % 4 == 0) else "linear_generic_kernel"
+        return fam, 2.0 * x.shape[0] * K * w.shape[0], "flop"
+
+    def attn_work(out, q, k, v, feat, wp, csc, H, **kw):
+        D = q.shape[1]
+        # compulsory traffic: q, out, self-term (3 N_dst D) + k, v (2 N_src D) + edge features + indices (SURVEY.md 8d, lin_edge fused)
+        return "gt_attn_fused_edge_fwd_kernel", es * (3 * csc.n_dst * D + 2 * csc.n_src * D) + 4 * csc.num_edges * feat.shape[1] + 4 * (csc.num_edges + csc.n_dst + 1), "byte"
+
+    def ln_work(out, x, *a, **kw):
+        return "layernorm_fwd_kernel", 2 * x.numel() * es, "byte"
+
+    saved = {n: getattr(ops, n) for n in ("linear", "gt_attention_fused_edge", "layer_norm")}
+    ops.linear = wrap("linear", saved["linear"], lin_work)
+    ops.gt_attention_fused_edge = wrap("attn", saved["gt_attention_fused_edge"], attn_work)
+    ops.layer_norm = wrap("ln", saved["layer_norm"], ln_work)
+    try:
+        torch.cuda.synchronize()
+        step()
+        torch.cuda.synchronize()
+    finally:
+        for n, f in saved.items():
+            setattr(ops, n, f)
+    fam = {}
+    for _, (name, work, unit), e0, e1 in rec:
+        d = fam.setdefault(name, {"calls": 0, "us": 0.0, "work": 0.0, "unit": unit})
+        d["calls"] += 1
+        d["us"] += e0.elapsed_time(e1) * 1e3
+        d["work"] += work
+    return fam
+
+
 def cpu_baseline(model_fp32_params, cfg, g, x, layers_sample):
     """The oracle (CPU restatement of the reference, parity-pinned) on the host cores: encoder + ``layers_sample``
     processor layers + decoder are timed once each, the full forward is t_enc + L * t_layer + t_dec."""
@@ -275,17 +328,29 @@ def main():
         }
         if world == 1 and args.kind == "gt" and not args.no_kernel_timing:
             with torch.inference_mode():
-                ks = time_kernels(model, g, args, dtype, device)
-            res["kernels"] = ks
-            L = args.layers
-            layer_us = sum(v["us"] for v in ks.values()) + ks["layernorm"]["us"]  # two LayerNorms per layer
-            dom = max((k for k in ks if ks[k]["bound"] == "mfma"), key=lambda k: ks[k]["us"])
-            attn = ks["gt_attention_fused_edge"]
-            res["roofline"] = {"kernel": "linear_mfma_kernel", "shape": dom, "bound": "mfma", "achieved": ks[dom]["achieved"], "peak": MFMA_BF16_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": ks[dom]["frac"], "traffic": None,
-                               "note": f"dominant kernel class by time; one processor layer = {layer_us:.0f} us of kernels x {L} layers",
-                               "gather_scatter": {"kernel": "gt_attn_fused_edge_fwd_kernel", "bound": "hbm", "achieved": attn["achieved"], "peak": HBM_PEAK_GBS,
-                                                  "unit": "GB/s", "frac": attn["frac"], "traffic": None}}
+                fam = profile_forward(step, dtype)
+                res["kernels"] = time_kernels(model, g, args, dtype, device)
+            res["kernel_families"] = {k: {"calls": v["calls"], "total_us": round(v["us"], 1), "avg_us": round(v["us"] / v["calls"], 2),
+                                          "work": v["work"], "unit": v["unit"]} for k, v in fam.items()}
+            traffic = {}
+            tpath = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
+            if os.path.exists(tpath):  # HBM bytes per launch from rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE), see DESIGN.md
+                traffic = json.load(open(tpath))
+            dom = max(fam, key=lambda k: fam[k]["us"])
+            d = fam[dom]
+            if d["unit"] == "flop":
+                ach, peak, unit, bound = d["work"] / d["us"] / 1e6, MFMA_BF16_PEAK_TFLOPS, "TFLOP/s", "mfma"
+            else:
+                ach, peak, unit, bound = d["work"] / d["us"] / 1e3, HBM_PEAK_GBS, "GB/s", "hbm"
+            res["roofline"] = {"kernel": dom, "bound": bound, "achieved": round(ach, 1), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
+                               "traffic": traffic.get(dom), "calls_per_step": d["calls"], "avg_launch_us": round(d["us"] / d["calls"], 2),
+                               "how": "sum of algorithmic work of all launches of the family in one forward / sum of their HIP-event durations"}
+            at = fam.get("gt_attn_fused_edge_fwd_kernel")
+            if at:
+                res["roofline"]["gather_scatter"] = {"kernel": "gt_attn_fused_edge_fwd_kernel", "bound": "hbm", "achieved": round(at["work"] / at["us"] / 1e3, 1),
+                                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(at["work"] / at["us"] / 1e3 / HBM_PEAK_GBS, 4),
+                                                     "traffic": traffic.get("gt_attn_fused_edge_fwd_kernel"), "calls_per_step": at["calls"],
+                                                     "avg_launch_us": round(at["us"] / at["calls"], 2)}
         if world == 1 and args.kind == "gt" and not args.no_cpu_baseline:
             cfg = {"num_heads": args.heads, "num_layers": args.layers, "num_channels": args.channels}
             res["cpu_baseline"] = cpu_baseline(params_fp32, cfg, g, x, layers_sample=2)
