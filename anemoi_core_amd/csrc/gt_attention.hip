@@ -96,6 +96,36 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void gt_attn_fwd_kernel(
   if (lse != nullptr && (lane % LPH) == 0) lse[(int64_t)d * H + lane / LPH] = (end > beg) ? m + __logf(l) : 0.f;
 }
 
+// <a, b> over a lane's VEC channels.  16-bit types use v_dot2c_f32_{bf16,f16} on the packed pairs as loaded (exact
+// products, fp32 accumulation): no per-element conversion of the K row.
+template <typename T, int VEC>
+__device__ __forceinline__ float dot_rows(const Vec<T, VEC>& a, const Vec<T, VEC>& b) {
+  float acc = 0.f;
+  if constexpr (sizeof(T) == 2 && (VEC % 2 == 0)) {
+    const uint32_t* pa = reinterpret_cast<const uint32_t*>(&a);
+    const uint32_t* pb = reinterpret_cast<const uint32_t*>(&b);
+#pragma unroll
+    for (int i = 0; i < VEC / 2; ++i) {
+      if constexpr (std::is_same<T, bf16_t>::value) {
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+        acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, pa[i]), __builtin_bit_cast(bf2, pb[i]), acc, false);
+      } else {
+        typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+        acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, pa[i]), __builtin_bit_cast(h2, pb[i]), acc, false);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc = fmaf(to_float(a.v[i]), to_float(b.v[i]), acc);
+  }
+  return acc;
+}
+
+// Deferred running max: the rescale of the accumulators only runs (wave-uniform branch) when some head's score
+// exceeds its running max by more than this; otherwise p = exp(s - m_old) <= e^8 is accumulated directly (fp32
+// accumulators; the value after the final division is the same).
+constexpr float kDeferThr = 8.0f;
+
 // ---------------------------------------------------------------------------------------------- fused lin_edge
 // LDS image of W' = [W_e | b_e | 0]: per lane a chunk of VEC*FE_PAD floats (+4 floats of padding so that
 // 16 consecutive lanes' ds_read_b128 hit 16 distinct 16-byte bank slots).
@@ -162,11 +192,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void gt_attn_fused_edge_fwd
     const int beg = __builtin_amdgcn_readfirstlane(colptr[d]);
     const int end = __builtin_amdgcn_readfirstlane(colptr[d + 1]);
 
+    const Raw q_raw = *reinterpret_cast<const Raw*>(q + (int64_t)d * ldq + c0);
     float qv[VEC], acc[VEC];
-    load_vec<T, VEC>(q + (int64_t)d * ldq + c0, qv);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-      qv[j] *= scale;
+      qv[j] = to_float(q_raw.v[j]) * scale;
       acc[j] = 0.f;
     }
     // qw[f] = (1/LPH) * sum over the head's channels of q[c] * W'[c][f]  (pre-divided: every lane of the
@@ -205,21 +235,26 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void gt_attn_fused_edge_fwd
         for (int st = 0; st < PF; ++st) {
           const int j = j0 + st;
           if (j < n) {
-            float dot = 0.f;
+            float dot = dot_rows<T, VEC>(q_raw, kb[st]) * scale;
 #pragma unroll
             for (int f = 0; f < FE_PAD; ++f) dot = fmaf(fb[st][f], qw[f], dot);
-#pragma unroll
-            for (int jj = 0; jj < VEC; ++jj) dot = fmaf(qv[jj], to_float(kb[st].v[jj]), dot);
             dot = group_sum<LPH>(dot);
-            const float m_new = fmaxf(m, dot);
-            const float corr = __expf(m - m_new);
-            const float p = __expf(dot - m_new);
-            l = fmaf(l, corr, p);
+            if (__builtin_amdgcn_ballot_w64(dot > m + kDeferThr) != 0) {  // always on the first edge, rare afterwards
+              const float m_new = fmaxf(m, dot);
+              const float corr = __expf(m - m_new);  // exp(-inf) = 0 on the first edge
+              l *= corr;
 #pragma unroll
-            for (int jj = 0; jj < VEC; ++jj) acc[jj] = fmaf(acc[jj], corr, p * to_float(vb[st].v[jj]));
+              for (int jj = 0; jj < VEC; ++jj) acc[jj] *= corr;
 #pragma unroll
-            for (int f = 0; f < FE_PAD; ++f) sf[f] = fmaf(sf[f], corr, p * fb[st][f]);
-            m = m_new;
+              for (int f = 0; f < FE_PAD; ++f) sf[f] *= corr;
+              m = m_new;
+            }
+            const float p = __expf(dot - m);
+            l += p;
+#pragma unroll
+            for (int jj = 0; jj < VEC; ++jj) acc[jj] = fmaf(p, to_float(vb[st].v[jj]), acc[jj]);
+#pragma unroll
+            for (int f = 0; f < FE_PAD; ++f) sf[f] = fmaf(p, fb[st][f], sf[f]);
             if (j + PF < n) fetch(j + PF, kb[st], vb[st], fb[st]);
           }
         }
@@ -244,192 +279,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void gt_attn_fused_edge_fwd
     }
     store_vec<T, VEC>(out + (int64_t)d * ldo + c0, o);
     if (lse != nullptr && (lane % LPH) == 0) lse[(int64_t)d * H + lane / LPH] = (end > beg) ? m + __logf(l) : 0.f;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------- fused lin_edge, v2
-// Same maths as above with ~3x fewer vector-ALU instructions per edge (the v1 kernel measured VALU-bound: 1.1k VALU
-// instructions per destination at 4 cycles each).  Requires FE_PAD % LPH == 0.
-//  * the FE_PAD edge features are SPLIT across the LPH lanes of a head (FPL = FE_PAD / LPH each): the feature part of
-//    the score needs FPL FMAs per lane (the head butterfly that finishes <q,k> also sums the partials) and the
-//    weighted feature sum FPL FMAs; the per-lane feature slice is a vector load (no scalar-load chain);
-//  * <q_h, k_h> uses v_dot2c_f32_{bf16,f16} on the packed 16-bit pairs as loaded (no conversions for K);
-//  * deferred running max: the O(VEC + FPL) rescale of the accumulators only runs (wave-uniform branch) when some
-//    head's score exceeds its running max by more than kDeferThr; otherwise p = exp(s - m_old) <= e^kDeferThr is added
-//    directly (fp32 accumulators; exact same value after the final division).
-constexpr float kDeferThr = 8.0f;
-
-template <typename T, int VEC>
-__device__ __forceinline__ float dot_rows(const Vec<T, VEC>& a, const Vec<T, VEC>& b) {
-  float acc = 0.f;
-  if constexpr (sizeof(T) == 2 && (VEC % 2 == 0)) {
-    const uint32_t* pa = reinterpret_cast<const uint32_t*>(&a);
-    const uint32_t* pb = reinterpret_cast<const uint32_t*>(&b);
-#pragma unroll
-    for (int i = 0; i < VEC / 2; ++i) {
-      if constexpr (std::is_same<T, bf16_t>::value) {
-        typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
-        acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, pa[i]), __builtin_bit_cast(bf2, pb[i]), acc, false);
-      } else {
-        typedef __attribute__((ext_vector_type(2))) _Float16 h2;
-        acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, pa[i]), __builtin_bit_cast(h2, pb[i]), acc, false);
-      }
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) acc = fmaf(to_float(a.v[i]), to_float(b.v[i]), acc);
-  }
-  return acc;
-}
-
-template <typename T, int VEC, int LPH, int FE_PAD>
-__global__ __launch_bounds__(64 * kWavesPerBlock, 4) void gt_attn_fused_edge_v2_kernel(
-    const T* __restrict__ q, int64_t ldq, const T* __restrict__ k, int64_t ldk, const T* __restrict__ v, int64_t ldv,
-    const float* __restrict__ feat, const float* __restrict__ w_packed, const int32_t* __restrict__ row,
-    const int32_t* __restrict__ colptr, const T* __restrict__ addend, int64_t ldadd, T* __restrict__ out, int64_t ldo,
-    float* __restrict__ lse, int n_dst, int H, float scale) {
-  using L = WLayout<VEC, FE_PAD>;
-  constexpr int FPL = FE_PAD / LPH;
-  extern __shared__ __attribute__((aligned(16))) float w_lds[];  // [64][kChunk]
-  const int lane = threadIdx.x & 63;
-  const int c0 = lane * VEC;
-  const int fi = lane % LPH;  // which feature slice of the head this lane owns
-
-  {
-    constexpr int kQ = FE_PAD / 4;
-    constexpr int kTotal = 64 * VEC * kQ;
-    constexpr int kIter = (kTotal + 64 * kWavesPerBlock - 1) / (64 * kWavesPerBlock);
-    float4 tmp[kIter];
-#pragma unroll
-    for (int it = 0; it < kIter; ++it) {
-      const int idx = threadIdx.x + it * 64 * kWavesPerBlock;
-      tmp[it] = idx < kTotal ? reinterpret_cast<const float4*>(w_packed)[idx] : float4{0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int it = 0; it < kIter; ++it) {
-      const int idx = threadIdx.x + it * 64 * kWavesPerBlock;
-      if (idx < kTotal) {
-        const int c = idx / kQ, qq = idx % kQ;
-        *reinterpret_cast<float4*>(w_lds + (c / VEC) * L::kChunk + (c % VEC) * FE_PAD + qq * 4) = tmp[it];
-      }
-    }
-  }
-  __syncthreads();
-  const float* wl = w_lds + lane * L::kChunk;
-
-  const int xcd = blockIdx.x & 7;
-  const int blocks_in_xcd = (gridDim.x - xcd + 7) >> 3;
-  const int waves_in_xcd = blocks_in_xcd * kWavesPerBlock;
-  const int wave_in_xcd = __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * kWavesPerBlock + (threadIdx.x >> 6));
-  const int per_xcd = (n_dst + 7) >> 3;
-  const int d_lo = xcd * per_xcd;
-  const int d_hi = min(n_dst, d_lo + per_xcd);
-
-  using Raw = Vec<T, VEC>;
-  constexpr int PF = 3;
-
-  for (int d = d_lo + wave_in_xcd; d < d_hi; d += waves_in_xcd) {
-    asm volatile("" ::: "memory");  // keep W' in LDS (see v1)
-    const int beg = __builtin_amdgcn_readfirstlane(colptr[d]);
-    const int end = __builtin_amdgcn_readfirstlane(colptr[d + 1]);
-
-    const Raw q_raw = *reinterpret_cast<const Raw*>(q + (int64_t)d * ldq + c0);
-    float acc[VEC], sf[FPL], qw_own[FPL];
-    {
-      // qw[f] = scale * sum over the head's channels of q[c] * W'[c][f]; every lane keeps only its FPL features
-      float qv[VEC];
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        qv[j] = to_float(q_raw.v[j]) * scale;
-        acc[j] = 0.f;
-      }
-#pragma unroll
-      for (int t = 0; t < FPL; ++t) qw_own[t] = 0.f;
-#pragma unroll
-      for (int f = 0; f < FE_PAD; ++f) {
-        float t = 0.f;
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) t = fmaf(qv[j], wl[j * FE_PAD + f], t);
-        t = group_sum<LPH>(t);
-        if (fi == f / FPL) qw_own[f % FPL] = t;  // compile-time f: one v_cndmask per feature
-      }
-#pragma unroll
-      for (int t = 0; t < FPL; ++t) sf[t] = 0.f;
-    }
-    float m = -INFINITY, l = 0.f;
-
-    for (int chunk = beg; chunk < end; chunk += 64) {
-      const int n = min(64, end - chunk);
-      const int my_src = (lane < n) ? row[chunk + lane] : 0;
-      Raw kb[PF], vb[PF];
-      float fb[PF][FPL];
-      auto fetch = [&](int j, Raw& kr, Raw& vr, float (&fr)[FPL]) {
-        const int s = __builtin_amdgcn_readlane(my_src, j);
-        kr = *reinterpret_cast<const Raw*>(k + (int64_t)s * ldk + c0);
-        vr = *reinterpret_cast<const Raw*>(v + (int64_t)s * ldv + c0);
-        const float* a = feat + (int64_t)(chunk + j) * FE_PAD + fi * FPL;
-#pragma unroll
-        for (int t = 0; t < FPL; ++t) fr[t] = a[t];
-      };
-#pragma unroll
-      for (int st = 0; st < PF; ++st)
-        if (st < n) fetch(st, kb[st], vb[st], fb[st]);
-      for (int j0 = 0; j0 < n; j0 += PF) {
-#pragma unroll
-        for (int st = 0; st < PF; ++st) {
-          const int j = j0 + st;
-          if (j < n) {
-            float dot = dot_rows<T, VEC>(q_raw, kb[st]) * scale;
-#pragma unroll
-            for (int t = 0; t < FPL; ++t) dot = fmaf(fb[st][t], qw_own[t], dot);
-            dot = group_sum<LPH>(dot);
-            if (__builtin_amdgcn_ballot_w64(dot > m + kDeferThr) != 0) {  // rare after the first edge
-              const float m_new = fmaxf(m, dot);
-              const float corr = __expf(m - m_new);
-              l *= corr;
-#pragma unroll
-              for (int jj = 0; jj < VEC; ++jj) acc[jj] *= corr;
-#pragma unroll
-              for (int t = 0; t < FPL; ++t) sf[t] *= corr;
-              m = m_new;
-            }
-            const float p = __expf(dot - m);
-            l += p;
-#pragma unroll
-            for (int jj = 0; jj < VEC; ++jj) acc[jj] = fmaf(p, to_float(vb[st].v[jj]), acc[jj]);
-#pragma unroll
-            for (int t = 0; t < FPL; ++t) sf[t] = fmaf(p, fb[st][t], sf[t]);
-            if (j + PF < n) fetch(j + PF, kb[st], vb[st], fb[st]);
-          }
-        }
-      }
-    }
-
-    asm volatile("" ::: "memory");
-    // all-gather the weighted feature sums of the head (FPL per lane -> FE_PAD) and apply W'
-    float sfa[FE_PAD];
-    const int head_base = lane & ~(LPH - 1);
-#pragma unroll
-    for (int g = 0; g < LPH; ++g)
-#pragma unroll
-      for (int t = 0; t < FPL; ++t) sfa[g * FPL + t] = __shfl(sf[t], head_base + g, 64);
-    const float inv = (end > beg) ? 1.0f / l : 0.f;
-    float o[VEC];
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      float t = acc[j];
-#pragma unroll
-      for (int f = 0; f < FE_PAD; ++f) t = fmaf(sfa[f], wl[j * FE_PAD + f], t);
-      o[j] = t * inv;
-    }
-    if (addend != nullptr) {
-      float ad[VEC];
-      load_vec<T, VEC>(addend + (int64_t)d * ldadd + c0, ad);
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) o[j] += ad[j];
-    }
-    store_vec<T, VEC>(out + (int64_t)d * ldo + c0, o);
-    if (lse != nullptr && fi == 0) lse[(int64_t)d * H + lane / LPH] = (end > beg) ? m + __logf(l) : 0.f;
   }
 }
 
@@ -559,13 +408,6 @@ static int launch_fast(const AttnArgs& a) {
     blocks = blocks < max_blocks ? blocks : max_blocks;
     blocks = (blocks + 7) & ~7;  // a whole number of workgroups per XCD
     const dim3 grid(blocks);
-    constexpr bool kUseV2 = false;  // v2 (VALU-lean) measured slower than v1 while both are latency-bound; see DESIGN.md
-    if constexpr (kUseV2 && FE_PAD % LPH == 0) {
-      hipLaunchKernelGGL((gt_attn_fused_edge_v2_kernel<T, VEC, LPH, FE_PAD>), grid, block, L::kFloats * sizeof(float),
-                         a.stream, (const T*)a.q, a.ldq, (const T*)a.k, a.ldk, (const T*)a.v, a.ldv, a.feat, a.w_packed,
-                         a.row, a.colptr, (const T*)a.addend, a.ldadd, (T*)a.out, a.ldo, a.lse, a.n_dst, a.H, scale);
-      return check_launch("gt_attn_fused_edge_v2_kernel");
-    }
     hipLaunchKernelGGL((gt_attn_fused_edge_fwd_kernel<T, VEC, LPH, FE_PAD>), grid, block, L::kFloats * sizeof(float),
                        a.stream, (const T*)a.q, a.ldq, (const T*)a.k, a.ldk, (const T*)a.v, a.ldv, a.feat, a.w_packed,
                        a.row, a.colptr, (const T*)a.addend, a.ldadd, (T*)a.out, a.ldo, a.lse, a.n_dst, a.H, scale);

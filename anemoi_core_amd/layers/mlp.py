@@ -42,6 +42,9 @@ class MLP(nn.Module):
         mods = list(self.mlp)
         lin_idx = [i for i, m in enumerate(mods) if isinstance(m, nn.Linear)]
         h = x.reshape(-1, x.shape[-1])
+        wdt = mods[lin_idx[0]].weight.dtype
+        if h.dtype != wdt:  # e.g. fp32 geometric edge attributes entering a bf16 model (what autocast does in the reference)
+            h = h.to(wdt)
         ln = None if skip_layer_norm else self.layer_norm
         for n, i in enumerate(lin_idx):
             if n == 0 and skip_first:
