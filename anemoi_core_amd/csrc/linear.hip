@@ -326,36 +326,58 @@ typedef __attribute__((address_space(1))) const void gbl_void_t;
 enum : int { EPI_RES = 1, EPI_GATHER = 2, EPI_GELU = 4 };
 
 // acc[mi][ni][r] = out[m0 + wr*64 + mi*16 + (lane & 15)][n0 + wc*64 + ni*16 + (lane>>4)*4 + r]
-// epi: this wave's 4 KiB LDS slice (16 rows x 256 B); one 16-row band (mi) at a time.
+// epi: this wave's 4 KiB LDS slice (16 rows x 256 B); one 16-row band (mi) at a time.  The band is written in the MFMA
+// layout (16-byte slots, 32-byte pairs XOR-swizzled by the row: conflict-free ds_write_b128) and read back as 8
+// CONSECUTIVE columns per lane, 8 lanes per row: every global access of the epilogue (bias, residual, gather rows,
+// output) is a 16-byte-per-lane access covering whole 128-byte lines - the 8-byte form measured store-issue-bound
+// (guide T21).  Interior tiles issue exactly kEpiStores = 8 stores per wave.
+constexpr int kEpiStores = 8;
+
 template <typename T, int EPI>
 __device__ __forceinline__ void mfma_epilogue_band(const LinArgs& a, f32x4 (&acc)[4][4], int m0, int n0, int wr, int wc,
                                                    int lane, unsigned char* epi, bool interior) {
   const T* __restrict__ bias = (const T*)a.bias;
   T* __restrict__ y = (T*)a.y;
+  using V8 = Vec<T, 8>;
+  const int cp = lane & 7;                           // which 8-column group (32-byte fp32 pair) of the 64 columns
+  const int nc = n0 + wc * 64 + cp * 8;
+  // O % 4 == 0 only: the second half of an 8-column group may fall outside; handled by narrowing to 4 columns
+  const int ncols = interior ? 8 : max(0, min(8, a.O - nc));
+  const int mrow0 = m0 + wr * 64 + (lane >> 3);      // + mi*16 + it*8
+  float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   using V4 = Vec<T, 4>;
-  const int nc = n0 + wc * 64 + (lane & 15) * 4;
-  const bool n_ok = interior || nc < a.O;  // O % 4 == 0: a 4-column group is entirely inside or outside
-  const int mrow0 = m0 + wr * 64 + (lane >> 4);  // + mi*16 + it*4
-  float bv[4] = {0.f, 0.f, 0.f, 0.f};
-  if (bias != nullptr && n_ok) load_vec<T, 4>(bias + nc, bv);
+  auto load8 = [&](const T* p, V8& dst) {
+    if (ncols == 8) {
+      dst = *reinterpret_cast<const V8*>(p);
+    } else if (ncols >= 4) {  // O % 8 == 4: only the first 4 columns of the last group exist
+      const V4 h = *reinterpret_cast<const V4*>(p);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst.v[r] = h.v[r];
+    }
+  };
+  if (bias != nullptr) {
+    V8 braw{};
+    load8(bias + nc, braw);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) bv[r] = to_float(braw.v[r]);
+  }
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
-    // operands of this band that do not depend on the accumulators: issue their loads first
-    V4 rv[4], t1[4], t2[4];
+    V8 rv[2], t1[2], t2[2];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int m = mrow0 + mi * 16 + it * 4;
-      const bool ok = interior || (n_ok && m < a.n_rows);
-      rv[it] = V4{};
-      t1[it] = V4{};
-      t2[it] = V4{};
+    for (int it = 0; it < 2; ++it) {
+      const int m = mrow0 + mi * 16 + it * 8;
+      const bool ok = interior || m < a.n_rows;
+      rv[it] = V8{};
+      t1[it] = V8{};
+      t2[it] = V8{};
       if constexpr ((EPI & EPI_RES) != 0) {
-        if (ok) rv[it] = *reinterpret_cast<const V4*>((const T*)a.residual + (int64_t)m * a.ldr + nc);
+        if (ok) load8((const T*)a.residual + (int64_t)m * a.ldr + nc, rv[it]);
       }
       if constexpr ((EPI & EPI_GATHER) != 0) {
         if (ok) {
-          t1[it] = *reinterpret_cast<const V4*>((const T*)a.g1 + (int64_t)a.idx1[m] * a.ldg1 + nc);
-          if (a.g2 != nullptr) t2[it] = *reinterpret_cast<const V4*>((const T*)a.g2 + (int64_t)a.idx2[m] * a.ldg2 + nc);
+          load8((const T*)a.g1 + (int64_t)a.idx1[m] * a.ldg1 + nc, t1[it]);
+          if (a.g2 != nullptr) load8((const T*)a.g2 + (int64_t)a.idx2[m] * a.ldg2 + nc, t2[it]);
         }
       }
     }
@@ -363,36 +385,54 @@ __device__ __forceinline__ void mfma_epilogue_band(const LinArgs& a, f32x4 (&acc
       const int row = lane & 15;
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) {
-        const int slot = (ni * 4 + (lane >> 4)) ^ row;
-        *reinterpret_cast<f32x4*>(epi + row * 256 + slot * 16) = acc[mi][ni];
+        const int slot = ni * 4 + (lane >> 4);                       // logical 16-byte slot (4 columns)
+        const int phys = ((((slot >> 1) ^ (row & 7)) << 1) | (slot & 1));
+        *reinterpret_cast<f32x4*>(epi + row * 256 + phys * 16) = acc[mi][ni];
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    f32x4 c[4];
+    f32x4 c[2][2];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int row = it * 4 + (lane >> 4);
-      c[it] = *reinterpret_cast<const f32x4*>(epi + row * 256 + (((lane & 15) ^ row) << 4));
+    for (int it = 0; it < 2; ++it) {
+      const int row = it * 8 + (lane >> 3);
+      const unsigned char* src = epi + row * 256 + ((cp ^ (row & 7)) << 5);
+      c[it][0] = *reinterpret_cast<const f32x4*>(src);
+      c[it][1] = *reinterpret_cast<const f32x4*>(src + 16);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // band consumed: the next band may overwrite the slice
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int m = mrow0 + mi * 16 + it * 4;
-      const bool ok = interior || (n_ok && m < a.n_rows);
-      float vv[4] = {c[it][0] + bv[0], c[it][1] + bv[1], c[it][2] + bv[2], c[it][3] + bv[3]};
+    for (int it = 0; it < 2; ++it) {
+      const int m = mrow0 + mi * 16 + it * 8;
+      const bool ok = (interior || m < a.n_rows) && ncols > 0;
+      float vv[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) vv[r] = c[it][r >> 2][r & 3] + bv[r];
       if constexpr ((EPI & EPI_GATHER) != 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) vv[r] += to_float(t1[it].v[r]) + to_float(t2[it].v[r]);
+        for (int r = 0; r < 8; ++r) vv[r] += to_float(t1[it].v[r]) + to_float(t2[it].v[r]);
       }
       if constexpr ((EPI & EPI_GELU) != 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) vv[r] = gelu_erf(vv[r]);
+        for (int r = 0; r < 8; ++r) vv[r] = gelu_erf(vv[r]);
       }
       if constexpr ((EPI & EPI_RES) != 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) vv[r] += to_float(rv[it].v[r]);
+        for (int r = 0; r < 8; ++r) vv[r] += to_float(rv[it].v[r]);
       }
-      if (ok) store_vec<T, 4>(y + (int64_t)m * a.ldy + nc, vv);
+      if (ok) {
+        T* dst = y + (int64_t)m * a.ldy + nc;
+        V8 o8;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) o8.v[r] = from_float<T>(vv[r]);
+        if (ncols == 8) {
+          *reinterpret_cast<V8*>(dst) = o8;
+        } else {
+          V4 o4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o4.v[r] = o8.v[r];
+          *reinterpret_cast<V4*>(dst) = o4;
+        }
+      }
     }
   }
 }
@@ -486,7 +526,6 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void linear_mfma_persistent_kernel
   }
 
   int g = 0;
-  constexpr int kEpiStores = 16;  // stores per wave of an interior tile's epilogue
   bool counted_stores = false, drain_all = false;
   for (int j = 0; j < my_tiles; ++j) {
     int m0, n0;
@@ -580,8 +619,12 @@ template <typename T>
 static bool ring_eligible(const LinArgs& a) {
   // K-tiles are whole, and the per-lane 32-bit byte offsets of the DMA addressing cover the operands
   const int64_t lim = (int64_t)1 << 31;
-  return a.K1 % BK == 0 && a.K2 % BK == 0 && (int64_t)a.n_rows * a.ldx * 2 < lim && (int64_t)a.O * a.ldw * 2 < lim &&
-         (a.x2 == nullptr || (int64_t)a.n_rows * a.ldx2 * 2 < lim);
+  const bool k_ok = a.K1 % BK == 0 && a.K2 % BK == 0 && (int64_t)a.n_rows * a.ldx * 2 < lim && (int64_t)a.O * a.ldw * 2 < lim &&
+                    (a.x2 == nullptr || (int64_t)a.n_rows * a.ldx2 * 2 < lim);
+  // 16-byte epilogue accesses
+  const bool e_ok = a.ldy % 8 == 0 && (!a.residual || a.ldr % 8 == 0) && (!a.g1 || a.ldg1 % 8 == 0) && (!a.g2 || a.ldg2 % 8 == 0) &&
+                    al(a.y, 16) && al(a.residual, 16) && al(a.bias, 16) && al(a.g1, 16) && al(a.g2, 16);
+  return k_ok && e_ok;
 }
 
 template <typename T, int EPI>

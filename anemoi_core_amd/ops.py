@@ -29,7 +29,15 @@ def _dt(t: Tensor) -> int:
         raise ValueError(f"unsupported dtype {t.dtype}; supported: float32, bfloat16, float16") from None
 
 
+try:  # raw handle of torch's current stream without constructing a Stream object (host launch overhead matters at N > 1)
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+except AttributeError:  # pragma: no cover
+    _raw_stream = None
+
+
 def _stream() -> int:
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -53,13 +61,14 @@ def _rows(t: Optional[Tensor], name: str, dtype=None) -> tuple[int, int]:
     """(data_ptr, leading dimension) of a 2-D row-major view whose last dim is contiguous."""
     if t is None:
         return 0, 0
-    if t.dim() != 2:
-        raise ValueError(f"{name}: expected a 2-D tensor, got shape {tuple(t.shape)}")
-    if t.shape[1] > 1 and t.stride(1) != 1:
-        raise ValueError(f"{name}: last dimension must be contiguous (strides {t.stride()})")
+    shape, stride = t.shape, t.stride()
+    if len(shape) != 2:
+        raise ValueError(f"{name}: expected a 2-D tensor, got shape {tuple(shape)}")
+    if shape[1] > 1 and stride[1] != 1:
+        raise ValueError(f"{name}: last dimension must be contiguous (strides {stride})")
     if dtype is not None and t.dtype != dtype:
         raise ValueError(f"{name}: dtype {t.dtype} does not match {dtype}")
-    ld = t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
+    ld = stride[0] if shape[0] > 1 else max(shape[1], stride[0])
     return t.data_ptr(), ld
 
 
