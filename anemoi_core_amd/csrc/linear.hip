@@ -562,25 +562,15 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void linear_mfma_persistent_kernel
           fa[ks][i] = *reinterpret_cast<const frag8*>(st + a_rd[ks] + i * 16 * BK * 2);
           fw[ks][i] = *reinterpret_cast<const frag8*>(st + w_rd[ks] + i * 16 * BK * 2);
         }
-#ifndef ANEMOI_GEMM_NO_MFMA
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16<T>(fw[0][ni], fa[0][mi], acc[mi][ni]);  // D^T tile: rows n, cols m
-#endif
-#ifndef ANEMOI_GEMM_NO_DMA
       issue_next();
-#else
-      ++ig;
-#endif
-#ifndef ANEMOI_GEMM_NO_MFMA
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16<T>(fw[1][ni], fa[1][mi], acc[mi][ni]);
-#else
-      asm volatile("" ::"v"(fa[0][0]), "v"(fw[0][0]), "v"(fa[1][3]), "v"(fw[1][3]));
-#endif
     }
     // epilogue in the stage that was just read (stage (g-1) % STAGES): every wave must be done reading it
     __builtin_amdgcn_s_barrier();
