@@ -441,12 +441,16 @@ template <typename T, int WM, int WN, int STAGES, int EPI>
 __global__ __launch_bounds__(64 * WM * WN, 1) void linear_mfma_persistent_kernel(LinArgs a, int tiles_n, int num_tiles) {
   constexpr int NW = WM * WN;
   constexpr int TBM = 64 * WM, TBN = 64 * WN;
-  constexpr int kAPW = TBM / 8 / NW, kWPW = TBN / 8 / NW;  // 1-KiB pieces (8 rows x 64 elements) per wave per K-tile
-  static_assert((TBM / 8) % NW == 0 && (TBN / 8) % NW == 0, "operand pieces must divide evenly over the waves");
+  // 1-KiB pieces (8 rows x 64 elements) per wave per K-tile.  When the piece count does not divide evenly over the
+  // waves (3 x 2 waves: 16 W pieces over 6 waves) every wave still issues the same number of DMAs - the surplus ones
+  // land in a 1-KiB dummy area after the ring - so that the counted vmcnt waits are identical for all waves.
+  constexpr int kAPieces = TBM / 8, kWPieces = TBN / 8;
+  constexpr int kAPW = (kAPieces + NW - 1) / NW, kWPW = (kWPieces + NW - 1) / NW;
   constexpr int kPPW = kAPW + kWPW;
   constexpr int kStageBytes = (TBM + TBN) * BK * 2;
   static_assert(NW * 4096 <= kStageBytes, "epilogue band staging must fit in one stage");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [STAGES][A tile | W tile]
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [STAGES][A tile | W tile] [1 KiB dummy]
+  unsigned char* const dummy = smem + STAGES * kStageBytes;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / WN, wc = wave % WN;
@@ -476,7 +480,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void linear_mfma_persistent_kernel
     tile_origin(j, m0, n0);
 #pragma unroll
     for (int i = 0; i < kAPW; ++i) {
-      const int row = (wave * kAPW + i) * 8 + (lane >> 3);
+      const int row = min(wave * kAPW + i, kAPieces - 1) * 8 + (lane >> 3);
       const int slot = (lane & 7) ^ ((row >> 1) & 7);
       const int m = min(m0 + row, a.n_rows - 1);  // rows past the end are computed but never stored
       a_voff[i] = (uint32_t)(((int64_t)m * a.ldx + slot * 8) * 2);
@@ -484,7 +488,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void linear_mfma_persistent_kernel
     }
 #pragma unroll
     for (int i = 0; i < kWPW; ++i) {
-      const int row = (wave * kWPW + i) * 8 + (lane >> 3);
+      const int row = min(wave * kWPW + i, kWPieces - 1) * 8 + (lane >> 3);
       const int slot = (lane & 7) ^ ((row >> 1) & 7);
       const int n = min(n0 + row, a.O - 1);
       w_voff[i] = (uint32_t)(((int64_t)n * a.ldw + slot * 8) * 2);
@@ -500,13 +504,17 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void linear_mfma_persistent_kernel
     const char* abase = first ? xb + (int64_t)k0 * 2 : x2b + (int64_t)(k0 - a.K1) * 2;
     const char* wbase = wb + (int64_t)k0 * 2;
 #pragma unroll
-    for (int i = 0; i < kAPW; ++i)
+    for (int i = 0; i < kAPW; ++i) {
+      const int pc = wave * kAPW + i;
       __builtin_amdgcn_global_load_lds((gbl_void_t*)(abase + (first ? a_voff[i] : a2_voff[i])),
-                                       (lds_void_t*)(stage + (wave * kAPW + i) * 1024), 16, 0, 0);
+                                       (lds_void_t*)(pc < kAPieces ? stage + pc * 1024 : dummy), 16, 0, 0);
+    }
 #pragma unroll
-    for (int i = 0; i < kWPW; ++i)
+    for (int i = 0; i < kWPW; ++i) {
+      const int pc = wave * kWPW + i;
       __builtin_amdgcn_global_load_lds((gbl_void_t*)(wbase + w_voff[i]),
-                                       (lds_void_t*)(stage + TBM * BK * 2 + (wave * kWPW + i) * 1024), 16, 0, 0);
+                                       (lds_void_t*)(pc < kWPieces ? stage + TBM * BK * 2 + pc * 1024 : dummy), 16, 0, 0);
+    }
     ++ig;
     if (++ikt == nk) {
       ikt = 0;
@@ -617,10 +625,10 @@ static bool ring_eligible(const LinArgs& a) {
   return k_ok && e_ok;
 }
 
-template <typename T, int EPI>
-static int launch_persistent(const LinArgs& a, hipStream_t st) {
-  constexpr int WM = 4, WN = 2, ST = 3;  // 256 x 128 tile, 8 waves, 3-stage ring: 144 KiB LDS, one workgroup per CU
-  constexpr int smem_bytes = ST * (64 * WM + 64 * WN) * BK * 2;
+template <typename T, int EPI, int WM>
+static int launch_persistent_wm(const LinArgs& a, hipStream_t st) {
+  constexpr int WN = 2, ST = 3;  // (64*WM) x 128 tile, 2*WM waves, 3-stage ring (144 KiB at WM = 4), one workgroup per CU
+  constexpr int smem_bytes = ST * (64 * WM + 64 * WN) * BK * 2 + 1024;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_mfma_persistent_kernel<T, WM, WN, ST, EPI>),
@@ -632,6 +640,18 @@ static int launch_persistent(const LinArgs& a, hipStream_t st) {
   const int grid = nt < 256 ? nt : 256;
   hipLaunchKernelGGL((linear_mfma_persistent_kernel<T, WM, WN, ST, EPI>), dim3(grid), dim3(64 * WM * WN), smem_bytes, st, a, tn, nt);
   return check_launch("linear_mfma_persistent_kernel");
+}
+
+template <typename T, int EPI>
+static int launch_persistent(const LinArgs& a, hipStream_t st) {
+  // Tile height: 256 rows (8 waves) by default; 192 rows (6 waves) when that removes a partly empty round of tiles
+  // (makespan = rounds x tile height, e.g. [10242 x 512] outputs: 164 tiles of 256 rows on 164 CUs -> 216 tiles of 192).
+  auto cost = [&](int wm) {
+    const int64_t tiles = (int64_t)((a.n_rows + 64 * wm - 1) / (64 * wm)) * ((a.O + 127) / 128);
+    return ((tiles + 255) / 256) * wm;
+  };
+  if (cost(3) < cost(4)) return launch_persistent_wm<T, EPI, 3>(a, st);
+  return launch_persistent_wm<T, EPI, 4>(a, st);
 }
 
 template <typename T>

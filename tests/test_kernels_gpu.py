@@ -223,7 +223,8 @@ def _lin_ref(x, w, b=None, act=None, res=None, x2=None, g1=None, i1=None, g2=Non
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("N,K,O", [(300, 512, 512), (1000, 512, 2048), (257, 2048, 512), (129, 64, 128), (70, 20, 64), (50, 11, 7), (333, 512, 100), (5, 64, 64),
                                    (1300, 512, 2048), (2100, 2048, 512), (1111, 512, 512), (1030, 64, 100), (1500, 72, 512),
-                                   (4200, 512, 2048), (3000, 192, 3072)])  # the last two: > 256 tiles -> persistent kernel
+                                   (4200, 512, 2048), (3000, 192, 3072),  # > 256 tiles: several tiles per persistent workgroup
+                                   (10242, 512, 512)])  # 192-row tile variant (216 tiles instead of 164 of 256 rows)
 def test_linear_epilogues(ops, dtype, N, K, O):
     gen = torch.Generator().manual_seed(N + K + O)
     x = torch.randn(N, K, generator=gen).to(dtype)
