@@ -75,9 +75,9 @@ def segment_softmax(alpha: Tensor, index: Tensor, num_segments: int) -> Tensor:
     """torch_geometric.utils.softmax as called at layers/conv.py:144 (dim 0)."""
     shape = (num_segments,) + tuple(alpha.shape[1:])
     idx = index.view(-1, *([1] * (alpha.dim() - 1))).expand_as(alpha)
-    seg_max = torch.zeros(shape, dtype=alpha.dtype).scatter_reduce_(0, idx, alpha, reduce="amax", include_self=False)
+    seg_max = alpha.new_zeros(shape).scatter_reduce_(0, idx, alpha, reduce="amax", include_self=False)
     ex = (alpha - seg_max.index_select(0, index)).exp()
-    seg_sum = torch.zeros(shape, dtype=alpha.dtype).index_add_(0, index, ex) + 1e-16
+    seg_sum = alpha.new_zeros(shape).index_add_(0, index, ex) + 1e-16
     return ex / seg_sum.index_select(0, index)
 
 
@@ -95,7 +95,7 @@ def gt_conv(query: Tensor, key: Tensor, value: Tensor, edges: Tensor, edge_index
     alpha = (q_i * k_j).sum(dim=-1) / C**0.5  # [M,H]
     alpha = segment_softmax(alpha, dst, n_dst)
     msg = v_j * alpha.unsqueeze(-1)
-    out = torch.zeros((n_dst,) + tuple(query.shape[1:]), dtype=query.dtype)
+    out = query.new_zeros((n_dst,) + tuple(query.shape[1:]))
     return out.index_add_(0, dst, msg)
 
 
@@ -118,7 +118,7 @@ def graph_conv(p: Params, prefix: str, x_src: Tensor, x_dst: Tensor, edge_attr: 
     src, dst = edge_index[0].long(), edge_index[1].long()
     x_i, x_j = x_dst.index_select(0, dst), x_src.index_select(0, src)
     edges_new = mlp(p, prefix + ".edge_mlp", torch.cat([x_i, x_j, edge_attr], dim=1)) + edge_attr
-    out = torch.zeros((x_dst.shape[0], edges_new.shape[1]), dtype=edges_new.dtype).index_add_(0, dst, edges_new)
+    out = edges_new.new_zeros((x_dst.shape[0], edges_new.shape[1])).index_add_(0, dst, edges_new)
     return out, edges_new
 
 

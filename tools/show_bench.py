@@ -7,3 +7,4 @@ for k, v in d.get("kernel_families", {}).items():
     print("  family %-34s calls %4d  total %9.1f us  avg %8.2f us" % (k, v["calls"], v["total_us"], v["avg_us"]))
 print("roofline:", {k: v for k, v in d.get("roofline", {}).items() if k != "note"})
 print("cpu:", d.get("cpu_baseline"))
+print("gpu eager:", d.get("gpu_eager_baseline"), "speedup", d.get("speedup_vs_gpu_eager"))
