@@ -16,7 +16,20 @@ import torch
 import torch.distributed as dist
 from torch import Tensor
 
+from ..utils import segments
+from ..utils.segments import collective
 from .shapes import comm_rank, comm_size
+
+
+# The two communication calls of the hot path.  Each is issued through ``collective`` so that a SegmentedGraph
+# (utils/segments.py) can re-issue it between hipGraph segments; tests swap these two for a host-staged transport to
+# run two ranks on ONE GPU (RCCL refuses two ranks per device).
+def _all_to_all_single(recv: Tensor, send: Tensor, recv_counts, send_counts, group) -> None:
+    collective(lambda: dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=send_counts, group=group))
+
+
+def _all_gather_into_tensor(out: Tensor, inp: Tensor, group) -> None:
+    collective(lambda: dist.all_gather_into_tensor(out, inp, group=group))
 
 
 def shard_tensor(x: Tensor, dim: int, shard_sizes: Sequence[int], group) -> Tensor:
@@ -37,13 +50,13 @@ def gather_tensor(x: Tensor, dim: int, shard_sizes: Sequence[int], group) -> Ten
         x = x.transpose(0, dim).contiguous()
     if len(set(shard_sizes)) == 1:
         out = x.new_empty((sum(shard_sizes),) + tuple(x.shape[1:]))
-        dist.all_gather_into_tensor(out, x, group=group)
+        _all_gather_into_tensor(out, x, group)
     else:
         pad = max(shard_sizes)
         buf = x.new_zeros((pad,) + tuple(x.shape[1:]))
         buf[: x.shape[0]] = x
         outs = x.new_empty((world * pad,) + tuple(x.shape[1:]))
-        dist.all_gather_into_tensor(outs, buf, group=group)
+        _all_gather_into_tensor(outs, buf, group)
         out = torch.cat([outs[r * pad: r * pad + n] for r, n in enumerate(shard_sizes)], dim=0)
     if dim != 0:
         out = out.transpose(0, dim).contiguous()
@@ -53,10 +66,7 @@ def gather_tensor(x: Tensor, dim: int, shard_sizes: Sequence[int], group) -> Ten
 def all_to_all_rows(send: Tensor, send_counts: Sequence[int], recv_counts: Sequence[int], group) -> Tensor:
     """Variable-count all-to-all over dim 0 of a packed [sum(send_counts), ...] buffer."""
     recv = send.new_empty((sum(recv_counts),) + tuple(send.shape[1:]))
-    if dist.get_backend(group) == "gloo" and send.dim() > 1:
-        # gloo's all_to_all_single wants flattened element counts expressed in rows: supported for contiguous rows
-        pass
-    dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts), group=group)
+    _all_to_all_single(recv, send.contiguous(), list(recv_counts), list(send_counts), group)
     return recv
 
 
@@ -83,6 +93,8 @@ def exchange_rows(x_local: Tensor, want_global_ids: Tensor, shard_sizes: Sequenc
         rows = gather_fn(x_local, want_global_ids.to(torch.int32)) if gather_fn is not None else x_local.index_select(0, want_global_ids.long())
         return rows, plan
     if plan is None:
+        if segments._ACTIVE is not None:
+            raise RuntimeError("exchange_rows: the needed-rows plan must exist before a SegmentedGraph capture (run a warm-up forward first)")
         bounds = torch.cumsum(torch.tensor(shard_sizes, dtype=torch.long, device=want_global_ids.device), 0)
         owner = torch.searchsorted(bounds, want_global_ids.long(), right=True)
         recv_counts = torch.bincount(owner, minlength=world)

@@ -287,13 +287,24 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (ROCm) device; there is no CPU fallback for the product path")
+    # Developer hook (never set by the driver): ANEMOI_BENCH_TRANSPORT=host runs the N > 1 code path with all ranks on ONE
+    # GPU over gloo + the test-only host transport, to exercise sharding and segmented capture on a 1-GPU box.
+    host_transport = os.environ.get("ANEMOI_BENCH_TRANSPORT") == "host"
+    if host_transport:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     group = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=device)
+        if host_transport:
+            dist.init_process_group("gloo")
+            from tests import gpu_host_transport
+
+            gpu_host_transport.install()
+        else:
+            dist.init_process_group("nccl", device_id=device)
         group = dist.group.WORLD
     dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
 
@@ -323,9 +334,9 @@ def main():
         for _ in range(max(2, args.warmup // 2)):  # builds the static caches, sizes the allocator
             out = step()
         sync_all()
-        # hipGraph capture is single-GPU only: capturing RCCL collectives on this stack either aborts the process (the
-        # ProcessGroupNCCL watchdog queries an event while the stream is capturing -> hipErrorStreamCaptureUnsupported)
-        # or hangs (capture_error_mode="thread_local"); measured with tools/nccl_capture_probe.py.  N > 1 runs eagerly.
+        # N = 1: the whole forward is ONE hipGraph.  N > 1: RCCL collectives cannot be captured on this stack (the capture
+        # aborts through the ProcessGroupNCCL watchdog or hangs; tools/nccl_capture_probe.py), so the forward becomes a
+        # chain of hipGraphs with the collectives re-issued eagerly in between (anemoi_core_amd/utils/segments.py).
         if not args.no_graph and world == 1:
             try:  # capture the whole forward (kernels are enqueued on torch's current stream through the C ABI)
                 s = torch.cuda.Stream()
@@ -341,6 +352,27 @@ def main():
                     print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
                 graph = None
                 torch.cuda.synchronize()
+        elif not args.no_graph:
+            from anemoi_core_amd.utils.segments import SegmentedGraph
+
+            ok, why = 1, ""
+            try:
+                expect = step().clone()
+                graph = SegmentedGraph()
+                out = graph.capture(step)
+                graph.replay()
+                torch.cuda.synchronize()
+                if not torch.equal(out, expect):  # kernels are deterministic: a replay must reproduce the eager run bit for bit
+                    ok, why = 0, "segmented replay differs from the eager forward"
+            except Exception as e:  # noqa: BLE001
+                ok, why = 0, f"{type(e).__name__}: {e}"
+            flag = torch.tensor([ok], device="cpu" if host_transport else device, dtype=torch.int32)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)  # every rank takes the same path
+            if int(flag.item()) == 0:
+                if why:
+                    print(f"[bench] rank {rank}: segmented hipGraph capture unusable ({why}); all ranks run eagerly", file=sys.stderr)
+                graph = None
+                torch.cuda.synchronize()
         run = graph.replay if graph is not None else step
         for _ in range(args.warmup):
             run()
@@ -351,7 +383,7 @@ def main():
         sync_all()
         elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device="cpu" if host_transport else device, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms = elapsed / args.steps * 1e3
@@ -368,7 +400,8 @@ def main():
                                    f"{'GraphTransformer' if args.kind == 'gt' else 'GNN'} processor {args.layers} layers x {args.channels} ch x {args.heads} heads, "
                                    f"enc {g.enc_edge_index.shape[1]} / dec {g.dec_edge_index.shape[1]} edges, batch 1",
                        "parallelism": f"hidden mesh sharded over {world} GPU(s), halo all-to-all per layer" if world > 1 else "single GPU",
-                       "hip_graph": graph is not None},
+                       "hip_graph": graph is not None,
+                       "graph_segments": getattr(graph, "num_graphs", 1) if graph is not None else 0},
         }
         if world == 1 and args.kind == "gt" and not args.no_kernel_timing:
             with torch.inference_mode():
