@@ -109,6 +109,22 @@ __device__ __forceinline__ float fast_erf(float x) {
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f)); }
 
+// GELU for the 16-bit GEMM epilogue (21 M evaluations per MLP launch, all on the VALU while the matrix cores idle):
+//   gelu(x) = max(x, 0) - |x| * Phi(-|x|),   Phi(-a) = 2^Q(a),  Q = degree-6 fit of log2(0.5 erfc(a / sqrt 2)) on [0, 6]
+// (beyond a = 6 the term is < 6e-9 and a is clamped).  One v_exp_f32 and 9 full-rate ops instead of v_rcp + v_exp + 14:
+// max |error| 6.4e-6 over all x, RELATIVE error of the negative branch 1e-4 (the exponent form keeps tiny outputs
+// accurate), i.e. 0.4 % of bf16 results differ from the erf form by one ulp - fewer than with the A&S erf above.
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float a = fminf(fabsf(x), 6.0f);
+  float q = fmaf(2.301719668e-05f, a, -6.095573365e-04f);
+  q = fmaf(q, a, 7.168568210e-03f);
+  q = fmaf(q, a, -5.103366076e-02f);
+  q = fmaf(q, a, -4.616288390e-01f);
+  q = fmaf(q, a, -1.149844046e+00f);
+  q = fmaf(q, a, -1.000145551e+00f);
+  return fmaf(-fabsf(x), __builtin_amdgcn_exp2f(q), fmaxf(x, 0.0f));
+}
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 }  // namespace anemoi

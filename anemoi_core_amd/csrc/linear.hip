@@ -15,6 +15,8 @@
 //    the fp32 parity path): 64x64 tile, fp32 FMA on the vector ALU.
 //
 // A = [x | x2] is a K-concatenation (GraphConv's cat[x, agg] / cat[x_i, x_j, e] never materialised).
+#include <type_traits>
+
 #include "common.h"
 
 namespace anemoi {
@@ -333,8 +335,8 @@ enum : int { EPI_RES = 1, EPI_GATHER = 2, EPI_GELU = 4 };
 // (guide T21).  Interior tiles issue exactly kEpiStores = 8 stores per wave.
 constexpr int kEpiStores = 8;
 
-template <typename T, int EPI>
-__device__ __forceinline__ void mfma_epilogue_band(const LinArgs& a, f32x4 (&acc)[4][4], int m0, int n0, int wr, int wc,
+template <typename T, int EPI, int MI = 4>
+__device__ __forceinline__ void mfma_epilogue_band(const LinArgs& a, f32x4 (&acc)[MI][4], int m0, int n0, int wr, int wc,
                                                    int lane, unsigned char* epi, bool interior) {
   const T* __restrict__ bias = (const T*)a.bias;
   T* __restrict__ y = (T*)a.y;
@@ -343,7 +345,7 @@ __device__ __forceinline__ void mfma_epilogue_band(const LinArgs& a, f32x4 (&acc
   const int nc = n0 + wc * 64 + cp * 8;
   // O % 4 == 0 only: the second half of an 8-column group may fall outside; handled by narrowing to 4 columns
   const int ncols = interior ? 8 : max(0, min(8, a.O - nc));
-  const int mrow0 = m0 + wr * 64 + (lane >> 3);      // + mi*16 + it*8
+  const int mrow0 = m0 + wr * (16 * MI) + (lane >> 3);  // + mi*16 + it*8
   float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   using V4 = Vec<T, 4>;
   auto load8 = [&](const T* p, V8& dst) {
@@ -362,7 +364,7 @@ __device__ __forceinline__ void mfma_epilogue_band(const LinArgs& a, f32x4 (&acc
     for (int r = 0; r < 8; ++r) bv[r] = to_float(braw.v[r]);
   }
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
+  for (int mi = 0; mi < MI; ++mi) {
     V8 rv[2], t1[2], t2[2];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -413,7 +415,7 @@ __device__ __forceinline__ void mfma_epilogue_band(const LinArgs& a, f32x4 (&acc
       }
       if constexpr ((EPI & EPI_GELU) != 0) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) vv[r] = gelu_erf(vv[r]);
+        for (int r = 0; r < 8; ++r) vv[r] = gelu_fast(vv[r]);
       }
       if constexpr ((EPI & EPI_RES) != 0) {
 #pragma unroll
@@ -437,7 +439,7 @@ __device__ __forceinline__ void mfma_epilogue_band(const LinArgs& a, f32x4 (&acc
   }
 }
 
-template <typename T, int WM, int WN, int STAGES, int EPI>
+template <typename T, int WM, int WN, int STAGES, int EPI, bool PP>
 __global__ __launch_bounds__(64 * WM * WN, 1) void linear_mfma_persistent_kernel(LinArgs a, int tiles_n, int num_tiles) {
   constexpr int NW = WM * WN;
   constexpr int TBM = 64 * WM, TBN = 64 * WN;
@@ -535,62 +537,310 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void linear_mfma_persistent_kernel
 
   int g = 0;
   bool counted_stores = false, drain_all = false;
+  frag8 fa[2][4], fw[2][4];
+  f32x4 acc[4][4];
+  auto read_frags = [&](const unsigned char* st) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fa[ks][i] = *reinterpret_cast<const frag8*>(st + a_rd[ks] + i * 16 * BK * 2);
+        fw[ks][i] = *reinterpret_cast<const frag8*>(st + w_rd[ks] + i * 16 * BK * 2);
+      }
+  };
+  auto mfma_half = [&](int ks) {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16<T>(fw[ks][ni], fa[ks][mi], acc[mi][ni]);  // D^T tile: rows n, cols m
+  };
+  // MODE 0: all waves in lock-step (read, multiply).  MODE 1 / 2: the two halves of a ping-pong pair - the two waves of
+  // a SIMD run half a K-step apart: while the MODE-1 wave reads the fragments of K-tile g from LDS, the MODE-2 wave
+  // multiplies K-tile g-1, then they swap, so the matrix pipe of every SIMD always has a wave feeding it instead of
+  // idling while all 8 waves read fragments.  Each mode is a separate instantiation (clean loops, no per-step branch).
+  auto run_tiles = [&](auto mode_tag) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    for (int j = 0; j < my_tiles; ++j) {
+      int m0, n0;
+      tile_origin(j, m0, n0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+      for (int kt = 0; kt < nk; ++kt, ++g) {
+        // K-tile g must have landed; the STAGES-2 newer K-tiles (and, right after an interior epilogue, its stores)
+        // may stay in flight
+        if (drain_all || g + STAGES - 2 >= total_g) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          drain_all = false;
+          counted_stores = false;
+        } else if (counted_stores && kt < STAGES - 1) {
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * kPPW + kEpiStores) : "memory");
+        } else {
+          counted_stores = false;
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * kPPW) : "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const unsigned char* st = smem + (g % STAGES) * kStageBytes;
+        if constexpr (MODE == 0) {
+          // both K-halves' fragments are requested up front (32 VGPRs); the DMA refill of the stage read in the
+          // previous K-step is issued between the two MFMA groups so that its address arithmetic overlaps matrix work
+          read_frags(st);
+          mfma_half(0);
+          issue_next();
+          mfma_half(1);
+        } else if constexpr (MODE == 1) {
+          read_frags(st);
+          issue_next();
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_half(0);
+          mfma_half(1);
+        } else {
+          if (kt > 0) {
+            mfma_half(0);
+            mfma_half(1);
+          }
+          issue_next();
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_sched_barrier(0);
+          asm volatile("" ::: "memory");
+          read_frags(st);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this stage is refilled after the next barrier
+        }
+      }
+      if constexpr (MODE == 2) {
+        mfma_half(0);
+        mfma_half(1);
+      }
+      // epilogue in the stage that was just read (stage (g-1) % STAGES): every wave must be done reading it
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const bool interior = (m0 + TBM <= a.n_rows) && (n0 + TBN <= a.O);
+      mfma_epilogue_band<T, EPI>(a, acc, m0, n0, wr, wc, lane, smem + ((g - 1) % STAGES) * kStageBytes + wave * 4096, interior);
+      // An interior tile issues exactly kEpiStores stores per wave, and every load of its epilogue has been consumed
+      // (waited for, with everything older) before the last store was issued.  Edge tiles predicate their stores.
+      if (interior && nk >= STAGES)
+        counted_stores = true;
+      else
+        drain_all = true;
+    }
+  };
+  if constexpr (!PP) {
+    run_tiles(std::integral_constant<int, 0>{});
+  } else {
+    if (wave < NW / 2)  // waves w and w + NW/2 share a SIMD
+      run_tiles(std::integral_constant<int, 1>{});
+    else
+      run_tiles(std::integral_constant<int, 2>{});
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- big-tile kernel
+// (32*MI) x 256 output tile per 8-wave workgroup, 2 (M) x 4 (N) waves of (16*MI) x 64.  Why: with every CU streaming,
+// the LDS-DMA path sustains only ~20-25 B/clk/CU next to running MFMAs (12-13 TB/s over the chip; the 256 x 128 kernel
+// above and the loader/consumer variant that was tried both sit on that rate), so the K-loop is bound by operand BYTES
+// per flop: a 320 x 256 tile moves 72 KiB per 10.5 MFLOP K-step where 256 x 128 moves 48 KiB per 4.2 MFLOP (0.6x).
+// [10240 x K] x [K -> 2048] is exactly 32 x 8 = 256 such tiles: one per CU, one round.  The ring is 2 stages of 72 KiB;
+// the refill of the other stage is issued piece by piece between the MFMAs of the first K-half, so the DMA queue never
+// waits for the step to end and the issue stalls hide behind matrix work.  Fragments are fetched per 16-row band right
+// before use (160 accumulator VGPRs leave no room for a whole K-half of fragments).
+template <typename T, int MI, int EPI>
+__global__ __launch_bounds__(512, 1) void linear_mfma_bigtile_kernel(LinArgs a, int tiles_n, int num_tiles) {
+  constexpr int WN = 4, NW = 8, STAGES = 2;
+  constexpr int TBM = 32 * MI, TBN = 64 * WN;
+  constexpr int kAPieces = TBM / 8, kWPieces = TBN / 8;
+  constexpr int kAPW = (kAPieces + NW - 1) / NW, kWPW = kWPieces / NW;
+  constexpr int kPPW = kAPW + kWPW;
+  constexpr int kStageBytes = (TBM + TBN) * BK * 2;
+  constexpr int kStores = 2 * MI;  // stores per wave of an interior epilogue
+  static_assert(kPPW <= MI, "one DMA piece per 16-row band of the first K-half");
+  static_assert(kPPW + kStores <= 63, "vmcnt is a 6-bit counter");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2][A tile | W tile] [1 KiB dummy]
+  unsigned char* const dummy = smem + STAGES * kStageBytes;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WN, wc = wave % WN;
+  const int G = gridDim.x;
+  const char* __restrict__ xb = (const char*)a.x;
+  const char* __restrict__ x2b = (const char*)a.x2;
+  const char* __restrict__ wb = (const char*)a.w;
+  const int nk = (a.K1 + a.K2) / BK;
+  const int my_tiles = (num_tiles - (int)blockIdx.x + G - 1) / G;
+  const int total_g = my_tiles * nk;
+
+  auto tile_origin = [&](int j, int& m0, int& n0) {
+    int id = blockIdx.x + j * G;
+    const int q = num_tiles >> 3, r = num_tiles & 7, xcd = id & 7, pos = id >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+    m0 = (id / tiles_n) * TBM;
+    n0 = (id % tiles_n) * TBN;
+  };
+
+  // ---- DMA issue side: K-tile ig (one ahead of the MFMA side), one 1-KiB piece per call
+  uint32_t a_voff[kAPW], a2_voff[kAPW], w_voff[kWPW];
+  auto setup_issue_tile = [&](int j) {
+    int m0, n0;
+    tile_origin(j, m0, n0);
+#pragma unroll
+    for (int i = 0; i < kAPW; ++i) {
+      const int row = min(wave * kAPW + i, kAPieces - 1) * 8 + (lane >> 3);
+      const int slot = (lane & 7) ^ ((row >> 1) & 7);
+      const int m = min(m0 + row, a.n_rows - 1);  // rows past the end are computed but never stored
+      a_voff[i] = (uint32_t)(((int64_t)m * a.ldx + slot * 8) * 2);
+      a2_voff[i] = (uint32_t)(((int64_t)m * a.ldx2 + slot * 8) * 2);
+    }
+#pragma unroll
+    for (int i = 0; i < kWPW; ++i) {
+      const int row = (wave * kWPW + i) * 8 + (lane >> 3);
+      const int slot = (lane & 7) ^ ((row >> 1) & 7);
+      const int n = min(n0 + row, a.O - 1);
+      w_voff[i] = (uint32_t)(((int64_t)n * a.ldw + slot * 8) * 2);
+    }
+  };
+  // The pieces of a K-tile are issued one by one between MFMAs, so the issue itself must be branch-free: everything
+  // uniform (source bases, destination stage, "is there still a K-tile to fetch") is fixed by begin_issue() before the
+  // MFMA block; past the last K-tile the pieces are re-fetched into the dummy KiB so that the vmcnt bookkeeping of all
+  // K-steps stays identical.
+  int ig = 0, ikt = 0, ij = 0;
+  const char* abase = xb;
+  const char* wbase = wb;
+  unsigned char* sdst = smem;
+  bool s_valid = true, s_first = true;
+  auto begin_issue = [&]() {
+    s_valid = ig < total_g;
+    if (s_valid) {
+      if (ikt == 0) setup_issue_tile(ij);
+      const int k0 = ikt * BK;
+      s_first = k0 < a.K1;
+      abase = s_first ? xb + (int64_t)k0 * 2 : x2b + (int64_t)(k0 - a.K1) * 2;
+      wbase = wb + (int64_t)k0 * 2;
+      sdst = smem + (ig % STAGES) * kStageBytes;
+    }
+  };
+  auto issue_piece = [&](int i) {  // i: compile-time piece index 0 .. kPPW-1
+    if (i < kAPW) {
+      const int pc = wave * kAPW + i;
+      unsigned char* dst = (s_valid && pc < kAPieces) ? sdst + pc * 1024 : dummy;
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(abase + (s_first ? a_voff[i] : a2_voff[i])), (lds_void_t*)dst, 16, 0, 0);
+    } else {
+      const int pc = wave * kWPW + (i - kAPW);
+      unsigned char* dst = s_valid ? sdst + TBM * BK * 2 + pc * 1024 : dummy;
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(wbase + w_voff[i - kAPW]), (lds_void_t*)dst, 16, 0, 0);
+    }
+  };
+  auto end_issue = [&]() {
+    if (s_valid) {
+      ++ig;
+      if (++ikt == nk) {
+        ikt = 0;
+        ++ij;
+      }
+    }
+  };
+  begin_issue();
+#pragma unroll
+  for (int i = 0; i < kPPW; ++i) issue_piece(i);
+  end_issue();
+
+  const int frow = lane & 15, fslot = lane >> 4;
+  int a_rd[2], w_rd[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    a_rd[ks] = lds_off(wr * (16 * MI) + frow, fslot + 4 * ks);
+    w_rd[ks] = TBM * BK * 2 + lds_off(wc * 64 + frow, fslot + 4 * ks);
+  }
+
+  int g = 0;
+  bool counted_stores = false;
   for (int j = 0; j < my_tiles; ++j) {
     int m0, n0;
     tile_origin(j, m0, n0);
-    f32x4 acc[4][4];
+    f32x4 acc[MI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int kt = 0; kt < nk; ++kt, ++g) {
-      // K-tile g must have landed; the STAGES-2 newer K-tiles (and, right after an interior epilogue, its stores) may
-      // stay in flight
-      if (drain_all || g + STAGES - 2 >= total_g) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        drain_all = false;
-        counted_stores = false;
-      } else if (counted_stores && kt < STAGES - 1) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * kPPW + kEpiStores) : "memory");
+      // K-tile g must have landed (it is the only DMA in flight); right after an interior epilogue its stores may stay
+      if (counted_stores && kt == 0) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kStores) : "memory");
       } else {
-        counted_stores = false;
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * kPPW) : "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      __builtin_amdgcn_s_barrier();
+      counted_stores = false;
+      __builtin_amdgcn_s_barrier();  // also: every wave has finished reading K-tile g-1, whose stage is refilled below
       asm volatile("" ::: "memory");
       const unsigned char* st = smem + (g % STAGES) * kStageBytes;
-      // both K-halves' fragments are requested up front (32 VGPRs); the DMA refill of the stage read in the previous
-      // K-step is issued between the two MFMA groups so that its address arithmetic overlaps matrix work
-      frag8 fa[2][4], fw[2][4];
+      begin_issue();
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+      for (int ks = 0; ks < 2; ++ks) {
+        frag8 fw[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          fa[ks][i] = *reinterpret_cast<const frag8*>(st + a_rd[ks] + i * 16 * BK * 2);
-          fw[ks][i] = *reinterpret_cast<const frag8*>(st + w_rd[ks] + i * 16 * BK * 2);
+        for (int i = 0; i < 4; ++i) fw[i] = *reinterpret_cast<const frag8*>(st + w_rd[ks] + i * 16 * BK * 2);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const frag8 fa = *reinterpret_cast<const frag8*>(st + a_rd[ks] + mi * 16 * BK * 2);
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16<T>(fw[ni], fa, acc[mi][ni]);  // D^T tile: rows n, cols m
+          if (ks == 0 && mi < kPPW) issue_piece(mi);
         }
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16<T>(fw[0][ni], fa[0][mi], acc[mi][ni]);  // D^T tile: rows n, cols m
-      issue_next();
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16<T>(fw[1][ni], fa[1][mi], acc[mi][ni]);
+      }
+      end_issue();
     }
-    // epilogue in the stage that was just read (stage (g-1) % STAGES): every wave must be done reading it
+    // epilogue in the stage that was just read: every wave must be done reading it
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     const bool interior = (m0 + TBM <= a.n_rows) && (n0 + TBN <= a.O);
-    mfma_epilogue_band<T, EPI>(a, acc, m0, n0, wr, wc, lane, smem + ((g - 1) % STAGES) * kStageBytes + wave * 4096, interior);
-    // An interior tile issues exactly kEpiStores stores per wave, and every load of its epilogue has been consumed
-    // (waited for, with everything older) before the last store was issued.  Edge tiles predicate their stores.
-    if (interior && nk >= STAGES)
-      counted_stores = true;
-    else
-      drain_all = true;
+    mfma_epilogue_band<T, EPI, MI>(a, acc, m0, n0, wr, wc, lane, smem + ((g - 1) % STAGES) * kStageBytes + wave * 4096, interior);
+    counted_stores = interior;  // exactly kStores stores per wave, issued after the DMAs of the next K-tile
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- tail rows
+// A handful of rows (the 2 rows by which an icosphere's 10 * 4^r + 2 nodes exceed a multiple of the big tile): one wave
+// per output column, lanes split K in 16-byte chunks, fp32 dot product + butterfly, lane 0 applies the epilogue.
+template <typename T>
+__global__ __launch_bounds__(256) void linear_tail_kernel(LinArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= a.O) return;
+  const T* __restrict__ w = (const T*)a.w + (int64_t)n * a.ldw;
+  for (int m = 0; m < a.n_rows; ++m) {
+    float acc = 0.f;
+    const T* __restrict__ xr = (const T*)a.x + (int64_t)m * a.ldx;
+    for (int k = lane * 8; k < a.K1; k += 512) {
+      float xv[8], wv[8];
+      load_vec<T, 8>(xr + k, xv);
+      load_vec<T, 8>(w + k, wv);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc = fmaf(xv[i], wv[i], acc);
+    }
+    if (a.K2 > 0) {
+      const T* __restrict__ x2r = (const T*)a.x2 + (int64_t)m * a.ldx2;
+      for (int k = lane * 8; k < a.K2; k += 512) {
+        float xv[8], wv[8];
+        load_vec<T, 8>(x2r + k, xv);
+        load_vec<T, 8>(w + a.K1 + k, wv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc = fmaf(xv[i], wv[i], acc);
+      }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      float vv = acc;
+      if (a.bias) vv += to_float(((const T*)a.bias)[n]);
+      if (a.g1) vv += to_float(((const T*)a.g1)[(int64_t)a.idx1[m] * a.ldg1 + n]);
+      if (a.g2) vv += to_float(((const T*)a.g2)[(int64_t)a.idx2[m] * a.ldg2 + n]);
+      if (a.act == ANEMOI_ACT_GELU) vv = gelu_erf(vv);
+      if (a.residual) vv += to_float(((const T*)a.residual)[(int64_t)m * a.ldr + n]);
+      ((T*)a.y)[(int64_t)m * a.ldy + n] = from_float<T>(vv);
+    }
   }
 }
 
@@ -625,33 +875,86 @@ static bool ring_eligible(const LinArgs& a) {
   return k_ok && e_ok;
 }
 
-template <typename T, int EPI, int WM>
+template <typename T, int EPI, int WM, bool PP>
 static int launch_persistent_wm(const LinArgs& a, hipStream_t st) {
   constexpr int WN = 2, ST = 3;  // (64*WM) x 128 tile, 2*WM waves, 3-stage ring (144 KiB at WM = 4), one workgroup per CU
   constexpr int smem_bytes = ST * (64 * WM + 64 * WN) * BK * 2 + 1024;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_mfma_persistent_kernel<T, WM, WN, ST, EPI>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_mfma_persistent_kernel<T, WM, WN, ST, EPI, PP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
     attr_set = true;
   }
   const int tm = (a.n_rows + 64 * WM - 1) / (64 * WM), tn = (a.O + 64 * WN - 1) / (64 * WN);
   const int nt = tm * tn;
   const int grid = nt < 256 ? nt : 256;
-  hipLaunchKernelGGL((linear_mfma_persistent_kernel<T, WM, WN, ST, EPI>), dim3(grid), dim3(64 * WM * WN), smem_bytes, st, a, tn, nt);
+  hipLaunchKernelGGL((linear_mfma_persistent_kernel<T, WM, WN, ST, EPI, PP>), dim3(grid), dim3(64 * WM * WN), smem_bytes, st, a, tn, nt);
   return check_launch("linear_mfma_persistent_kernel");
+}
+
+template <typename T, int EPI, int MI>
+static int launch_bigtile(const LinArgs& a, hipStream_t st) {
+  constexpr int TBM = 32 * MI, TBN = 256;
+  constexpr int smem_bytes = 2 * (TBM + TBN) * BK * 2 + 1024;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_mfma_bigtile_kernel<T, MI, EPI>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+    attr_set = true;
+  }
+  const int tm = (a.n_rows + TBM - 1) / TBM, tn = (a.O + TBN - 1) / TBN;
+  const int nt = tm * tn;
+  const int grid = nt < 256 ? nt : 256;
+  hipLaunchKernelGGL((linear_mfma_bigtile_kernel<T, MI, EPI>), dim3(grid), dim3(512), smem_bytes, st, a, tn, nt);
+  return check_launch("linear_mfma_bigtile_kernel");
+}
+
+// Estimated duration [us] of one launch on 256 CUs.  Both terms are measured rates: the K-loop moves (TBM + TBN) * 128 B
+// of operands per K-step at the ~44 GB/s per CU the LDS-DMA path sustains next to running MFMAs, the epilogue writes
+// TBM * TBN outputs at ~0.09 ns each; every round of tiles pays both.
+static double tile_cost_us(int tbm, int tbn, int rows, int O, int nk) {
+  const int64_t tiles = (int64_t)((rows + tbm - 1) / tbm) * ((O + tbn - 1) / tbn);
+  const double rounds = (double)((tiles + 255) / 256);
+  return rounds * (nk * (tbm + tbn) * 2.9e-3 + (double)tbm * tbn * 0.09e-3);
 }
 
 template <typename T, int EPI>
 static int launch_persistent(const LinArgs& a, hipStream_t st) {
-  // Tile height: 256 rows (8 waves) by default; 192 rows (6 waves) when that removes a partly empty round of tiles
-  // (makespan = rounds x tile height, e.g. [10242 x 512] outputs: 164 tiles of 256 rows on 164 CUs -> 216 tiles of 192).
-  auto cost = [&](int wm) {
-    const int64_t tiles = (int64_t)((a.n_rows + 64 * wm - 1) / (64 * wm)) * ((a.O + 127) / 128);
-    return ((tiles + 255) / 256) * wm;
-  };
-  if (cost(3) < cost(4)) return launch_persistent_wm<T, EPI, 3>(a, st);
-  return launch_persistent_wm<T, EPI, 4>(a, st);
+  const int nk = (a.K1 + a.K2) / BK;
+  const double c4 = tile_cost_us(256, 128, a.n_rows, a.O, nk), c3 = tile_cost_us(192, 128, a.n_rows, a.O, nk);
+  // 320 x 256 tiles; a few rows beyond a multiple of 320 (the icosphere's 10 * 4^r + 2 nodes) go to a second, tiny
+  // launch of the generic kernel instead of costing a whole extra round of tiles
+  constexpr int kBigM = 320, kTail = 32;
+  const int rem = a.n_rows % kBigM;
+  const bool split = rem > 0 && rem <= kTail && a.n_rows > kBigM;
+  const int main_rows = split ? a.n_rows - rem : a.n_rows;
+  const double cb = tile_cost_us(kBigM, 256, main_rows, a.O, nk) + (split ? 5.0 : 0.0);
+  static const int force_big = [] { const char* e = getenv("ANEMOI_GEMM_BIG"); return e ? atoi(e) : -1; }();
+  const bool big = force_big >= 0 ? (force_big != 0 && a.O >= 64) : cb < 0.95 * (c3 < c4 ? c3 : c4);
+  if (big) {
+    LinArgs m = a;
+    m.n_rows = main_rows;
+    const int rc = launch_bigtile<T, EPI, 10>(m, st);
+    if (rc != ANEMOI_OK || !split) return rc;
+    LinArgs t = a;  // rows [main_rows, n_rows)
+    const int64_t o = main_rows;
+    t.n_rows = rem;
+    t.x = (const T*)a.x + o * a.ldx;
+    if (a.x2) t.x2 = (const T*)a.x2 + o * a.ldx2;
+    if (a.residual) t.residual = (const T*)a.residual + o * a.ldr;
+    if (a.idx1) t.idx1 = a.idx1 + o;
+    if (a.idx2) t.idx2 = a.idx2 + o;
+    t.y = (T*)a.y + o * a.ldy;
+    hipLaunchKernelGGL((linear_tail_kernel<T>), dim3((t.O + 3) / 4), dim3(256), 0, st, t);
+    return check_launch("linear_tail_kernel");
+  }
+  static const bool pp = [] { const char* e = getenv("ANEMOI_GEMM_PP"); return !(e && e[0] == '0'); }();
+  if (pp) {
+    if (c3 < c4) return launch_persistent_wm<T, EPI, 3, true>(a, st);
+    return launch_persistent_wm<T, EPI, 4, true>(a, st);
+  }
+  if (c3 < c4) return launch_persistent_wm<T, EPI, 3, false>(a, st);
+  return launch_persistent_wm<T, EPI, 4, false>(a, st);
 }
 
 template <typename T>
