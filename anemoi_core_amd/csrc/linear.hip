@@ -44,6 +44,7 @@ struct LinArgs {
   int n_rows;
   int O;
   int act;
+  int tail_rows = 0;  // big-tile kernel only: rows [n_rows, n_rows + tail_rows) are computed on the VALU, a column per wave
 };
 
 // ---------------------------------------------------------------------------------------------- generic (VALU)
@@ -640,6 +641,49 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void linear_mfma_persistent_kernel
   }
 }
 
+// ---------------------------------------------------------------------------------------------- tail rows
+// A handful of rows (the 2 rows by which an icosphere's 10 * 4^r + 2 nodes exceed a multiple of the big tile): one wave
+// per output column, lanes split K in 16-byte chunks, fp32 dot product + butterfly, lane 0 applies the epilogue.
+// Called at the end of the big-tile kernel by every wave of the grid (column = global wave index, stride = waves in the
+// grid): 2 rows x 2048 columns are one column per wave, a few hundred cycles hidden behind the draining stores.
+template <typename T>
+__device__ __forceinline__ void tail_rows_valu(const LinArgs& a, int m_begin, int m_end, int n_first, int n_stride, int lane) {
+  for (int n = n_first; n < a.O; n += n_stride) {
+    const T* __restrict__ w = (const T*)a.w + (int64_t)n * a.ldw;
+    for (int m = m_begin; m < m_end; ++m) {
+      float acc = 0.f;
+      const T* __restrict__ xr = (const T*)a.x + (int64_t)m * a.ldx;
+      for (int k = lane * 8; k < a.K1; k += 512) {
+        float xv[8], wv[8];
+        load_vec<T, 8>(xr + k, xv);
+        load_vec<T, 8>(w + k, wv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc = fmaf(xv[i], wv[i], acc);
+      }
+      if (a.K2 > 0) {
+        const T* __restrict__ x2r = (const T*)a.x2 + (int64_t)m * a.ldx2;
+        for (int k = lane * 8; k < a.K2; k += 512) {
+          float xv[8], wv[8];
+          load_vec<T, 8>(x2r + k, xv);
+          load_vec<T, 8>(w + a.K1 + k, wv);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc = fmaf(xv[i], wv[i], acc);
+        }
+      }
+      acc = wave_sum(acc);
+      if (lane == 0) {
+        float vv = acc;
+        if (a.bias) vv += to_float(((const T*)a.bias)[n]);
+        if (a.g1) vv += to_float(((const T*)a.g1)[(int64_t)a.idx1[m] * a.ldg1 + n]);
+        if (a.g2) vv += to_float(((const T*)a.g2)[(int64_t)a.idx2[m] * a.ldg2 + n]);
+        if (a.act == ANEMOI_ACT_GELU) vv = gelu_fast(vv);  // same formula as the rows of the MFMA epilogue
+        if (a.residual) vv += to_float(((const T*)a.residual)[(int64_t)m * a.ldr + n]);
+        ((T*)a.y)[(int64_t)m * a.ldy + n] = from_float<T>(vv);
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- big-tile kernel
 // (32*MI) x 256 output tile per 8-wave workgroup, 2 (M) x 4 (N) waves of (16*MI) x 64.  Why: with every CU streaming,
 // the LDS-DMA path sustains only ~20-25 B/clk/CU next to running MFMAs (12-13 TB/s over the chip; the 256 x 128 kernel
@@ -661,7 +705,9 @@ __global__ __launch_bounds__(512, 1) void linear_mfma_bigtile_kernel(LinArgs a, 
   static_assert(kPPW <= MI, "one DMA piece per 16-row band of the first K-half");
   static_assert(kPPW + kStores <= 63, "vmcnt is a 6-bit counter");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2][A tile | W tile] [1 KiB dummy]
-  unsigned char* const dummy = smem + STAGES * kStageBytes;
+  // LDS destinations of the DMA as 32-bit LDS addresses (no flat -> local pointer casts on the issue path)
+  const uint32_t smem_l = (uint32_t)(size_t)(lds_void_t*)smem;
+  const uint32_t dummy_l = smem_l + STAGES * kStageBytes;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / WN, wc = wave % WN;
@@ -709,7 +755,7 @@ __global__ __launch_bounds__(512, 1) void linear_mfma_bigtile_kernel(LinArgs a, 
   int ig = 0, ikt = 0, ij = 0;
   const char* abase = xb;
   const char* wbase = wb;
-  unsigned char* sdst = smem;
+  uint32_t sdst = smem_l;
   bool s_valid = true, s_first = true;
   auto begin_issue = [&]() {
     s_valid = ig < total_g;
@@ -719,18 +765,18 @@ __global__ __launch_bounds__(512, 1) void linear_mfma_bigtile_kernel(LinArgs a, 
       s_first = k0 < a.K1;
       abase = s_first ? xb + (int64_t)k0 * 2 : x2b + (int64_t)(k0 - a.K1) * 2;
       wbase = wb + (int64_t)k0 * 2;
-      sdst = smem + (ig % STAGES) * kStageBytes;
+      sdst = smem_l + (ig % STAGES) * kStageBytes;
     }
   };
   auto issue_piece = [&](int i) {  // i: compile-time piece index 0 .. kPPW-1
     if (i < kAPW) {
       const int pc = wave * kAPW + i;
-      unsigned char* dst = (s_valid && pc < kAPieces) ? sdst + pc * 1024 : dummy;
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(abase + (s_first ? a_voff[i] : a2_voff[i])), (lds_void_t*)dst, 16, 0, 0);
+      const uint32_t dst = (s_valid && pc < kAPieces) ? sdst + pc * 1024 : dummy_l;
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(abase + (s_first ? a_voff[i] : a2_voff[i])), (lds_void_t*)(size_t)dst, 16, 0, 0);
     } else {
       const int pc = wave * kWPW + (i - kAPW);
-      unsigned char* dst = s_valid ? sdst + TBM * BK * 2 + pc * 1024 : dummy;
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(wbase + w_voff[i - kAPW]), (lds_void_t*)dst, 16, 0, 0);
+      const uint32_t dst = s_valid ? sdst + TBM * BK * 2 + pc * 1024 : dummy_l;
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(wbase + w_voff[i - kAPW]), (lds_void_t*)(size_t)dst, 16, 0, 0);
     }
   };
   auto end_issue = [&]() {
@@ -746,6 +792,8 @@ __global__ __launch_bounds__(512, 1) void linear_mfma_bigtile_kernel(LinArgs a, 
 #pragma unroll
   for (int i = 0; i < kPPW; ++i) issue_piece(i);
   end_issue();
+  // the tail rows ride in the shadow of the first (cold) K-tile's flight time
+  if (a.tail_rows > 0) tail_rows_valu<T>(a, a.n_rows, a.n_rows + a.tail_rows, (int)blockIdx.x * NW + wave, G * NW, lane);
 
   const int frow = lane & 15, fslot = lane >> 4;
   int a_rd[2], w_rd[2];
@@ -799,48 +847,6 @@ __global__ __launch_bounds__(512, 1) void linear_mfma_bigtile_kernel(LinArgs a, 
     const bool interior = (m0 + TBM <= a.n_rows) && (n0 + TBN <= a.O);
     mfma_epilogue_band<T, EPI, MI>(a, acc, m0, n0, wr, wc, lane, smem + ((g - 1) % STAGES) * kStageBytes + wave * 4096, interior);
     counted_stores = interior;  // exactly kStores stores per wave, issued after the DMAs of the next K-tile
-  }
-}
-
-// ---------------------------------------------------------------------------------------------- tail rows
-// A handful of rows (the 2 rows by which an icosphere's 10 * 4^r + 2 nodes exceed a multiple of the big tile): one wave
-// per output column, lanes split K in 16-byte chunks, fp32 dot product + butterfly, lane 0 applies the epilogue.
-template <typename T>
-__global__ __launch_bounds__(256) void linear_tail_kernel(LinArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (n >= a.O) return;
-  const T* __restrict__ w = (const T*)a.w + (int64_t)n * a.ldw;
-  for (int m = 0; m < a.n_rows; ++m) {
-    float acc = 0.f;
-    const T* __restrict__ xr = (const T*)a.x + (int64_t)m * a.ldx;
-    for (int k = lane * 8; k < a.K1; k += 512) {
-      float xv[8], wv[8];
-      load_vec<T, 8>(xr + k, xv);
-      load_vec<T, 8>(w + k, wv);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) acc = fmaf(xv[i], wv[i], acc);
-    }
-    if (a.K2 > 0) {
-      const T* __restrict__ x2r = (const T*)a.x2 + (int64_t)m * a.ldx2;
-      for (int k = lane * 8; k < a.K2; k += 512) {
-        float xv[8], wv[8];
-        load_vec<T, 8>(x2r + k, xv);
-        load_vec<T, 8>(w + a.K1 + k, wv);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc = fmaf(xv[i], wv[i], acc);
-      }
-    }
-    acc = wave_sum(acc);
-    if (lane == 0) {
-      float vv = acc;
-      if (a.bias) vv += to_float(((const T*)a.bias)[n]);
-      if (a.g1) vv += to_float(((const T*)a.g1)[(int64_t)a.idx1[m] * a.ldg1 + n]);
-      if (a.g2) vv += to_float(((const T*)a.g2)[(int64_t)a.idx2[m] * a.ldg2 + n]);
-      if (a.act == ANEMOI_ACT_GELU) vv = gelu_erf(vv);
-      if (a.residual) vv += to_float(((const T*)a.residual)[(int64_t)m * a.ldr + n]);
-      ((T*)a.y)[(int64_t)m * a.ldy + n] = from_float<T>(vv);
-    }
   }
 }
 
@@ -922,31 +928,20 @@ template <typename T, int EPI>
 static int launch_persistent(const LinArgs& a, hipStream_t st) {
   const int nk = (a.K1 + a.K2) / BK;
   const double c4 = tile_cost_us(256, 128, a.n_rows, a.O, nk), c3 = tile_cost_us(192, 128, a.n_rows, a.O, nk);
-  // 320 x 256 tiles; a few rows beyond a multiple of 320 (the icosphere's 10 * 4^r + 2 nodes) go to a second, tiny
-  // launch of the generic kernel instead of costing a whole extra round of tiles
+  // 320 x 256 tiles; a few rows beyond a multiple of 320 (the icosphere's 10 * 4^r + 2 nodes) are computed on the VALU
+  // at the end of the same kernel (a column per wave) instead of costing a whole extra round of tiles
   constexpr int kBigM = 320, kTail = 32;
   const int rem = a.n_rows % kBigM;
   const bool split = rem > 0 && rem <= kTail && a.n_rows > kBigM;
   const int main_rows = split ? a.n_rows - rem : a.n_rows;
-  const double cb = tile_cost_us(kBigM, 256, main_rows, a.O, nk) + (split ? 5.0 : 0.0);
+  const double cb = tile_cost_us(kBigM, 256, main_rows, a.O, nk) + (split ? 0.5 : 0.0);
   static const int force_big = [] { const char* e = getenv("ANEMOI_GEMM_BIG"); return e ? atoi(e) : -1; }();
   const bool big = force_big >= 0 ? (force_big != 0 && a.O >= 64) : cb < 0.95 * (c3 < c4 ? c3 : c4);
   if (big) {
     LinArgs m = a;
     m.n_rows = main_rows;
-    const int rc = launch_bigtile<T, EPI, 10>(m, st);
-    if (rc != ANEMOI_OK || !split) return rc;
-    LinArgs t = a;  // rows [main_rows, n_rows)
-    const int64_t o = main_rows;
-    t.n_rows = rem;
-    t.x = (const T*)a.x + o * a.ldx;
-    if (a.x2) t.x2 = (const T*)a.x2 + o * a.ldx2;
-    if (a.residual) t.residual = (const T*)a.residual + o * a.ldr;
-    if (a.idx1) t.idx1 = a.idx1 + o;
-    if (a.idx2) t.idx2 = a.idx2 + o;
-    t.y = (T*)a.y + o * a.ldy;
-    hipLaunchKernelGGL((linear_tail_kernel<T>), dim3((t.O + 3) / 4), dim3(256), 0, st, t);
-    return check_launch("linear_tail_kernel");
+    m.tail_rows = split ? rem : 0;
+    return launch_bigtile<T, EPI, 10>(m, st);
   }
   static const bool pp = [] { const char* e = getenv("ANEMOI_GEMM_PP"); return !(e && e[0] == '0'); }();
   if (pp) {
