@@ -881,9 +881,9 @@ static bool ring_eligible(const LinArgs& a) {
   return k_ok && e_ok;
 }
 
-template <typename T, int EPI, int WM, bool PP>
+template <typename T, int EPI, int WM, bool PP, int WN = 2>
 static int launch_persistent_wm(const LinArgs& a, hipStream_t st) {
-  constexpr int WN = 2, ST = 3;  // (64*WM) x 128 tile, 2*WM waves, 3-stage ring (144 KiB at WM = 4), one workgroup per CU
+  constexpr int ST = 3;  // (64*WM) x (64*WN) tile, WM*WN waves, 3-stage ring (144 KiB at 4 x 2: one workgroup per CU)
   constexpr int smem_bytes = ST * (64 * WM + 64 * WN) * BK * 2 + 1024;
   static bool attr_set = false;
   if (!attr_set) {
@@ -893,7 +893,9 @@ static int launch_persistent_wm(const LinArgs& a, hipStream_t st) {
   }
   const int tm = (a.n_rows + 64 * WM - 1) / (64 * WM), tn = (a.O + 64 * WN - 1) / (64 * WN);
   const int nt = tm * tn;
-  const int grid = nt < 256 ? nt : 256;
+  const int per_cu = (160 * 1024) / smem_bytes < 1 ? 1 : (160 * 1024) / smem_bytes;  // small tiles: several workgroups per CU
+  const int cap = 256 * (per_cu > 4 ? 4 : per_cu);
+  const int grid = nt < cap ? nt : cap;
   hipLaunchKernelGGL((linear_mfma_persistent_kernel<T, WM, WN, ST, EPI, PP>), dim3(grid), dim3(64 * WM * WN), smem_bytes, st, a, tn, nt);
   return check_launch("linear_mfma_persistent_kernel");
 }
@@ -943,6 +945,10 @@ static int launch_persistent(const LinArgs& a, hipStream_t st) {
     m.tail_rows = split ? rem : 0;
     return launch_bigtile<T, EPI, 10>(m, st);
   }
+  // few tiles (small M, e.g. one rank's rows of a sharded mesh): 64 x 128 tiles on more CUs; the K-loop of a lone tile
+  // is bound by the ~40 cycles a CU needs per 1-KiB LDS-DMA piece, i.e. by the tile's operand bytes, like the model says
+  const double c1 = tile_cost_us(64, 128, a.n_rows, a.O, nk);
+  if (c1 < 0.9 * (c3 < c4 ? c3 : c4)) return launch_persistent_wm<T, EPI, 1, false, 2>(a, st);
   static const bool pp = [] { const char* e = getenv("ANEMOI_GEMM_PP"); return !(e && e[0] == '0'); }();
   if (pp) {
     if (c3 < c4) return launch_persistent_wm<T, EPI, 3, true>(a, st);
