@@ -174,10 +174,16 @@ def profile_forward(step, dtype):
     ops.layer_norm = wrap("ln", saved["layer_norm"], ln_work)
     try:
         torch.cuda.synchronize()
-        # The kernels (avg ~30 us) outlast the host's per-op launch cost (~10 us), so the host runs ahead of the queue and
-        # each pair brackets one kernel plus ~2.5 us of event-marker cost (tools/event_probe.py: 33.8 us per pair vs 31.6 us
-        # per launch back-to-back).  Do NOT pre-roll with a heavy GEMM burst to back the queue up: the clocks drop after
-        # it and every kernel then measures 30-45 % slow for several ms (same probe).
+        # Back the queue up with a SLEEP kernel (no power draw, unlike a GEMM burst, which lowers the clocks for ms
+        # afterwards - tools/event_probe.py) so that the host is done enqueueing before the first kernel starts: every
+        # event pair then brackets exactly one kernel (+ ~2.5 us of marker cost), never a wait for the host.
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        torch.cuda._sleep(1_000_000)
+        e1.record()
+        torch.cuda.synchronize()
+        per_ms = 1_000_000 / max(e0.elapsed_time(e1), 1e-3)
+        torch.cuda._sleep(int(per_ms * 12.0))  # ~12 ms: the eager forward with its ~330 event records enqueues in ~5 ms
         step()
         torch.cuda.synchronize()
     finally:
