@@ -224,7 +224,8 @@ def _lin_ref(x, w, b=None, act=None, res=None, x2=None, g1=None, i1=None, g2=Non
 @pytest.mark.parametrize("N,K,O", [(300, 512, 512), (1000, 512, 2048), (257, 2048, 512), (129, 64, 128), (70, 20, 64), (50, 11, 7), (333, 512, 100), (5, 64, 64),
                                    (1300, 512, 2048), (2100, 2048, 512), (1111, 512, 512), (1030, 64, 100), (1500, 72, 512),
                                    (4200, 512, 2048), (3000, 192, 3072),  # > 256 tiles: several tiles per persistent workgroup
-                                   (10242, 512, 512)])  # 192-row tile variant (216 tiles instead of 164 of 256 rows)
+                                   (10242, 512, 512),  # 192-row tile variant (216 tiles instead of 164 of 256 rows)
+                                   (10242, 512, 2048), (10242, 192, 2048)])  # 320x256 big tile, one per CU, + 2 tail rows on the VALU
 def test_linear_epilogues(ops, dtype, N, K, O):
     gen = torch.Generator().manual_seed(N + K + O)
     x = torch.randn(N, K, generator=gen).to(dtype)
@@ -240,7 +241,8 @@ def test_linear_epilogues(ops, dtype, N, K, O):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("N,K1,K2,O", [(400, 512, 512, 512), (90, 32, 32, 32), (200, 128, 64, 256), (1400, 512, 512, 512), (1200, 128, 64, 256)])
+@pytest.mark.parametrize("N,K1,K2,O", [(400, 512, 512, 512), (90, 32, 32, 32), (200, 128, 64, 256), (1400, 512, 512, 512), (1200, 128, 64, 256),
+                                       (10242, 256, 256, 2048)])  # big tile + tail rows with the K-concat / gather-add epilogue
 def test_linear_concat_and_gather(ops, dtype, N, K1, K2, O):
     gen = torch.Generator().manual_seed(N + K1)
     x, x2 = torch.randn(N, K1, generator=gen).to(dtype), torch.randn(N, K2, generator=gen).to(dtype)
