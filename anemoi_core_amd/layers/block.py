@@ -299,7 +299,7 @@ class GraphConvProcessorBlock(GraphConvBaseBlock):
             x_in = comm.gather_tensor(x, 0, shard_info.nodes, model_comm_group)
             n_loc = x.shape[0]
             d0 = sum(shard_info.nodes[: comm_rank(model_comm_group)])
-            out_full, edges_new = self._conv_sharded(x_in, x, d0, edge_attr, edge_index)
+            out_full, edges_new = self._conv_sharded(x_in, x, d0, edge_attr, edge_index, layer_kwargs.get("local_edge_cache"))
             out = out_full
             assert out.shape[0] == n_loc
         else:
@@ -307,10 +307,14 @@ class GraphConvProcessorBlock(GraphConvBaseBlock):
         nodes_new = self.node_mlp(x, x2=out, residual=x)
         return nodes_new, edges_new
 
-    def _conv_sharded(self, x_all: Tensor, x_loc: Tensor, d0: int, edge_attr: Tensor, edge_index: Tensor):
-        # local edges carry GLOBAL ids: sources index the gathered table, destinations are shifted to local rows
-        ei = torch.stack([edge_index[0], edge_index[1] - d0])
-        return self.conv((x_all, x_loc), edge_attr, ei, size=(x_all.shape[0], x_loc.shape[0]))
+    def _conv_sharded(self, x_all: Tensor, x_loc: Tensor, d0: int, edge_attr: Tensor, edge_index: Tensor, cache: Optional[dict] = None):
+        # local edges carry GLOBAL ids: sources index the gathered table, destinations are shifted to local rows.  The
+        # relabelled index is shared by all layers of a processor (``cache``): one CSC for the whole stack.
+        cache = self.__dict__.setdefault("_own_cache", {}) if cache is None else cache
+        key = (edge_index.data_ptr(), version(edge_index), d0)
+        if cache.get("key") != key:
+            cache["key"], cache["ei"], cache["anchor"] = key, torch.stack([edge_index[0], edge_index[1] - d0]), edge_index
+        return self.conv((x_all, x_loc), edge_attr, cache["ei"], size=(x_all.shape[0], x_loc.shape[0]))
 
 
 class GraphConvMapperBlock(GraphConvBaseBlock):
@@ -319,8 +323,19 @@ class GraphConvMapperBlock(GraphConvBaseBlock):
         x_src, x_dst = x
         check_inference(x_src, x_dst, edge_attr)
         if model_is_distributed(model_comm_group):
-            raise NotImplementedError("sharded GNN mappers are not implemented yet (GraphTransformer mappers are)")
-        out, edges_new = self.conv((x_src, x_dst), edge_attr, edge_index, size=size)
+            # block.py:441-479: node shards in, this rank's (dst-owned, globally numbered) edges; every source row is made
+            # available (the mappers of this package call forward_local with only the rows they need instead)
+            x_src_all = comm.gather_tensor(x_src, 0, shard_info.src_nodes, model_comm_group)
+            d0 = sum(shard_info.dst_nodes[: comm_rank(model_comm_group)])
+            ei = torch.stack([edge_index[0], edge_index[1] - d0])
+            return self.forward_local(x_src_all, x_dst, x_src, edge_attr, ei)
+        return self.forward_local(x_src, x_dst, x_src, edge_attr, edge_index, size=size)
+
+    def forward_local(self, x_src_conv: Tensor, x_dst: Tensor, x_src_update: Tensor, edge_attr: Tensor, edge_index: Tensor, size=None):
+        """``x_src_conv``: the source rows ``edge_index[0]`` refers to; ``x_src_update``: the source rows this rank owns
+        (the same tensor when nothing is sharded)."""
+        size = (x_src_conv.shape[0], x_dst.shape[0]) if size is None else size
+        out, edges_new = self.conv((x_src_conv, x_dst), edge_attr, edge_index, size=size)
         nodes_new_dst = self.node_mlp(x_dst, x2=out, residual=x_dst)
-        nodes_new_src = self.node_mlp(x_src, x2=x_src, residual=x_src) if self.update_src_nodes else x_src
+        nodes_new_src = self.node_mlp(x_src_update, x2=x_src_update, residual=x_src_update) if self.update_src_nodes else x_src_update
         return (nodes_new_src, nodes_new_dst), edges_new

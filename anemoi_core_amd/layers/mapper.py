@@ -26,26 +26,12 @@ from ..distributed.partition import (
     local_bipartite_graph,
     shard_edges_1hop,
 )
-from ..distributed.shapes import BipartiteGraphShardInfo, comm_rank, comm_size, model_is_distributed
+from ..distributed.shapes import BipartiteGraphShardInfo, comm_rank, comm_size, get_shard_sizes, model_is_distributed
 from .block import GraphConvMapperBlock, GraphTransformerMapperBlock
 from .kernels import PaddedLinear, check_inference
 from .mlp import MLP
 from .utils import compute_mlp_hidden_dim, load_layer_kernels
 from ..utils.tensors import version
-
-
-class BaseMapper(nn.Module):
-    def __init__(self, *, in_channels_src: int, in_channels_dst: int, hidden_dim: int, out_channels_dst: Optional[int] = None,
-                 cpu_offload: bool = False, gradient_checkpointing: bool = True, layer_kernels=None, **kwargs) -> None:
-        super().__init__()
-        self.in_channels_src = in_channels_src
-        self.in_channels_dst = in_channels_dst
-        self.hidden_dim = hidden_dim
-        self.out_channels_dst = out_channels_dst
-        self.gradient_checkpointing = gradient_checkpointing
-        self.layer_factory = load_layer_kernels(layer_kernels)
-        if cpu_offload:
-            raise NotImplementedError("cpu_offload is a training memory feature; not needed with 288 GB of HBM")
 
 
 class _LocalGraphCache:
@@ -62,30 +48,21 @@ class _LocalGraphCache:
         return self.val
 
 
-class GraphTransformerBaseMapper(BaseMapper):
+class BaseMapper(nn.Module):
     def __init__(self, *, in_channels_src: int, in_channels_dst: int, hidden_dim: int, out_channels_dst: Optional[int] = None,
-                 num_chunks: int, num_heads: int, mlp_hidden_ratio: float, edge_dim: int, attn_channels: Optional[int] = None,
-                 qk_norm: bool = False, mlp_implementation: str = "mlp", cpu_offload: bool = False, layer_kernels=None,
-                 shard_strategy: str = "edges", graph_attention_backend: str = "hip", edge_pre_mlp: bool = False, **kwargs) -> None:
-        super().__init__(in_channels_src=in_channels_src, in_channels_dst=in_channels_dst, hidden_dim=hidden_dim,
-                         out_channels_dst=out_channels_dst, cpu_offload=cpu_offload, layer_kernels=layer_kernels, **kwargs)
-        self.num_chunks = num_chunks
-        assert shard_strategy in ["heads", "edges"], (
-            f"Invalid shard strategy '{shard_strategy}' for {self.__class__.__name__}. Supported strategies are 'heads' and 'edges'."
-        )
-        self.shard_strategy = shard_strategy
-        self.proc = GraphTransformerMapperBlock(
-            in_channels=hidden_dim, hidden_dim=compute_mlp_hidden_dim(hidden_dim, mlp_hidden_ratio), out_channels=hidden_dim,
-            attn_channels=attn_channels, num_heads=num_heads, edge_dim=edge_dim, qk_norm=qk_norm,
-            mlp_implementation=mlp_implementation, layer_kernels=self.layer_factory, shard_strategy=shard_strategy,
-            graph_attention_backend=graph_attention_backend, edge_pre_mlp=edge_pre_mlp,
-        )
-        self.emb_nodes_dst = self.layer_factory.Linear(self.in_channels_dst, self.hidden_dim)
+                 cpu_offload: bool = False, gradient_checkpointing: bool = True, layer_kernels=None, **kwargs) -> None:
+        super().__init__()
+        self.in_channels_src = in_channels_src
+        self.in_channels_dst = in_channels_dst
+        self.hidden_dim = hidden_dim
+        self.out_channels_dst = out_channels_dst
+        self.gradient_checkpointing = gradient_checkpointing
+        self.layer_factory = load_layer_kernels(layer_kernels)
+        if cpu_offload:
+            raise NotImplementedError("cpu_offload is a training memory feature; not needed with 288 GB of HBM")
         self._local = _LocalGraphCache()
         self._plan = None
-        self._emb_src, self._emb_dst = PaddedLinear(), PaddedLinear()
 
-    # subclasses: pre_process(x_src_compact, x_dst) -> embedded pair, post_process(x_dst)
     def _local_graph(self, x, shard_info, edge_attr, edge_index, group):
         """Rank-local (dst range, edges, compact sources) — index work only, cached for the static graph."""
         world, rank = comm_size(group), comm_rank(group)
@@ -114,6 +91,29 @@ class GraphTransformerBaseMapper(BaseMapper):
 
         return self._local.get(key, build)
 
+
+class GraphTransformerBaseMapper(BaseMapper):
+    def __init__(self, *, in_channels_src: int, in_channels_dst: int, hidden_dim: int, out_channels_dst: Optional[int] = None,
+                 num_chunks: int, num_heads: int, mlp_hidden_ratio: float, edge_dim: int, attn_channels: Optional[int] = None,
+                 qk_norm: bool = False, mlp_implementation: str = "mlp", cpu_offload: bool = False, layer_kernels=None,
+                 shard_strategy: str = "edges", graph_attention_backend: str = "hip", edge_pre_mlp: bool = False, **kwargs) -> None:
+        super().__init__(in_channels_src=in_channels_src, in_channels_dst=in_channels_dst, hidden_dim=hidden_dim,
+                         out_channels_dst=out_channels_dst, cpu_offload=cpu_offload, layer_kernels=layer_kernels, **kwargs)
+        self.num_chunks = num_chunks
+        assert shard_strategy in ["heads", "edges"], (
+            f"Invalid shard strategy '{shard_strategy}' for {self.__class__.__name__}. Supported strategies are 'heads' and 'edges'."
+        )
+        self.shard_strategy = shard_strategy
+        self.proc = GraphTransformerMapperBlock(
+            in_channels=hidden_dim, hidden_dim=compute_mlp_hidden_dim(hidden_dim, mlp_hidden_ratio), out_channels=hidden_dim,
+            attn_channels=attn_channels, num_heads=num_heads, edge_dim=edge_dim, qk_norm=qk_norm,
+            mlp_implementation=mlp_implementation, layer_kernels=self.layer_factory, shard_strategy=shard_strategy,
+            graph_attention_backend=graph_attention_backend, edge_pre_mlp=edge_pre_mlp,
+        )
+        self.emb_nodes_dst = self.layer_factory.Linear(self.in_channels_dst, self.hidden_dim)
+        self._emb_src, self._emb_dst = PaddedLinear(), PaddedLinear()
+
+    # subclasses: pre_process(x_src_compact, x_dst) -> embedded pair, post_process(x_dst)
     def forward(self, x, batch_size: int, shard_info: BipartiteGraphShardInfo, edge_attr: Tensor, edge_index: Tensor,
                 model_comm_group=None, keep_x_dst_sharded: bool = False, edges_are_dst_sorted: bool = True, cond=None, **kwargs):
         if cond is not None:
@@ -207,10 +207,11 @@ class GNNBaseMapper(BaseMapper):
 
     def mapper_forward(self, x, batch_size, shard_info, edge_attr, edge_index, model_comm_group=None,
                        keep_x_dst_sharded: bool = False, edges_are_dst_sorted: bool = True, **kwargs):
-        if model_is_distributed(model_comm_group):
-            raise NotImplementedError("sharded GNN mappers are not implemented yet (GraphTransformer mappers are)")
         x_src, x_dst = x
         check_inference(x_src, x_dst, edge_attr)
+        if model_is_distributed(model_comm_group):
+            return self._mapper_forward_sharded(x_src, x_dst, shard_info, edge_attr, edge_index, model_comm_group,
+                                                keep_x_dst_sharded, edges_are_dst_sorted)
         edge_attr, edge_index = ensure_edges_are_dst_sorted(edge_attr, edge_index, edges_are_sharded=False,
                                                            edges_are_dst_sorted=edges_are_dst_sorted)
         size = (x_src.shape[0], x_dst.shape[0])
@@ -218,6 +219,31 @@ class GNNBaseMapper(BaseMapper):
         x_src, x_dst = self.pre_process((x_src, x_dst))
         (x_src, x_dst), edge_attr = self.proc((x_src, x_dst), edge_attr, edge_index, shard_info, model_comm_group, size=size, **kwargs)
         return x_src, self.post_process(x_dst)
+
+    def _mapper_forward_sharded(self, x_src, x_dst, shard_info, edge_attr, edge_index, group, keep_x_dst_sharded, edges_are_dst_sorted):
+        """Reference mapper.py:776-836 + GraphConvMapperBlock (block.py:441-479): nodes sharded in balanced contiguous
+        ranges, every rank owns the edges of its destination range.  The node embeddings and the source update run on
+        the local shards (work split over the ranks, as in the reference); where the reference then all-gathers every
+        embedded source row (``sync_tensor``) only the rows this rank's edges touch are exchanged (``exchange_rows``,
+        plan built once).  A source table that came in replicated is returned replicated."""
+        edge_attr, edge_index = ensure_edges_are_dst_sorted(edge_attr, edge_index, edges_are_sharded=shard_info.edges_are_sharded(),
+                                                           model_comm_group=group, edges_are_dst_sorted=edges_are_dst_sorted)
+        g = self._local_graph((x_src, x_dst), shard_info, edge_attr, edge_index, group)
+        d0, d1 = g["dst_range"]
+        x_dst_loc = x_dst if shard_info.dst_is_sharded() else x_dst[d0:d1]
+        src_was_sharded = shard_info.src_is_sharded()
+        src_sizes = shard_info.src_nodes if src_was_sharded else get_shard_sizes(x_src, 0, group)
+        x_src_loc = x_src if src_was_sharded else comm.shard_tensor(x_src, 0, src_sizes, group)
+        e_loc = self.emb_edges(g["edge_attr"])
+        xs_loc, xd_loc = self.pre_process((x_src_loc, x_dst_loc))
+        xs_need, self._plan = comm.exchange_rows(xs_loc, g["src_ids"], src_sizes, group, gather_fn=ops.gather_rows, plan=self._plan)
+        (xs_new, xd_new), _ = self.proc.forward_local(xs_need, xd_loc, xs_loc, e_loc, g["edge_index"])
+        out_dst = self.post_process(xd_new)
+        if not keep_x_dst_sharded:
+            out_dst = comm.gather_tensor(out_dst, 0, g["partition"].dst_splits, group)
+        if not src_was_sharded:
+            xs_new = comm.gather_tensor(xs_new, 0, src_sizes, group)
+        return xs_new, out_dst
 
     def forward(self, x, batch_size: int, shard_info: BipartiteGraphShardInfo, edge_attr: Tensor, edge_index: Tensor,
                 model_comm_group=None, keep_x_dst_sharded: bool = False, edges_are_dst_sorted: bool = True, **kwargs):

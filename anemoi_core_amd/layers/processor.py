@@ -103,16 +103,22 @@ class GNNProcessor(BaseProcessor):
         self.build_layers(GraphConvProcessorBlock, in_channels=num_channels, out_channels=num_channels, num_chunks=1, **kwargs_build)
         kwargs_build["edge_dim"] = edge_dim  # only the first layer embeds the raw edge attributes
         self.proc[0] = GraphConvProcessorBlock(in_channels=num_channels, out_channels=num_channels, num_chunks=1, **kwargs_build)
+        self._shard_cache = None
+        self._local_edge_cache: dict = {}
 
     def forward(self, x: Tensor, batch_size: int, shard_info: GraphShardInfo, edge_attr: Tensor, edge_index: Tensor,
                 model_comm_group=None, edges_are_dst_sorted: bool = True, *args, **kwargs) -> Tensor:
-        if not shard_info.edges_are_sharded():
+        if not shard_info.edges_are_sharded():  # local slice of the dst-sorted edges (no communication), cached: static graph
             target_nodes = sum(shard_info.nodes) if shard_info.nodes_are_sharded() else x.shape[0]
-            edge_attr, edge_index, edge_shard_sizes = shard_edges_1hop(
-                edge_attr, edge_index, target_nodes, target_nodes, model_comm_group, edges_are_dst_sorted=edges_are_dst_sorted)
-            if edge_shard_sizes is None and not edges_are_dst_sorted:
-                edge_attr, edge_index = ensure_edges_are_dst_sorted(edge_attr, edge_index, edges_are_sharded=False,
-                                                                   edges_are_dst_sorted=False)
+            key = (edge_index.data_ptr(), version(edge_index), edge_attr.data_ptr(), version(edge_attr), target_nodes,
+                   id(model_comm_group), edges_are_dst_sorted)
+            if self._shard_cache is None or self._shard_cache[0] != key:
+                ea, ei, edge_shard_sizes = shard_edges_1hop(edge_attr, edge_index, target_nodes, target_nodes, model_comm_group,
+                                                            edges_are_dst_sorted=edges_are_dst_sorted)
+                if edge_shard_sizes is None and not edges_are_dst_sorted:
+                    ea, ei = ensure_edges_are_dst_sorted(ea, ei, edges_are_sharded=False, edges_are_dst_sorted=False)
+                self._shard_cache = (key, (ea, ei, edge_shard_sizes), (edge_attr, edge_index))
+            edge_attr, edge_index, edge_shard_sizes = self._shard_cache[1]
             shard_info = GraphShardInfo(nodes=shard_info.nodes, edges=edge_shard_sizes)
-        x, _ = self.run_layers((x, edge_attr), edge_index, shard_info, model_comm_group, **kwargs)
+        x, _ = self.run_layers((x, edge_attr), edge_index, shard_info, model_comm_group, local_edge_cache=self._local_edge_cache, **kwargs)
         return x

@@ -371,7 +371,10 @@ def main():
                 if not torch.equal(out, expect):  # kernels are deterministic: a replay must reproduce the eager run bit for bit
                     ok, why = 0, "segmented replay differs from the eager forward"
             except Exception as e:  # noqa: BLE001
-                ok, why = 0, f"{type(e).__name__}: {e}"
+                import traceback
+
+                ok, why = 0, f"{type(e).__name__}: {str(e).splitlines()[0]} @ " + " <- ".join(
+                    f"{os.path.basename(f.filename)}:{f.lineno}" for f in reversed(traceback.extract_tb(e.__traceback__)[-6:]))
             flag = torch.tensor([ok], device="cpu" if host_transport else device, dtype=torch.int32)
             torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)  # every rank takes the same path
             if int(flag.item()) == 0:

@@ -126,13 +126,13 @@ def test_sharded_processor_reproduces_reference_rank_outputs(world):
     assert float((torch.cat([o["out"] for o in outs]) - s["out"]).abs().max()) < 1e-5  # sharded == unsharded
 
 
-def _model_worker(rank, world, group):
+def _model_worker(rank, world, group, kind="gt"):
     from tests import cpu_ops_shim
 
     cpu_ops_shim.install()
     from tests.helpers import build_model_from_fixture
 
-    c = load_golden("model_tiny.pt")["gt"]
+    c = load_golden("model_tiny.pt")[kind]
     model, _ = build_model_from_fixture(c)
     model.load_state_dict(c["params"], strict=True)
     with torch.no_grad():
@@ -147,4 +147,13 @@ def test_sharded_full_model_matches_reference_output(world):
     unsharded output on every rank."""
     c = load_golden("model_tiny.pt")["gt"]
     for o in _spawn(_model_worker, world):
+        assert float((o["out"] - c["out"]).abs().max()) < 2e-4
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_gnn_model_matches_reference_output(world):
+    """GNN encoder / processor / decoder (GraphConv) with sharded nodes and dst-owned edges: node embeddings and updates on
+    the local shards, needed source rows exchanged, == the reference's unsharded output on every rank."""
+    c = load_golden("model_tiny.pt")["gnn"]
+    for o in _spawn(_model_worker, world, "gnn"):
         assert float((o["out"] - c["out"]).abs().max()) < 2e-4

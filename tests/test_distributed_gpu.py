@@ -41,26 +41,27 @@ def _entry(rank, world, init_file, fn, tmp, args):
         dist.destroy_process_group()
 
 
-def _model(dtype=torch.float32):
+def _model(dtype=torch.float32, kind="gt"):
     from tests.helpers import build_model_from_fixture
 
-    c = load_golden("model_tiny.pt")["gt"]
+    c = load_golden("model_tiny.pt")[kind]
     model, _ = build_model_from_fixture(c)
     model.load_state_dict(c["params"], strict=True)
     return model.to("cuda").to(dtype), c
 
 
-def _eager_worker(rank, world, group):
-    model, c = _model()
+def _eager_worker(rank, world, group, kind="gt"):
+    model, c = _model(kind=kind)
     with torch.inference_mode():
         y = model({"data": c["x"].cuda()}, model_comm_group=group)["data"]
     return dict(out=y.cpu())
 
 
+@pytest.mark.parametrize("kind", ["gt", "gnn"])
 @pytest.mark.parametrize("world", [2, 3])
-def test_sharded_model_on_hip_kernels_matches_reference(world):
-    c = load_golden("model_tiny.pt")["gt"]
-    for o in _spawn(_eager_worker, world):
+def test_sharded_model_on_hip_kernels_matches_reference(world, kind):
+    c = load_golden("model_tiny.pt")[kind]
+    for o in _spawn(_eager_worker, world, kind):
         assert float((o["out"] - c["out"]).abs().max()) < 2e-4
 
 
