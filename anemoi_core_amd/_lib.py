@@ -9,7 +9,7 @@ import ctypes as C
 import os
 import threading
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libanemoi_hip.so")
 
 F32, BF16, F16 = 0, 1, 2
@@ -22,6 +22,8 @@ SIGNATURES = {
     "anemoi_hip_abi_version": ([], C.c_int),
     "anemoi_hip_last_error": ([], C.c_char_p),
     "anemoi_gt_attention_fwd": ([_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _i64, _p, _i64, _p, _i32, _i32, _i32, _i32, C.c_int, _p], C.c_int),
+    "anemoi_gt_attention_bwd": ([_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p,
+                                 _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i32, _i32, _i32, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_gt_attention_fused_edge_fwd": ([_p, _i64, _p, _i64, _p, _i64, _p, _i32, _p, _p, _p, _p, _i64, _p, _i64, _p, _i32, _i32, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_pack_edge_weights": ([_p, _p, _p, _i32, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_pack_edge_features": ([_p, _i64, _p, _i32, _i32, _i32, C.c_int, _p], C.c_int),

@@ -144,6 +144,47 @@ def gt_attention(q: Tensor, k: Tensor, v: Tensor, e: Optional[Tensor], csc: CSC,
     return (out, lse) if return_lse else out
 
 
+def build_reverse_csr(csc: CSC) -> tuple[Tensor, Tensor, Tensor]:
+    """(rowptr [n_src+1], edge_ids [M], edge_dst [M]) int32: the CSC edges grouped by SOURCE, as the backward pass walks
+    them (reference triton/utils.py:25-70 returns the same triple next to the CSC).  Index bookkeeping, any device."""
+    order = torch.sort(csc.row.long(), stable=True)[1]
+    rowptr = torch.zeros(csc.n_src + 1, dtype=torch.long, device=csc.row.device)
+    if csc.num_edges:
+        rowptr[1:] = torch.cumsum(torch.bincount(csc.row.long(), minlength=csc.n_src), 0)
+    return rowptr.to(torch.int32).contiguous(), order.to(torch.int32).contiguous(), csc.dst
+
+
+def gt_attention_backward(d_out: Tensor, q: Tensor, k: Tensor, v: Tensor, e: Tensor, out: Tensor, lse: Tensor, csc: CSC,
+                          reverse: tuple[Tensor, Tensor, Tensor], num_heads: int):
+    """Gradients (dq, dk, dv, de) of ``gt_attention`` with a materialised edge tensor.  All node/edge tensors [rows, D];
+    ``out``/``lse`` are the forward's results; ``reverse`` = build_reverse_csr(csc)."""
+    rowptr, edge_ids, edge_dst = reverse
+    _dev(d_out, q, k, v, e, out, lse, csc.row, rowptr, edge_ids, edge_dst)
+    D = q.shape[1]
+    if D % num_heads:
+        raise ValueError(f"channels {D} not divisible by heads {num_heads}")
+    M = csc.num_edges
+    if q.shape[0] != csc.n_dst or k.shape[0] != csc.n_src or v.shape[0] != csc.n_src or e.shape[0] != M:
+        raise ValueError("tensor row counts do not match the graph")
+    if d_out.shape != q.shape or out.shape != q.shape or tuple(lse.shape) != (csc.n_dst, num_heads) or lse.dtype != torch.float32:
+        raise ValueError("d_out/out must have q's shape and lse must be fp32 [n_dst, H]")
+    if rowptr.shape[0] != csc.n_src + 1 or edge_ids.shape[0] != M or edge_dst.shape[0] != M:
+        raise ValueError("reverse CSR does not match the graph")
+    dq, dk, dv, de = torch.empty_like(q, memory_format=torch.contiguous_format), torch.empty((csc.n_src, D), dtype=q.dtype, device=q.device), \
+        torch.empty((csc.n_src, D), dtype=q.dtype, device=q.device), torch.empty((M, D), dtype=q.dtype, device=q.device)
+    ws = torch.empty((2, M, num_heads), dtype=torch.float32, device=q.device)
+    (qp, ldq), (kp, ldk), (vp, ldv), (ep, lde) = _rows(q, "q"), _rows(k, "k", q.dtype), _rows(v, "v", q.dtype), _rows(e, "e", q.dtype)
+    (op, ldo), (gp, ldg) = _rows(out, "out", q.dtype), _rows(d_out, "d_out", q.dtype)
+    i32 = lambda t: t if t.dtype == torch.int32 and t.is_contiguous() else t.to(torch.int32).contiguous()  # noqa: E731
+    rowptr, edge_ids, edge_dst = i32(rowptr), i32(edge_ids), i32(edge_dst)
+    rc = _lib.load().anemoi_gt_attention_bwd(
+        qp, ldq, kp, ldk, vp, ldv, ep, lde, op, ldo, lse.contiguous().data_ptr(), gp, ldg, csc.row.data_ptr(), csc.colptr.data_ptr(),
+        rowptr.data_ptr(), edge_ids.data_ptr(), edge_dst.data_ptr(), dq.data_ptr(), D, dk.data_ptr(), D, dv.data_ptr(), D,
+        de.data_ptr(), D, ws[0].data_ptr(), ws[1].data_ptr(), csc.n_dst, csc.n_src, M, num_heads, D // num_heads, _dt(q), _stream())
+    _lib.check(rc, "gt_attention_bwd")
+    return dq, dk, dv, de
+
+
 def edge_feature_pad(fe: int) -> int:
     return 4 * ((fe + 1 + 3) // 4)
 
@@ -305,6 +346,42 @@ def _graph_transformer_attention_fake(q, k, v, e, row, colptr, rowptr, edge_ids,
     return (torch.empty((N_dst, H, Cc), device=q.device, dtype=q.dtype),
             torch.empty((N_dst, H, Cc), device=q.device, dtype=torch.float32),
             torch.empty((N_dst, H), device=q.device, dtype=torch.float32))
+
+
+@torch.library.custom_op("anemoi_amd::graph_transformer_attention_backward", mutates_args=(), device_types="cuda")
+def graph_transformer_attention_backward(d_out: Tensor, q: Tensor, k: Tensor, v: Tensor, e: Tensor, out_saved: Tensor, m: Tensor,
+                                         row: Tensor, colptr: Tensor, rowptr: Tensor, edge_ids: Tensor,
+                                         edge_dst: Tensor) -> tuple[Tensor, Tensor, Tensor, Tensor]:
+    """Same signature as the reference's ``anemoi::graph_transformer_attention_backward`` (triton/gt.py:447-492):
+    returns (dQ, dK, dV, dE) shaped like q, k, v, e."""
+    N_dst, H, Cc = q.shape
+    flat = lambda t: t.contiguous().view(t.shape[0], H * Cc)  # noqa: E731
+    csc = CSC(row=row.to(torch.int32).contiguous(), dst=edge_dst.to(torch.int32).contiguous(),
+              colptr=colptr.to(torch.int32).contiguous(), n_src=k.shape[0], n_dst=N_dst)
+    dq, dk, dv, de = gt_attention_backward(flat(d_out).to(q.dtype), flat(q), flat(k), flat(v), flat(e), flat(out_saved).to(q.dtype), m, csc,
+                                           (rowptr, edge_ids, edge_dst), H)
+    return dq.view_as(q), dk.view_as(k), dv.view_as(v), de.view_as(e)
+
+
+@graph_transformer_attention_backward.register_fake
+def _graph_transformer_attention_backward_fake(d_out, q, k, v, e, out_saved, m, row, colptr, rowptr, edge_ids, edge_dst):
+    return torch.empty_like(q), torch.empty_like(k), torch.empty_like(v), torch.empty_like(e)
+
+
+def _gta_setup_context(ctx, inputs, output):
+    q, k, v, e, row, colptr, rowptr, edge_ids, edge_dst = inputs
+    _out, out_saved, m = output
+    ctx.save_for_backward(q, k, v, e, out_saved, m, row, colptr, rowptr, edge_ids, edge_dst)
+
+
+def _gta_backward(ctx, d_out, _d_out_saved, _d_m):
+    # only the gradient of the user-facing ``out`` is used (triton/gt.py:526-538)
+    q, k, v, e, out_saved, m, row, colptr, rowptr, edge_ids, edge_dst = ctx.saved_tensors
+    dq, dk, dv, de = graph_transformer_attention_backward(d_out, q, k, v, e, out_saved, m, row, colptr, rowptr, edge_ids, edge_dst)
+    return dq, dk, dv, de, None, None, None, None, None
+
+
+graph_transformer_attention.register_autograd(_gta_backward, setup_context=_gta_setup_context)
 
 
 def graph_transformer_attention_conv(query: Tensor, key: Tensor, value: Tensor, edges: Tensor, csc: tuple[Tensor, Tensor],

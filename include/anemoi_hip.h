@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ANEMOI_HIP_ABI_VERSION 1
+#define ANEMOI_HIP_ABI_VERSION 2
 
 typedef enum { ANEMOI_F32 = 0, ANEMOI_BF16 = 1, ANEMOI_F16 = 2 } anemoi_dtype_t;
 typedef enum { ANEMOI_ACT_NONE = 0, ANEMOI_ACT_GELU = 1 } anemoi_act_t;
@@ -53,6 +53,23 @@ int anemoi_gt_attention_fwd(const void* q, int64_t ldq, const void* k, int64_t l
                             const void* e, int64_t lde, const int32_t* row, const int32_t* colptr,
                             const void* addend, int64_t ldadd, void* out, int64_t ldo, float* lse,
                             int32_t n_dst, int32_t n_src, int32_t H, int32_t C, anemoi_dtype_t dtype, void* stream);
+
+/* Backward of the op above (materialised E).
+ * Replaces: anemoi::graph_transformer_attention_backward = _gt_bwd_dst_pass + _gt_bwd_src_pass (triton/gt.py:182-376,
+ * 447-492) and its autograd registration (triton/gt.py:526-556).
+ *   out, lse: the forward's results; d_out: gradient of out [n_dst, H*C];
+ *   row/colptr: CSC as in the forward; rowptr[n_src+1], edge_ids[M] (CSC edge ids grouped by source), edge_dst[M]
+ *   (destination of every CSC edge): the reverse CSR of the same graph (triton/utils.py:25-70);
+ *   dq [n_dst, H*C], dk, dv [n_src, H*C], de [M, H*C] (CSC order): outputs, every row written (zeros where a node has no
+ *   edges);  p_ws, ds_ws: fp32 workspace [M, H] each (per-edge softmax weight and score gradient, handed from the
+ *   destination pass to the source pass).  Deterministic: no atomics. */
+int anemoi_gt_attention_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                            const void* e, int64_t lde, const void* out, int64_t ldo, const float* lse,
+                            const void* d_out, int64_t lddo, const int32_t* row, const int32_t* colptr,
+                            const int32_t* rowptr, const int32_t* edge_ids, const int32_t* edge_dst,
+                            void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, void* de, int64_t ldde,
+                            float* p_ws, float* ds_ws, int32_t n_dst, int32_t n_src, int32_t n_edges, int32_t H, int32_t C,
+                            anemoi_dtype_t dtype, void* stream);
 
 /* Same op with ``lin_edge`` fused: E[e] = edge_attr[e] @ w_edge^T + b_edge is never materialised.
  * Replaces: lin_edge(...) + the op above (layers/block.py:623-635 + triton/gt.py:81-179).
