@@ -27,6 +27,10 @@ SIGNATURES = {
     "anemoi_gt_attention_fused_edge_fwd": ([_p, _i64, _p, _i64, _p, _i64, _p, _i32, _p, _p, _p, _p, _i64, _p, _i64, _p, _i32, _i32, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_pack_edge_weights": ([_p, _p, _p, _i32, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_pack_edge_features": ([_p, _i64, _p, _i32, _i32, _i32, C.c_int, _p], C.c_int),
+    "anemoi_reduce_workspace_bytes": ([_i32], _i64),
+    "anemoi_layernorm_bwd": ([_p, _i64, _p, _p, _i64, _p, _i64, _p, _p, _p, _i32, _i32, _f, C.c_int, _p], C.c_int),
+    "anemoi_colsum": ([_p, _i64, _p, _p, _i32, _i32, C.c_int, _p], C.c_int),
+    "anemoi_gelu_bwd": ([_p, _i64, _p, _i64, _p, _i64, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_layernorm_fwd": ([_p, _i64, _p, _p, _p, _i64, _p, _i64, _i32, _i32, _f, C.c_int, _p], C.c_int),
     "anemoi_linear_fwd": ([_p, _i64, _i32, _p, _i64, _i32, _p, _i64, _p, _p, _i64, _p, _p, _i64, _p, _p, _i64, _p, _i64, _i32, _i32, C.c_int, C.c_int, _p], C.c_int),
     "anemoi_edge_ln_residual_segment_sum_fwd": ([_p, _i64, _p, _i64, _p, _p, _f, _p, _p, _i64, _p, _i64, _i32, _i32, C.c_int, _p], C.c_int),

@@ -1,0 +1,272 @@
+// Backward of the row-wise ops (scope row f1): LayerNorm, GELU, bias (column sums).  Same lane layout as rowwise.hip:
+// one wave64 per row, a lane owns VEC contiguous elements per 64*VEC chunk.
+//
+// Reference semantics: autograd of torch.nn.LayerNorm / torch.nn.GELU (exact erf form) / the bias of torch.nn.Linear as
+// the reference's layer_kernels instantiate them (models/src/anemoi/models/layers/utils.py:107-121).
+//   x^ = (x - mean) rstd;  g = dy * gamma;  dx = rstd (g - mean(g) - x^ mean(g x^));  dgamma = sum_rows dy x^;  dbeta = sum_rows dy
+// Column sums are deterministic: a persistent grid of kPartialWaves waves walks the rows, each wave keeps its partial
+// column sums in registers and writes them once to an fp32 workspace [kPartialWaves][2][D]; a second tiny kernel adds the
+// partials in a fixed order (no atomics).
+#include "common.h"
+
+namespace anemoi {
+namespace {
+
+constexpr int kWaves = 4;             // waves per block
+constexpr int kPartialBlocks = 256;   // persistent grid: one block per CU
+constexpr int kPartialWaves = kPartialBlocks * kWaves;
+constexpr int kMaxChunks = 8;
+
+template <typename T, int VEC, int CH>
+__device__ __forceinline__ void load_row(const T* __restrict__ p, int D, int lane, float (&r)[CH][VEC]) {
+#pragma unroll
+  for (int t = 0; t < CH; ++t) {
+    const int c = (t * 64 + lane) * VEC;
+    if (c < D) {
+      load_vec<T, VEC>(p + c, r[t]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) r[t][j] = 0.f;
+    }
+  }
+}
+
+// MODE 0: LayerNorm backward (dx + partial dgamma/dbeta).  MODE 1: column sums of x only (bias gradient).
+template <typename T, int VEC, int CH, int MODE>
+__global__ __launch_bounds__(64 * kWaves) void rowwise_bwd_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ gamma,
+                                                                  const T* __restrict__ dy, int64_t lddy, T* __restrict__ dx,
+                                                                  int64_t lddx, float* __restrict__ part, int n_rows, int D,
+                                                                  float eps) {
+  const int lane = threadIdx.x & 63;
+  const int w = blockIdx.x * kWaves + (threadIdx.x >> 6);
+  const int nw = gridDim.x * kWaves;
+  float sg[CH][VEC], sb[CH][VEC], g[CH][VEC];
+#pragma unroll
+  for (int t = 0; t < CH; ++t)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) sg[t][j] = sb[t][j] = g[t][j] = 0.f;
+  if constexpr (MODE == 0) load_row<T, VEC, CH>(gamma, D, lane, g);
+  const float inv_d = 1.0f / (float)D;
+  for (int r = w; r < n_rows; r += nw) {
+    float xv[CH][VEC];
+    load_row<T, VEC, CH>(x + (int64_t)r * ldx, D, lane, xv);
+    if constexpr (MODE == 1) {
+#pragma unroll
+      for (int t = 0; t < CH; ++t)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) sb[t][j] += xv[t][j];
+    } else {
+      float gv[CH][VEC];
+      load_row<T, VEC, CH>(dy + (int64_t)r * lddy, D, lane, gv);
+      float s = 0.f;
+#pragma unroll
+      for (int t = 0; t < CH; ++t)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) s += xv[t][j];
+      const float mean = wave_sum(s) * inv_d;
+      float ss = 0.f;
+#pragma unroll
+      for (int t = 0; t < CH; ++t) {
+        const int c = (t * 64 + lane) * VEC;
+        if (c < D) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            xv[t][j] -= mean;
+            ss = fmaf(xv[t][j], xv[t][j], ss);
+          }
+        }
+      }
+      const float rstd = rsqrtf(wave_sum(ss) * inv_d + eps);
+      float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+      for (int t = 0; t < CH; ++t)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          xv[t][j] *= rstd;  // x^ (0 outside the row)
+          sb[t][j] += gv[t][j];
+          sg[t][j] = fmaf(gv[t][j], xv[t][j], sg[t][j]);
+          gv[t][j] *= g[t][j];  // g = dy * gamma
+          c1 += gv[t][j];
+          c2 = fmaf(gv[t][j], xv[t][j], c2);
+        }
+      c1 = wave_sum(c1) * inv_d;
+      c2 = wave_sum(c2) * inv_d;
+#pragma unroll
+      for (int t = 0; t < CH; ++t) {
+        const int c = (t * 64 + lane) * VEC;
+        if (c < D) {
+          float o[VEC];
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) o[j] = rstd * (gv[t][j] - c1 - xv[t][j] * c2);
+          store_vec<T, VEC>(dx + (int64_t)r * lddx + c, o);
+        }
+      }
+    }
+  }
+  if (part != nullptr) {
+    float* p = part + (int64_t)w * 2 * D;
+#pragma unroll
+    for (int t = 0; t < CH; ++t) {
+      const int c = (t * 64 + lane) * VEC;
+      if (c < D) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          p[c + j] = sg[t][j];
+          p[D + c + j] = sb[t][j];
+        }
+      }
+    }
+  }
+}
+
+// out[0][c] = sum_w part[w][0][c], out[1][c] = sum_w part[w][1][c]; fixed order
+__global__ void reduce_partials_kernel(const float* __restrict__ part, int nw, int D, float* __restrict__ out0, float* __restrict__ out1) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= 2 * D) return;
+  float s = 0.f;
+  for (int w = 0; w < nw; ++w) s += part[(int64_t)w * 2 * D + c];
+  if (c < D) {
+    if (out0) out0[c] = s;
+  } else if (out1) {
+    out1[c - D] = s;
+  }
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ pre, int64_t ldp, const T* __restrict__ dy, int64_t lddy,
+                                                       T* __restrict__ dpre, int64_t lddp, int n_rows, int D) {
+  const int per_row = D / VEC;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)n_rows * per_row) return;
+  const int r = (int)(i / per_row), c = (int)(i % per_row) * VEC;
+  float x[VEC], g[VEC], o[VEC];
+  load_vec<T, VEC>(pre + (int64_t)r * ldp + c, x);
+  load_vec<T, VEC>(dy + (int64_t)r * lddy + c, g);
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    const float cdf = 0.5f * (1.0f + fast_erf(x[j] * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x[j] * x[j]);
+    o[j] = g[j] * fmaf(x[j], pdf, cdf);  // d/dx [x Phi(x)] = Phi(x) + x phi(x)
+  }
+  store_vec<T, VEC>(dpre + (int64_t)r * lddp + c, o);
+}
+
+template <typename T>
+int pick_vec(int D, std::initializer_list<int64_t> lds, std::initializer_list<const void*> ptrs) {
+  int vec = 16 / (int)sizeof(T);
+  auto ok = [&](int v) {
+    if (D % v) return false;
+    for (int64_t ld : lds)
+      if (ld % v) return false;
+    for (const void* p : ptrs)
+      if (p && (reinterpret_cast<uintptr_t>(p) % (v * sizeof(T)))) return false;
+    return true;
+  };
+  while (vec > 1 && !ok(vec)) vec >>= 1;
+  return vec;
+}
+
+int pick_chunks(int D, int vec) {
+  for (int ch = 1; ch <= kMaxChunks; ch *= 2)
+    if (D <= 64 * vec * ch) return ch;
+  return 0;
+}
+
+#define ALL_VEC_CH(M) \
+  M(1, 1) M(1, 2) M(1, 4) M(1, 8) M(2, 1) M(2, 2) M(2, 4) M(2, 8) M(4, 1) M(4, 2) M(4, 4) M(4, 8) M(8, 1) M(8, 2) M(8, 4) M(8, 8)
+
+template <typename T, int MODE>
+int launch_rowwise_bwd(const void* x, int64_t ldx, const void* gamma, const void* dy, int64_t lddy, void* dx, int64_t lddx,
+                       float* out0, float* out1, float* ws, int n_rows, int D, float eps, hipStream_t st) {
+  const int vec = MODE == 0 ? pick_vec<T>(D, {ldx, lddy, lddx}, {x, dy, dx, gamma}) : pick_vec<T>(D, {ldx}, {x});
+  const int ch = pick_chunks(D, vec);
+  ANEMOI_REQUIRE(ch > 0, "rowwise backward: D=%d too large for the register-resident row", D);
+  int blocks = (n_rows + kWaves - 1) / kWaves;
+  blocks = blocks < kPartialBlocks ? blocks : kPartialBlocks;
+  const bool want_sums = out0 != nullptr || out1 != nullptr;
+  if (n_rows == 0) {  // no rows: the sums are zero
+    if (!want_sums) return ANEMOI_OK;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, st, ws, 0, D, out0, out1);
+    return check_launch("reduce_partials_kernel");
+  }
+#define RB_CASE(V, C)                                                                                                          \
+  case V * 16 + C:                                                                                                             \
+    hipLaunchKernelGGL((rowwise_bwd_kernel<T, V, C, MODE>), dim3(blocks), dim3(64 * kWaves), 0, st, (const T*)x, ldx,          \
+                       (const T*)gamma, (const T*)dy, lddy, (T*)dx, lddx, want_sums ? ws : nullptr, n_rows, D, eps);           \
+    break;
+  switch (vec * 16 + ch) {
+    ALL_VEC_CH(RB_CASE)
+    default: set_error("rowwise backward: bad vector width"); return ANEMOI_E_INVALID;
+  }
+#undef RB_CASE
+  int rc = check_launch("rowwise_bwd_kernel");
+  if (rc != ANEMOI_OK || !want_sums) return rc;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, st, ws, blocks * kWaves, D, out0, out1);
+  return check_launch("reduce_partials_kernel");
+}
+
+template <typename T>
+int launch_gelu_bwd(const void* pre, int64_t ldp, const void* dy, int64_t lddy, void* dpre, int64_t lddp, int n_rows, int D, hipStream_t st) {
+  const int vec = pick_vec<T>(D, {ldp, lddy, lddp}, {pre, dy, dpre});
+  const int64_t n = (int64_t)n_rows * (D / vec);
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+#define GB_CASE(V)                                                                                                          \
+  case V:                                                                                                                   \
+    hipLaunchKernelGGL((gelu_bwd_kernel<T, V>), grid, block, 0, st, (const T*)pre, ldp, (const T*)dy, lddy, (T*)dpre, lddp, n_rows, D); \
+    break;
+  switch (vec) {
+    GB_CASE(1) GB_CASE(2) GB_CASE(4) GB_CASE(8)
+    default: set_error("gelu_bwd: bad vector width"); return ANEMOI_E_INVALID;
+  }
+#undef GB_CASE
+  return check_launch("gelu_bwd_kernel");
+}
+
+}  // namespace
+}  // namespace anemoi
+
+using namespace anemoi;
+
+extern "C" int64_t anemoi_reduce_workspace_bytes(int32_t D) { return (int64_t)kPartialWaves * 2 * (D > 0 ? D : 0) * (int64_t)sizeof(float); }
+
+extern "C" int anemoi_layernorm_bwd(const void* x, int64_t ldx, const void* gamma, const void* d_y, int64_t lddy, void* d_x,
+                                    int64_t lddx, float* d_gamma, float* d_beta, float* workspace, int32_t n_rows, int32_t D,
+                                    float eps, anemoi_dtype_t dtype, void* stream) {
+  ANEMOI_REQUIRE(n_rows >= 0 && D > 0 && ldx >= D && lddy >= D && lddx >= D, "layernorm_bwd: bad sizes n_rows=%d D=%d", n_rows, D);
+  ANEMOI_REQUIRE(x && gamma && d_y && d_x, "layernorm_bwd: null pointer");
+  ANEMOI_REQUIRE(workspace || (!d_gamma && !d_beta), "layernorm_bwd: d_gamma/d_beta need the workspace (anemoi_reduce_workspace_bytes)");
+  hipStream_t st = as_stream(stream);
+  switch (dtype) {
+    case ANEMOI_F32: return launch_rowwise_bwd<float, 0>(x, ldx, gamma, d_y, lddy, d_x, lddx, d_gamma, d_beta, workspace, n_rows, D, eps, st);
+    case ANEMOI_BF16: return launch_rowwise_bwd<bf16_t, 0>(x, ldx, gamma, d_y, lddy, d_x, lddx, d_gamma, d_beta, workspace, n_rows, D, eps, st);
+    case ANEMOI_F16: return launch_rowwise_bwd<f16_t, 0>(x, ldx, gamma, d_y, lddy, d_x, lddx, d_gamma, d_beta, workspace, n_rows, D, eps, st);
+    default: set_error("unknown dtype"); return ANEMOI_E_INVALID;
+  }
+}
+
+extern "C" int anemoi_colsum(const void* x, int64_t ldx, float* out, float* workspace, int32_t n_rows, int32_t D,
+                             anemoi_dtype_t dtype, void* stream) {
+  ANEMOI_REQUIRE(n_rows >= 0 && D > 0 && ldx >= D, "colsum: bad sizes n_rows=%d D=%d", n_rows, D);
+  ANEMOI_REQUIRE(x && out && workspace, "colsum: null pointer");
+  hipStream_t st = as_stream(stream);
+  switch (dtype) {
+    case ANEMOI_F32: return launch_rowwise_bwd<float, 1>(x, ldx, nullptr, nullptr, 0, nullptr, 0, nullptr, out, workspace, n_rows, D, 0.f, st);
+    case ANEMOI_BF16: return launch_rowwise_bwd<bf16_t, 1>(x, ldx, nullptr, nullptr, 0, nullptr, 0, nullptr, out, workspace, n_rows, D, 0.f, st);
+    case ANEMOI_F16: return launch_rowwise_bwd<f16_t, 1>(x, ldx, nullptr, nullptr, 0, nullptr, 0, nullptr, out, workspace, n_rows, D, 0.f, st);
+    default: set_error("unknown dtype"); return ANEMOI_E_INVALID;
+  }
+}
+
+extern "C" int anemoi_gelu_bwd(const void* pre, int64_t ldp, const void* d_y, int64_t lddy, void* d_pre, int64_t lddp,
+                               int32_t n_rows, int32_t D, anemoi_dtype_t dtype, void* stream) {
+  ANEMOI_REQUIRE(n_rows >= 0 && D > 0 && ldp >= D && lddy >= D && lddp >= D, "gelu_bwd: bad sizes");
+  if (n_rows == 0) return ANEMOI_OK;
+  ANEMOI_REQUIRE(pre && d_y && d_pre, "gelu_bwd: null pointer");
+  hipStream_t st = as_stream(stream);
+  switch (dtype) {
+    case ANEMOI_F32: return launch_gelu_bwd<float>(pre, ldp, d_y, lddy, d_pre, lddp, n_rows, D, st);
+    case ANEMOI_BF16: return launch_gelu_bwd<bf16_t>(pre, ldp, d_y, lddy, d_pre, lddp, n_rows, D, st);
+    case ANEMOI_F16: return launch_gelu_bwd<f16_t>(pre, ldp, d_y, lddy, d_pre, lddp, n_rows, D, st);
+    default: set_error("unknown dtype"); return ANEMOI_E_INVALID;
+  }
+}

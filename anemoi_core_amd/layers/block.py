@@ -21,7 +21,7 @@ from ..distributed.halo import HaloInfo, build_halo_info
 from ..distributed.partition import build_graph_partition_from_shard_info
 from ..distributed.shapes import BipartiteGraphShardInfo, GraphShardInfo, comm_rank, comm_size, model_is_distributed
 from .conv import GraphConv
-from .graphcache import get_csc, get_edge_features
+from .graphcache import get_csc, get_edge_features, get_reverse_csr
 from .kernels import check_inference
 from .mlp import MLP
 from .utils import compute_mlp_hidden_dim
@@ -39,6 +39,9 @@ class _FusedWeights:
     def get(self, tag: str, linears: list) -> tuple[Tensor, Tensor]:
         ps = [p for lin in linears for p in (lin.weight, lin.bias) if p is not None]
         sig = tuple((p.data_ptr(), version(p), p.dtype, str(p.device)) for p in ps)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in ps):  # training: gradients flow through the cat
+            return (torch.cat([lin.weight for lin in linears], dim=0),
+                    torch.cat([lin.bias if lin.bias is not None else lin.weight.new_zeros(lin.out_features) for lin in linears]))
         hit = self._cache.get(tag)
         if hit is not None and hit[0] == sig:
             return hit[1], hit[2]
@@ -115,6 +118,18 @@ class GraphTransformerBaseBlock(BaseBlock):
         if self.qk_norm:  # per-head LayerNorm over C, no bias (block.py:655-660)
             query = self.q_norm(query.reshape(-1, H, C)).view(-1, H * C)
             key = self.k_norm(key.reshape(-1, H, C)).view(-1, H * C)
+        if ops._needs_grad(query, key, value, x_r, edge_attr, self.lin_edge.weight):
+            # training (scope row f1): E = lin_edge(edge_pre_mlp(edge_attr)) is materialised, as in the reference
+            # (block.py:623-635), and the attention runs through the op mirror, whose backward is registered
+            from ..autograd import attention
+
+            ea = edge_attr if csc.perm is None else edge_attr.index_select(0, csc.perm)
+            ea = ea.to(self.lin_edge.weight.dtype)
+            if not isinstance(self.edge_pre_mlp, nn.Identity):
+                lin = self.edge_pre_mlp[0]
+                ea = ops.linear(ea, lin.weight, lin.bias, act="gelu")
+            e = ops.linear(ea, self.lin_edge.weight, self.lin_edge.bias)
+            return attention(query, key, value, e, csc, H, get_reverse_csr(csc)) + x_r
         if isinstance(self.edge_pre_mlp, nn.Identity):
             feat = get_edge_features(edge_attr, csc.perm)
         else:
@@ -168,7 +183,6 @@ class GraphTransformerMapperBlock(GraphTransformerBaseBlock):
         if self.shard_strategy == "heads" and model_is_distributed(model_comm_group):
             raise NotImplementedError("shard_strategy='heads' (Ulysses all-to-all) is scope row f2 (next); use 'edges'")
         x_src, x_dst = x
-        check_inference(x_src, x_dst, edge_attr)
         size = (size, size) if isinstance(size, int) else tuple(size)
         csc = get_csc(edge_index, size, edges_are_dst_sorted)
         A = self.attn_channels
@@ -228,7 +242,6 @@ class GraphTransformerProcessorBlock(GraphTransformerBaseBlock):
                 size, model_comm_group=None, cond=None, edges_are_dst_sorted: bool = True, halo_cache: Optional[dict] = None,
                 **kwargs):
         self._unsupported_cond(cond)
-        check_inference(x, edge_attr)
         A = self.attn_channels
         ln = self.layer_norm_attention
         xn = ops.layer_norm(x, ln.weight, ln.bias, ln.eps)

@@ -26,7 +26,6 @@ class GraphTransformerConv(nn.Module):
 
     def forward(self, query: Tensor, key: Tensor, value: Tensor, edge_attr: Optional[Tensor], edge_index: Tensor,
                 size=None, edges_are_dst_sorted: bool = False) -> Tensor:
-        check_inference(query, key, value, edge_attr)
         n_dst, H, C = query.shape
         size = (key.shape[0], n_dst) if size is None else size
         csc = get_csc(edge_index, size, edges_are_dst_sorted)

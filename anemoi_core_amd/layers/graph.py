@@ -22,6 +22,8 @@ class TrainableTensor(nn.Module):
         """cat[x repeated B times, trainable repeated B times] along features; cached while the inputs are unchanged
         (the result is a pure function of static buffers and parameters)."""
         t = self.trainable
+        if t is not None and t.requires_grad and torch.is_grad_enabled():  # training: differentiable, never cached
+            return torch.cat([x.repeat(batch_size, 1), t.to(device=x.device, dtype=x.dtype).repeat(batch_size, 1)], dim=-1)
         key = (x.data_ptr(), version(x), x.dtype, str(x.device), batch_size, None if t is None else (t.data_ptr(), version(t), t.dtype))
         if self._cache is not None and self._cache[0] == key:
             return self._cache[1]

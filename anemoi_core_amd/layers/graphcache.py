@@ -56,6 +56,15 @@ def get_edge_features(edge_attr: Tensor, perm: Optional[Tensor] = None) -> Tenso
     return _feat_cache.get(_key(edge_attr, None if perm is None else perm.data_ptr()), edge_attr, build)
 
 
+_rev_cache = _LRU()
+
+
+def get_reverse_csr(csc: ops.CSC):
+    """(rowptr, edge_ids, edge_dst) of a cached CSC, for the attention backward (built once per static graph)."""
+    return _rev_cache.get(_key(csc.row, csc.colptr.data_ptr(), csc.n_src, csc.n_dst), csc, lambda: ops.build_reverse_csr(csc))
+
+
 def clear() -> None:
     _csc_cache.data.clear()
     _feat_cache.data.clear()
+    _rev_cache.data.clear()

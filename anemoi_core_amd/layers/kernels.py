@@ -15,11 +15,12 @@ from ..utils.tensors import version
 
 
 def check_inference(*tensors: Tensor) -> None:
-    """Forward-only for now: the backward kernels are SURVEY.md §8 row f1 ("next")."""
+    """GraphConv (GNN) family: forward only for now.  The GraphTransformer family, Linear, LayerNorm and MLP are
+    differentiable (scope row f1: ops.linear / ops.layer_norm / the attention op carry HIP backward kernels)."""
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
         raise NotImplementedError(
-            "anemoi_core_amd implements the forward pass only (backward kernels are the next scope row); "
-            "run under torch.no_grad() / torch.inference_mode()."
+            "the GraphConv (GNN) blocks of anemoi_core_amd implement the forward pass only (their backward is scope row f1, "
+            "next); run under torch.no_grad() / torch.inference_mode(), or use the GraphTransformer family."
         )
 
 
@@ -27,7 +28,6 @@ class Linear(nn.Linear):
     """torch.nn.Linear parameters, MFMA forward (bias fused)."""
 
     def forward(self, x: Tensor) -> Tensor:  # noqa: D102
-        check_inference(x, self.weight)
         y = ops.linear(x.reshape(-1, x.shape[-1]), self.weight, self.bias)
         return y.view(*x.shape[:-1], self.out_features)
 
@@ -41,7 +41,6 @@ class LayerNorm(nn.LayerNorm):
             raise NotImplementedError("only affine LayerNorm over the last dimension is supported")
 
     def forward(self, x: Tensor, residual: Tensor | None = None) -> Tensor:  # noqa: D102
-        check_inference(x, self.weight)
         return ops.layer_norm(x, self.weight, self.bias, self.eps, residual)
 
 
@@ -71,6 +70,8 @@ class PaddedLinear:
         pad = (-K) % 8
         if pad == 0 or x.dtype == torch.float32:
             return ops.linear(x, lin.weight, lin.bias, **kw)
+        if torch.is_grad_enabled() and lin.weight.requires_grad:  # training: gradients flow through the padding
+            return ops.linear(torch.nn.functional.pad(x, (0, pad)), torch.nn.functional.pad(lin.weight, (0, pad)), lin.bias, **kw)
         sig = (lin.weight.data_ptr(), version(lin.weight), lin.weight.dtype, str(lin.weight.device))
         if self._sig != sig:
             with torch.no_grad():

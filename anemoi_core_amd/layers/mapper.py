@@ -121,7 +121,6 @@ class GraphTransformerBaseMapper(BaseMapper):
         if self.shard_strategy == "heads" and model_is_distributed(model_comm_group):
             raise NotImplementedError("shard_strategy='heads' (Ulysses all-to-all) is scope row f2 (next); use 'edges'")
         x_src, x_dst = x
-        check_inference(x_src, x_dst, edge_attr)
         edge_attr, edge_index = ensure_edges_are_dst_sorted(
             edge_attr, edge_index, edges_are_sharded=shard_info.edges_are_sharded(), model_comm_group=model_comm_group,
             edges_are_dst_sorted=edges_are_dst_sorted)

@@ -7,7 +7,7 @@ from typing import Optional
 from torch import Tensor, nn
 
 from .. import ops
-from .kernels import GELU, check_inference
+from .kernels import GELU
 
 
 class MLP(nn.Module):
@@ -38,7 +38,6 @@ class MLP(nn.Module):
         ``x2``: second K-slab of the first layer (cat never materialised); ``residual`` is fused into the last kernel
         (LayerNorm if present, else last Linear); ``skip_first``: the caller already applied layer 0 (+GELU) — used by
         GraphConv, whose first edge layer is a gather-add GEMM; ``skip_layer_norm``: caller fuses the LayerNorm."""
-        check_inference(x)
         mods = list(self.mlp)
         lin_idx = [i for i, m in enumerate(mods) if isinstance(m, nn.Linear)]
         h = x.reshape(-1, x.shape[-1])

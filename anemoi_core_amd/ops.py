@@ -241,8 +241,22 @@ def gt_attention_fused_edge(q: Tensor, k: Tensor, v: Tensor, edge_feat: Tensor, 
     return (out, lse) if return_lse else out
 
 
+def _needs_grad(*tensors) -> bool:
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
 def layer_norm(x: Tensor, weight: Tensor, bias: Optional[Tensor], eps: float = 1e-5, residual: Optional[Tensor] = None) -> Tensor:
-    """LayerNorm over the last dim of a [..., D] tensor (fp32 statistics), optionally + residual (same shape)."""
+    """LayerNorm over the last dim of a [..., D] tensor (fp32 statistics), optionally + residual (same shape).
+    Differentiable: with autograd recording it runs as ``autograd.LayerNormFunction`` (HIP backward kernel)."""
+    if _needs_grad(x, weight, bias, residual):
+        from .autograd import LayerNormFunction
+
+        y = LayerNormFunction.apply(x, weight, bias, float(eps))
+        return y if residual is None else y + residual
+    return _layer_norm_fwd(x, weight, bias, eps, residual)
+
+
+def _layer_norm_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], eps: float = 1e-5, residual: Optional[Tensor] = None) -> Tensor:
     _dev(x, weight, bias, residual)
     D = x.shape[-1]
     x2 = x.reshape(-1, D)
@@ -263,7 +277,23 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, *, act: Opt
            residual: Optional[Tensor] = None, x2: Optional[Tensor] = None, g1: Optional[Tensor] = None,
            idx1: Optional[Tensor] = None, g2: Optional[Tensor] = None, idx2: Optional[Tensor] = None,
            out: Optional[Tensor] = None) -> Tensor:
-    """y = act([x | x2] @ weight^T + bias + g1[idx1] + g2[idx2]) + residual.  x [N, K1], x2 [N, K2], weight [O, K1+K2]."""
+    """y = act([x | x2] @ weight^T + bias + g1[idx1] + g2[idx2]) + residual.  x [N, K1], x2 [N, K2], weight [O, K1+K2].
+    Differentiable (without the gather-add terms): with autograd recording it runs as ``autograd.LinearFunction``."""
+    if _needs_grad(x, weight, bias, residual, x2, g1, g2):
+        if g1 is not None or g2 is not None or out is not None:
+            raise NotImplementedError("backward of the gather-add GEMM epilogue (GraphConv training) is scope row f1 (next)")
+        from .autograd import LinearFunction
+
+        if x2 is not None:
+            x = torch.cat([x, x2.to(x.dtype)], dim=1)
+        return LinearFunction.apply(x, weight, bias, act, residual)
+    return _linear_fwd(x, weight, bias, act=act, residual=residual, x2=x2, g1=g1, idx1=idx1, g2=g2, idx2=idx2, out=out)
+
+
+def _linear_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, *, act: Optional[str] = None,
+                residual: Optional[Tensor] = None, x2: Optional[Tensor] = None, g1: Optional[Tensor] = None,
+                idx1: Optional[Tensor] = None, g2: Optional[Tensor] = None, idx2: Optional[Tensor] = None,
+                out: Optional[Tensor] = None) -> Tensor:
     _dev(x, weight, bias, residual, x2, g1, idx1, g2, idx2, out)
     N, K1 = x.shape
     K2 = 0 if x2 is None else x2.shape[1]
@@ -292,6 +322,56 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, *, act: Opt
                                        _lib.ACT_GELU if act == "gelu" else _lib.ACT_NONE, _dt(x), _stream())
     _lib.check(rc, "linear_fwd")
     return y
+
+
+_REDUCE_WS: dict = {}
+
+
+def _reduce_workspace(D: int, device) -> Tensor:
+    """fp32 scratch for the deterministic column sums (per device and width, allocated once)."""
+    key = (str(device), D)
+    ws = _REDUCE_WS.get(key)
+    if ws is None:
+        ws = torch.empty(_lib.load().anemoi_reduce_workspace_bytes(D) // 4, dtype=torch.float32, device=device)
+        _REDUCE_WS[key] = ws
+    return ws
+
+
+def layer_norm_backward(d_y: Tensor, x: Tensor, weight: Tensor, eps: float = 1e-5, need_param_grads: bool = True):
+    """(dx, dgamma fp32 [D], dbeta fp32 [D]) of LayerNorm over the last dim; statistics recomputed from x."""
+    _dev(d_y, x, weight)
+    D = x.shape[-1]
+    x2, g2 = x.reshape(-1, D), d_y.reshape(-1, D)
+    dx = torch.empty((x2.shape[0], D), dtype=x.dtype, device=x.device)
+    dg = torch.empty(D, dtype=torch.float32, device=x.device) if need_param_grads else None
+    db = torch.empty(D, dtype=torch.float32, device=x.device) if need_param_grads else None
+    (xp, ldx), (gp, ldg) = _rows(x2, "x"), _rows(g2, "d_y", x.dtype)
+    rc = _lib.load().anemoi_layernorm_bwd(xp, ldx, _vec(weight, "weight", D, x.dtype), gp, ldg, dx.data_ptr(), D,
+                                          dg.data_ptr() if need_param_grads else 0, db.data_ptr() if need_param_grads else 0,
+                                          _reduce_workspace(D, x.device).data_ptr() if need_param_grads else 0,
+                                          x2.shape[0], D, float(eps), _dt(x), _stream())
+    _lib.check(rc, "layernorm_bwd")
+    return dx.view(x.shape), dg, db
+
+
+def colsum(x: Tensor) -> Tensor:
+    """fp32 column sums of a [N, D] tensor (bias gradient), deterministic."""
+    _dev(x)
+    N, D = x.shape
+    out = torch.empty(D, dtype=torch.float32, device=x.device)
+    p, ld = _rows(x, "x")
+    _lib.check(_lib.load().anemoi_colsum(p, ld, out.data_ptr(), _reduce_workspace(D, x.device).data_ptr(), N, D, _dt(x), _stream()), "colsum")
+    return out
+
+
+def gelu_backward(pre: Tensor, d_y: Tensor) -> Tensor:
+    """d_pre = d_y * gelu'(pre) (exact erf form), [N, D]."""
+    _dev(pre, d_y)
+    N, D = pre.shape
+    out = torch.empty((N, D), dtype=pre.dtype, device=pre.device)
+    (pp, ldp), (gp, ldg) = _rows(pre, "pre"), _rows(d_y, "d_y", pre.dtype)
+    _lib.check(_lib.load().anemoi_gelu_bwd(pp, ldp, gp, ldg, out.data_ptr(), D, N, D, _dt(pre), _stream()), "gelu_bwd")
+    return out
 
 
 def edge_ln_residual_segment_sum(z: Tensor, e_old: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], eps: float,

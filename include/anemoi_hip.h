@@ -99,6 +99,23 @@ int anemoi_layernorm_fwd(const void* x, int64_t ldx, const void* gamma, const vo
                          int64_t ldr, void* y, int64_t ldy, int32_t n_rows, int32_t D, float eps, anemoi_dtype_t dtype,
                          void* stream);
 
+/* LayerNorm backward.  Replaces: autograd of layer_kernels.LayerNorm (layers/utils.py:107-121).
+ *   d_x [n_rows, D] (same dtype), d_gamma / d_beta fp32 [D] (either may be NULL; both NULL: no column sums);
+ *   workspace: anemoi_reduce_workspace_bytes(D) bytes of fp32 scratch (per-wave partial column sums, added in a fixed
+ *   order by a second kernel: deterministic, no atomics).  Statistics are recomputed from x (nothing saved by the forward). */
+int64_t anemoi_reduce_workspace_bytes(int32_t D);
+int anemoi_layernorm_bwd(const void* x, int64_t ldx, const void* gamma, const void* d_y, int64_t lddy, void* d_x,
+                         int64_t lddx, float* d_gamma, float* d_beta, float* workspace, int32_t n_rows, int32_t D,
+                         float eps, anemoi_dtype_t dtype, void* stream);
+
+/* out[c] = sum_r x[r, c] in fp32 (bias gradient of torch.nn.Linear); same workspace and determinism as above. */
+int anemoi_colsum(const void* x, int64_t ldx, float* out, float* workspace, int32_t n_rows, int32_t D,
+                  anemoi_dtype_t dtype, void* stream);
+
+/* d_pre = d_y * gelu'(pre), gelu'(x) = Phi(x) + x phi(x) (exact erf form; autograd of torch.nn.GELU, layers/utils.py:111). */
+int anemoi_gelu_bwd(const void* pre, int64_t ldp, const void* d_y, int64_t lddy, void* d_pre, int64_t lddp,
+                    int32_t n_rows, int32_t D, anemoi_dtype_t dtype, void* stream);
+
 /* Linear layer with fused epilogue.  Replaces torch.nn.Linear (+ GELU + residual add) as used by
  * get_qkve / projection / MLP (layers/block.py:623-635,1268-1271; layers/mlp.py:158-169).
  *   y[n, o] = act( sum_k A[n,k] * w[o,k] + bias[o] + g1[idx1[n], o] + g2[idx2[n], o] ) + residual[n, o]

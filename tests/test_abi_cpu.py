@@ -15,7 +15,7 @@ def header_functions():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     out = {}
-    for m in re.finditer(r"^(?:int|const char\*)\s+(anemoi_\w+)\s*\((.*?)\);", text, flags=re.S | re.M):
+    for m in re.finditer(r"^(?:int|int64_t|const char\*)\s+(anemoi_\w+)\s*\((.*?)\);", text, flags=re.S | re.M):
         args = m.group(2).strip()
         out[m.group(1)] = 0 if args == "void" else len([a for a in args.split(",") if a.strip()])
     return out
