@@ -22,7 +22,7 @@ from ..distributed.partition import build_graph_partition_from_shard_info
 from ..distributed.shapes import BipartiteGraphShardInfo, GraphShardInfo, comm_rank, comm_size, model_is_distributed
 from .conv import GraphConv
 from .graphcache import get_csc, get_edge_features, get_reverse_csr
-from .kernels import check_inference
+from .kernels import PaddedLinear, check_inference
 from .mlp import MLP
 from .utils import compute_mlp_hidden_dim
 from ..utils.tensors import version
@@ -110,6 +110,7 @@ class GraphTransformerBaseBlock(BaseBlock):
             raise ValueError(f"Backend '{graph_attention_backend}' not supported for GraphTransformerBlock")
         self.graph_attention_backend = "hip"
         self._fused = _FusedWeights()
+        self._pad_edge = PaddedLinear()
 
     # -- pieces ---------------------------------------------------------------------------------------------
     def _attention(self, query: Tensor, key: Tensor, value: Tensor, x_r: Tensor, edge_attr: Tensor, csc: ops.CSC) -> Tensor:
@@ -125,10 +126,10 @@ class GraphTransformerBaseBlock(BaseBlock):
 
             ea = edge_attr if csc.perm is None else edge_attr.index_select(0, csc.perm)
             ea = ea.to(self.lin_edge.weight.dtype)
+            # edge_dim (11) is no multiple of 8: zero-pad K so that forward, dX and dW all run on the MFMA kernels
             if not isinstance(self.edge_pre_mlp, nn.Identity):
-                lin = self.edge_pre_mlp[0]
-                ea = ops.linear(ea, lin.weight, lin.bias, act="gelu")
-            e = ops.linear(ea, self.lin_edge.weight, self.lin_edge.bias)
+                ea = self._pad_edge(ea, self.edge_pre_mlp[0], act="gelu")
+            e = self._pad_edge(ea, self.lin_edge)
             return attention(query, key, value, e, csc, H, get_reverse_csr(csc)) + x_r
         if isinstance(self.edge_pre_mlp, nn.Identity):
             feat = get_edge_features(edge_attr, csc.perm)
