@@ -478,23 +478,27 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void linear_mfma_persistent_kernel
   // ---- DMA issue side (runs STAGES-1 K-tiles ahead of the MFMA side, across tile boundaries).  Addresses are a
   // wave-uniform 64-bit base (operand + K offset) plus a per-lane 32-bit byte offset fixed for the tile.
   uint32_t a_voff[kAPW], a2_voff[kAPW], w_voff[kWPW];
+  int64_t x_toff = 0, x2_toff = 0, w_toff = 0;  // byte offset of the tile being issued (wave-uniform, 64-bit)
   auto setup_issue_tile = [&](int j) {
     int m0, n0;
     tile_origin(j, m0, n0);
+    x_toff = (int64_t)m0 * a.ldx * 2;
+    x2_toff = (int64_t)m0 * a.ldx2 * 2;
+    w_toff = (int64_t)n0 * a.ldw * 2;
 #pragma unroll
     for (int i = 0; i < kAPW; ++i) {
       const int row = min(wave * kAPW + i, kAPieces - 1) * 8 + (lane >> 3);
       const int slot = (lane & 7) ^ ((row >> 1) & 7);
       const int m = min(m0 + row, a.n_rows - 1);  // rows past the end are computed but never stored
-      a_voff[i] = (uint32_t)(((int64_t)m * a.ldx + slot * 8) * 2);
-      a2_voff[i] = (uint32_t)(((int64_t)m * a.ldx2 + slot * 8) * 2);
+      a_voff[i] = (uint32_t)(((int64_t)(m - m0) * a.ldx + slot * 8) * 2);  // relative to the tile's first row: fits 32 bits
+      a2_voff[i] = (uint32_t)(((int64_t)(m - m0) * a.ldx2 + slot * 8) * 2);
     }
 #pragma unroll
     for (int i = 0; i < kWPW; ++i) {
       const int row = min(wave * kWPW + i, kWPieces - 1) * 8 + (lane >> 3);
       const int slot = (lane & 7) ^ ((row >> 1) & 7);
       const int n = min(n0 + row, a.O - 1);
-      w_voff[i] = (uint32_t)(((int64_t)n * a.ldw + slot * 8) * 2);
+      w_voff[i] = (uint32_t)(((int64_t)(n - n0) * a.ldw + slot * 8) * 2);
     }
   };
   int ig = 0, ikt = 0, ij = 0;  // next K-tile to issue: global index, index within its tile, tile
@@ -504,8 +508,8 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void linear_mfma_persistent_kernel
     const int k0 = ikt * BK;
     unsigned char* stage = smem + (ig % STAGES) * kStageBytes;
     const bool first = k0 < a.K1;  // uniform
-    const char* abase = first ? xb + (int64_t)k0 * 2 : x2b + (int64_t)(k0 - a.K1) * 2;
-    const char* wbase = wb + (int64_t)k0 * 2;
+    const char* abase = first ? xb + x_toff + (int64_t)k0 * 2 : x2b + x2_toff + (int64_t)(k0 - a.K1) * 2;
+    const char* wbase = wb + w_toff + (int64_t)k0 * 2;
 #pragma unroll
     for (int i = 0; i < kAPW; ++i) {
       const int pc = wave * kAPW + i;
@@ -729,23 +733,27 @@ __global__ __launch_bounds__(512, 1) void linear_mfma_bigtile_kernel(LinArgs a, 
 
   // ---- DMA issue side: K-tile ig (one ahead of the MFMA side), one 1-KiB piece per call
   uint32_t a_voff[kAPW], a2_voff[kAPW], w_voff[kWPW];
+  int64_t x_toff = 0, x2_toff = 0, w_toff = 0;  // byte offset of the tile being issued (wave-uniform, 64-bit)
   auto setup_issue_tile = [&](int j) {
     int m0, n0;
     tile_origin(j, m0, n0);
+    x_toff = (int64_t)m0 * a.ldx * 2;
+    x2_toff = (int64_t)m0 * a.ldx2 * 2;
+    w_toff = (int64_t)n0 * a.ldw * 2;
 #pragma unroll
     for (int i = 0; i < kAPW; ++i) {
       const int row = min(wave * kAPW + i, kAPieces - 1) * 8 + (lane >> 3);
       const int slot = (lane & 7) ^ ((row >> 1) & 7);
       const int m = min(m0 + row, a.n_rows - 1);  // rows past the end are computed but never stored
-      a_voff[i] = (uint32_t)(((int64_t)m * a.ldx + slot * 8) * 2);
-      a2_voff[i] = (uint32_t)(((int64_t)m * a.ldx2 + slot * 8) * 2);
+      a_voff[i] = (uint32_t)(((int64_t)(m - m0) * a.ldx + slot * 8) * 2);  // relative to the tile's first row: fits 32 bits
+      a2_voff[i] = (uint32_t)(((int64_t)(m - m0) * a.ldx2 + slot * 8) * 2);
     }
 #pragma unroll
     for (int i = 0; i < kWPW; ++i) {
       const int row = (wave * kWPW + i) * 8 + (lane >> 3);
       const int slot = (lane & 7) ^ ((row >> 1) & 7);
       const int n = min(n0 + row, a.O - 1);
-      w_voff[i] = (uint32_t)(((int64_t)n * a.ldw + slot * 8) * 2);
+      w_voff[i] = (uint32_t)(((int64_t)(n - n0) * a.ldw + slot * 8) * 2);
     }
   };
   // The pieces of a K-tile are issued one by one between MFMAs, so the issue itself must be branch-free: everything
@@ -763,8 +771,8 @@ __global__ __launch_bounds__(512, 1) void linear_mfma_bigtile_kernel(LinArgs a, 
       if (ikt == 0) setup_issue_tile(ij);
       const int k0 = ikt * BK;
       s_first = k0 < a.K1;
-      abase = s_first ? xb + (int64_t)k0 * 2 : x2b + (int64_t)(k0 - a.K1) * 2;
-      wbase = wb + (int64_t)k0 * 2;
+      abase = s_first ? xb + x_toff + (int64_t)k0 * 2 : x2b + x2_toff + (int64_t)(k0 - a.K1) * 2;
+      wbase = wb + w_toff + (int64_t)k0 * 2;
       sdst = smem_l + (ig % STAGES) * kStageBytes;
     }
   };
@@ -871,10 +879,11 @@ static int launch_generic(const LinArgs& a, hipStream_t st) {
 
 template <typename T>
 static bool ring_eligible(const LinArgs& a) {
-  // K-tiles are whole, and the per-lane 32-bit byte offsets of the DMA addressing cover the operands
+  // K-tiles are whole, and the per-lane 32-bit byte offsets of the DMA addressing (relative to a tile's first row) cover
+  // one tile of each operand (at most 320 rows)
   const int64_t lim = (int64_t)1 << 31;
-  const bool k_ok = a.K1 % BK == 0 && a.K2 % BK == 0 && (int64_t)a.n_rows * a.ldx * 2 < lim && (int64_t)a.O * a.ldw * 2 < lim &&
-                    (a.x2 == nullptr || (int64_t)a.n_rows * a.ldx2 * 2 < lim);
+  const bool k_ok = a.K1 % BK == 0 && a.K2 % BK == 0 && 320 * a.ldx * 2 < lim && 320 * a.ldw * 2 < lim &&
+                    (a.x2 == nullptr || 320 * a.ldx2 * 2 < lim);
   // 16-byte epilogue accesses
   const bool e_ok = a.ldy % 8 == 0 && (!a.residual || a.ldr % 8 == 0) && (!a.g1 || a.ldg1 % 8 == 0) && (!a.g2 || a.ldg2 % 8 == 0) &&
                     al(a.y, 16) && al(a.residual, 16) && al(a.bias, 16) && al(a.g1, 16) && al(a.g2, 16);

@@ -176,3 +176,20 @@ def test_full_model_o96_bf16_vs_fp32_and_determinism():
     scale = float(y32.abs().max())
     assert float(err.max()) < 8e-2 * max(scale, 1.0), (float(err.max()), scale)
     assert float(err.mean()) < 1e-2 * max(scale, 1.0)
+
+
+def test_linear_operand_larger_than_2_gib():
+    """N320 decoder MLP-2: x [542 080 x 2048] bf16 is 2.2 GB - beyond 32-bit byte offsets from the operand base; the DMA
+    addressing is tile-relative, so the MFMA path must still be taken and be right on the first, middle and last rows."""
+    from anemoi_core_amd import ops
+
+    n, K, Oo = 542080, 2048, 512
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    x = torch.randn(n, K, device=DEV, dtype=torch.bfloat16, generator=gen)
+    w = (torch.randn(Oo, K, device=DEV, generator=gen) / K**0.5).to(torch.bfloat16)
+    b = torch.randn(Oo, device=DEV, generator=gen).to(torch.bfloat16)
+    y = ops.linear(x, w, b)
+    for r0 in (0, n // 2 - 100, n - 400):
+        rows = slice(r0, r0 + 400)
+        ref = torch.nn.functional.linear(x[rows].float(), w.float(), b.float())
+        assert float((y[rows].float() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
