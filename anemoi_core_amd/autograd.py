@@ -29,31 +29,68 @@ def _t_padded(a: Tensor, mult: int = 64) -> Tensor:
 
 
 class LinearFunction(torch.autograd.Function):
-    """y = act(x W^T + b) + residual."""
+    """y = act(x W^T + b + g1[idx1] + g2[idx2]) + residual.  segN = (ptr, ids): output rows grouped by idxN (adjoint of the
+    gather = deterministic segment sum)."""
 
     @staticmethod
-    def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], act: Optional[str], residual: Optional[Tensor]):
+    def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], act: Optional[str], residual: Optional[Tensor],
+                g1: Optional[Tensor] = None, idx1: Optional[Tensor] = None, seg1=None, g2: Optional[Tensor] = None,
+                idx2: Optional[Tensor] = None, seg2=None):
         ctx.act = act
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
-        ctx.save_for_backward(x, weight, bias)
-        return ops._linear_fwd(x, weight, bias, act=act, residual=residual)
+        ctx.seg1, ctx.seg2 = seg1, seg2
+        ctx.save_for_backward(x, weight, bias, g1, idx1, g2, idx2)
+        return ops._linear_fwd(x, weight, bias, act=act, residual=residual, g1=g1, idx1=idx1, g2=g2, idx2=idx2)
 
     @staticmethod
     def backward(ctx, d_y: Tensor):
-        x, weight, bias = ctx.saved_tensors
+        x, weight, bias, g1, idx1, g2, idx2 = ctx.saved_tensors
         d_y = d_y.contiguous()
         dz = d_y
         if ctx.act == "gelu":
-            pre = ops._linear_fwd(x, weight, bias)
+            pre = ops._linear_fwd(x, weight, bias, g1=g1, idx1=idx1, g2=g2, idx2=idx2)
             dz = ops.gelu_backward(pre, d_y)
-        dx = dw = db = None
+        dx = dw = db = dg1 = dg2 = None
         if ctx.needs_input_grad[0]:
             dx = ops._linear_fwd(dz, weight.t().contiguous())
         if ctx.needs_input_grad[1]:
             dw = ops._linear_fwd(_t_padded(dz), _t_padded(x.reshape(-1, x.shape[-1]))).to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = ops.colsum(dz).to(bias.dtype)
-        return dx, dw, db, None, (d_y if ctx.has_res and ctx.needs_input_grad[4] else None)
+        if g1 is not None and ctx.needs_input_grad[5]:
+            dg1 = ops.segment_sum_rows(dz, *ctx.seg1)
+        if g2 is not None and ctx.needs_input_grad[8]:
+            dg2 = ops.segment_sum_rows(dz, *ctx.seg2)
+        return (dx, dw, db, None, (d_y if ctx.has_res and ctx.needs_input_grad[4] else None), dg1, None, None, dg2, None, None)
+
+
+class EdgeLnResidualSegmentSumFunction(torch.autograd.Function):
+    """(e_new, agg) = (LayerNorm(z) + e_old, segment sum of e_new over the in-edges of every destination): GraphConv's
+    ``edge_mlp(...).layer_norm + edge_attr`` and ``scatter(sum)`` (reference layers/conv.py:73-81)."""
+
+    @staticmethod
+    def forward(ctx, z: Tensor, e_old: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], eps: float, csc):
+        ctx.eps, ctx.csc, ctx.has_ln, ctx.has_beta = eps, csc, gamma is not None, beta is not None
+        ctx.save_for_backward(z, gamma)
+        return ops._edge_ln_residual_segment_sum_fwd(z, e_old, gamma, beta, eps, csc)
+
+    @staticmethod
+    def backward(ctx, d_e_new: Optional[Tensor], d_agg: Optional[Tensor]):
+        z, gamma = ctx.saved_tensors
+        csc = ctx.csc
+        if d_agg is None:
+            total = d_e_new.contiguous()
+        elif d_e_new is None:
+            total = ops.gather_rows(d_agg.contiguous(), csc.dst)
+        else:
+            total = ops.gather_add_rows(d_e_new.contiguous(), d_agg.contiguous(), csc.dst)
+        dz, dg, db = total, None, None
+        if ctx.has_ln:
+            need_p = ctx.needs_input_grad[2] or (ctx.has_beta and ctx.needs_input_grad[3])
+            dz, dg, db = ops.layer_norm_backward(total, z, gamma, ctx.eps, need_param_grads=need_p)
+            dg = dg.to(gamma.dtype) if ctx.needs_input_grad[2] else None
+            db = db.to(gamma.dtype) if ctx.has_beta and ctx.needs_input_grad[3] else None
+        return (dz if ctx.needs_input_grad[0] else None, total if ctx.needs_input_grad[1] else None, dg, db, None, None)
 
 
 class LayerNormFunction(torch.autograd.Function):

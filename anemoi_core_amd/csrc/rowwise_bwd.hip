@@ -151,6 +151,51 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ pre
   store_vec<T, VEC>(dpre + (int64_t)r * lddp + c, o);
 }
 
+// out[r] = sum_{i in [ptr[r], ptr[r+1])} x[ids ? ids[i] : i]   (fp32 accumulation, one wave per output row).
+// ids == NULL: contiguous segments (edges sorted by destination); ids = the reverse-CSR edge list: rows grouped by source.
+// Adjoint of the row gathers in the GraphConv GEMM epilogue and of gather_rows (deterministic, no atomics).
+template <typename T, int VEC>
+__global__ __launch_bounds__(64 * kWaves) void segment_sum_rows_kernel(const T* __restrict__ x, int64_t ldx, const int32_t* __restrict__ ptr,
+                                                                       const int32_t* __restrict__ ids, T* __restrict__ out, int64_t ldo,
+                                                                       int n_out, int D) {
+  const int lane = threadIdx.x & 63;
+  const int r = __builtin_amdgcn_readfirstlane(blockIdx.x * kWaves + (threadIdx.x >> 6));
+  if (r >= n_out) return;
+  const int beg = ptr[r], end = ptr[r + 1];
+  for (int c = lane * VEC; c < D; c += 64 * VEC) {
+    float acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+    for (int i = beg; i < end; ++i) {
+      const int row = ids ? ids[i] : i;
+      float v[VEC];
+      load_vec<T, VEC>(x + (int64_t)row * ldx + c, v);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] += v[j];
+    }
+    store_vec<T, VEC>(out + (int64_t)r * ldo + c, acc);
+  }
+}
+
+// out[i] = a[i] + b[idx[i]]
+template <typename T, int VEC>
+__global__ __launch_bounds__(64 * kWaves) void gather_add_rows_kernel(const T* __restrict__ a, int64_t lda, const T* __restrict__ b, int64_t ldb,
+                                                                      const int32_t* __restrict__ idx, T* __restrict__ out, int64_t ldo,
+                                                                      int n_out, int D) {
+  const int lane = threadIdx.x & 63;
+  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * kWaves + (threadIdx.x >> 6));
+  if (i >= n_out) return;
+  const int s = idx[i];
+  for (int c = lane * VEC; c < D; c += 64 * VEC) {
+    float u[VEC], v[VEC];
+    load_vec<T, VEC>(a + (int64_t)i * lda + c, u);
+    load_vec<T, VEC>(b + (int64_t)s * ldb + c, v);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) u[j] += v[j];
+    store_vec<T, VEC>(out + (int64_t)i * ldo + c, u);
+  }
+}
+
 template <typename T>
 int pick_vec(int D, std::initializer_list<int64_t> lds, std::initializer_list<const void*> ptrs) {
   int vec = 16 / (int)sizeof(T);
@@ -222,6 +267,39 @@ int launch_gelu_bwd(const void* pre, int64_t ldp, const void* dy, int64_t lddy, 
   return check_launch("gelu_bwd_kernel");
 }
 
+template <typename T>
+int launch_segment_sum(const void* x, int64_t ldx, const int32_t* ptr, const int32_t* ids, void* out, int64_t ldo, int n_out, int D, hipStream_t st) {
+  const int vec = pick_vec<T>(D, {ldx, ldo}, {x, out});
+  const dim3 grid((n_out + kWaves - 1) / kWaves), block(64 * kWaves);
+#define SS_CASE(V)                                                                                                          \
+  case V:                                                                                                                   \
+    hipLaunchKernelGGL((segment_sum_rows_kernel<T, V>), grid, block, 0, st, (const T*)x, ldx, ptr, ids, (T*)out, ldo, n_out, D); \
+    break;
+  switch (vec) {
+    SS_CASE(1) SS_CASE(2) SS_CASE(4) SS_CASE(8)
+    default: set_error("segment_sum_rows: bad vector width"); return ANEMOI_E_INVALID;
+  }
+#undef SS_CASE
+  return check_launch("segment_sum_rows_kernel");
+}
+
+template <typename T>
+int launch_gather_add(const void* a, int64_t lda, const void* b, int64_t ldb, const int32_t* idx, void* out, int64_t ldo, int n_out, int D,
+                      hipStream_t st) {
+  const int vec = pick_vec<T>(D, {lda, ldb, ldo}, {a, b, out});
+  const dim3 grid((n_out + kWaves - 1) / kWaves), block(64 * kWaves);
+#define GA_CASE(V)                                                                                                          \
+  case V:                                                                                                                   \
+    hipLaunchKernelGGL((gather_add_rows_kernel<T, V>), grid, block, 0, st, (const T*)a, lda, (const T*)b, ldb, idx, (T*)out, ldo, n_out, D); \
+    break;
+  switch (vec) {
+    GA_CASE(1) GA_CASE(2) GA_CASE(4) GA_CASE(8)
+    default: set_error("gather_add_rows: bad vector width"); return ANEMOI_E_INVALID;
+  }
+#undef GA_CASE
+  return check_launch("gather_add_rows_kernel");
+}
+
 }  // namespace
 }  // namespace anemoi
 
@@ -267,6 +345,34 @@ extern "C" int anemoi_gelu_bwd(const void* pre, int64_t ldp, const void* d_y, in
     case ANEMOI_F32: return launch_gelu_bwd<float>(pre, ldp, d_y, lddy, d_pre, lddp, n_rows, D, st);
     case ANEMOI_BF16: return launch_gelu_bwd<bf16_t>(pre, ldp, d_y, lddy, d_pre, lddp, n_rows, D, st);
     case ANEMOI_F16: return launch_gelu_bwd<f16_t>(pre, ldp, d_y, lddy, d_pre, lddp, n_rows, D, st);
+    default: set_error("unknown dtype"); return ANEMOI_E_INVALID;
+  }
+}
+
+extern "C" int anemoi_segment_sum_rows(const void* x, int64_t ldx, const int32_t* ptr, const int32_t* ids, void* out, int64_t ldo,
+                                       int32_t n_out, int32_t D, anemoi_dtype_t dtype, void* stream) {
+  ANEMOI_REQUIRE(n_out >= 0 && D > 0 && ldx >= D && ldo >= D, "segment_sum_rows: bad sizes");
+  if (n_out == 0) return ANEMOI_OK;
+  ANEMOI_REQUIRE(x && ptr && out, "segment_sum_rows: null pointer");
+  hipStream_t st = as_stream(stream);
+  switch (dtype) {
+    case ANEMOI_F32: return launch_segment_sum<float>(x, ldx, ptr, ids, out, ldo, n_out, D, st);
+    case ANEMOI_BF16: return launch_segment_sum<bf16_t>(x, ldx, ptr, ids, out, ldo, n_out, D, st);
+    case ANEMOI_F16: return launch_segment_sum<f16_t>(x, ldx, ptr, ids, out, ldo, n_out, D, st);
+    default: set_error("unknown dtype"); return ANEMOI_E_INVALID;
+  }
+}
+
+extern "C" int anemoi_gather_add_rows(const void* a, int64_t lda, const void* b, int64_t ldb, const int32_t* idx, void* out, int64_t ldo,
+                                      int32_t n_out, int32_t D, anemoi_dtype_t dtype, void* stream) {
+  ANEMOI_REQUIRE(n_out >= 0 && D > 0 && lda >= D && ldb >= D && ldo >= D, "gather_add_rows: bad sizes");
+  if (n_out == 0) return ANEMOI_OK;
+  ANEMOI_REQUIRE(a && b && idx && out, "gather_add_rows: null pointer");
+  hipStream_t st = as_stream(stream);
+  switch (dtype) {
+    case ANEMOI_F32: return launch_gather_add<float>(a, lda, b, ldb, idx, out, ldo, n_out, D, st);
+    case ANEMOI_BF16: return launch_gather_add<bf16_t>(a, lda, b, ldb, idx, out, ldo, n_out, D, st);
+    case ANEMOI_F16: return launch_gather_add<f16_t>(a, lda, b, ldb, idx, out, ldo, n_out, D, st);
     default: set_error("unknown dtype"); return ANEMOI_E_INVALID;
   }
 }

@@ -32,6 +32,14 @@ def _all_gather_into_tensor(out: Tensor, inp: Tensor, group) -> None:
     collective(lambda: dist.all_gather_into_tensor(out, inp, group=group))
 
 
+def _forward_only(*tensors) -> None:
+    """The adjoints of the exchanges (reference primitives.py:463-521) are not built yet: refuse to record a graph that
+    would silently drop gradients."""
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        raise NotImplementedError("the backward of the model-parallel exchanges is scope row f1 (next): train on one GPU per "
+                                  "model instance, or run the sharded forward under torch.no_grad()")
+
+
 def shard_tensor(x: Tensor, dim: int, shard_sizes: Sequence[int], group) -> Tensor:
     """Local slice of a replicated tensor (no communication): graph.py:66-103 / primitives.py:24-57."""
     if comm_size(group) == 1:
@@ -45,6 +53,7 @@ def gather_tensor(x: Tensor, dim: int, shard_sizes: Sequence[int], group) -> Ten
     world = comm_size(group)
     if world == 1:
         return x
+    _forward_only(x)
     x = x.contiguous()
     if dim != 0:
         x = x.transpose(0, dim).contiguous()
@@ -78,6 +87,7 @@ def halo_exchange(x: Tensor, send_index: Tensor, send_counts: Sequence[int], rec
     ``gather_fn(x, idx)`` packs the send buffer (ops.gather_rows on the GPU)."""
     if comm_size(group) == 1:
         return x
+    _forward_only(x)
     packed = gather_fn(x, send_index) if gather_fn is not None else x.index_select(0, send_index.long())
     recv = all_to_all_rows(packed, send_counts, recv_counts, group)
     return torch.cat([x, recv], dim=0)
@@ -92,6 +102,7 @@ def exchange_rows(x_local: Tensor, want_global_ids: Tensor, shard_sizes: Sequenc
     if world == 1:
         rows = gather_fn(x_local, want_global_ids.to(torch.int32)) if gather_fn is not None else x_local.index_select(0, want_global_ids.long())
         return rows, plan
+    _forward_only(x_local)
     if plan is None:
         if segments._ACTIVE is not None:
             raise RuntimeError("exchange_rows: the needed-rows plan must exist before a SegmentedGraph capture (run a warm-up forward first)")

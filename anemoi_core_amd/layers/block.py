@@ -22,7 +22,7 @@ from ..distributed.partition import build_graph_partition_from_shard_info
 from ..distributed.shapes import BipartiteGraphShardInfo, GraphShardInfo, comm_rank, comm_size, model_is_distributed
 from .conv import GraphConv
 from .graphcache import get_csc, get_edge_features, get_reverse_csr
-from .kernels import PaddedLinear, check_inference
+from .kernels import PaddedLinear
 from .mlp import MLP
 from .utils import compute_mlp_hidden_dim
 from ..utils.tensors import version
@@ -306,7 +306,6 @@ class GraphConvBaseBlock(BaseBlock):
 class GraphConvProcessorBlock(GraphConvBaseBlock):
     def forward(self, x: Tensor, edge_attr: Tensor, edge_index: Tensor, shard_info: GraphShardInfo, model_comm_group=None,
                 size=None, **layer_kwargs):
-        check_inference(x, edge_attr)
         if self.emb_edges is not None:
             edge_attr = self.emb_edges(edge_attr)
         if model_is_distributed(model_comm_group):  # block.py:375: all node rows are needed as sources
@@ -335,7 +334,6 @@ class GraphConvMapperBlock(GraphConvBaseBlock):
     def forward(self, x, edge_attr: Tensor, edge_index: Tensor, shard_info: BipartiteGraphShardInfo, model_comm_group=None,
                 size=None, **layer_kwargs):
         x_src, x_dst = x
-        check_inference(x_src, x_dst, edge_attr)
         if model_is_distributed(model_comm_group):
             # block.py:441-479: node shards in, this rank's (dst-owned, globally numbered) edges; every source row is made
             # available (the mappers of this package call forward_local with only the rows they need instead)

@@ -8,8 +8,7 @@ import torch
 from torch import Tensor, nn
 
 from .. import ops
-from .graphcache import get_csc
-from .kernels import check_inference
+from .graphcache import get_csc, get_reverse_csr
 from .mlp import MLP
 
 
@@ -53,7 +52,6 @@ class GraphConv(nn.Module):
 
     def forward(self, x, edge_attr: Tensor, edge_index: Tensor, size=None, edges_are_dst_sorted: bool = True):
         x_src, x_dst = (x, x) if isinstance(x, Tensor) else x
-        check_inference(x_src, x_dst, edge_attr)
         size = (x_src.shape[0], x_dst.shape[0]) if size is None else size
         csc = get_csc(edge_index, size, edges_are_dst_sorted)
         if csc.perm is not None:
@@ -63,7 +61,11 @@ class GraphConv(nn.Module):
         w = lin0.weight  # [out, 3D] = [W_i | W_j | W_e]
         p_dst = ops.linear(x_dst, w[:, :D])
         p_src = ops.linear(x_src, w[:, D:2 * D])
-        h = ops.linear(edge_attr, w[:, 2 * D:], lin0.bias, act="gelu", g1=p_dst, idx1=csc.dst, g2=p_src, idx2=csc.row)
+        seg = {}
+        if ops._needs_grad(p_dst, p_src, edge_attr, w):  # training: the adjoint of the two row gathers = segment sums
+            rowptr, edge_ids, _ = get_reverse_csr(csc)
+            seg = dict(seg1=(csc.colptr, None), seg2=(rowptr, edge_ids))
+        h = ops.linear(edge_attr, w[:, 2 * D:], lin0.bias, act="gelu", g1=p_dst, idx1=csc.dst, g2=p_src, idx2=csc.row, **seg)
         z = self.edge_mlp(h, skip_first=True, skip_layer_norm=True)
         ln = self.edge_mlp.layer_norm
         edges_new, out = ops.edge_ln_residual_segment_sum(z, edge_attr, None if ln is None else ln.weight,

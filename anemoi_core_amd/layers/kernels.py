@@ -14,16 +14,6 @@ from .. import ops
 from ..utils.tensors import version
 
 
-def check_inference(*tensors: Tensor) -> None:
-    """GraphConv (GNN) family: forward only for now.  The GraphTransformer family, Linear, LayerNorm and MLP are
-    differentiable (scope row f1: ops.linear / ops.layer_norm / the attention op carry HIP backward kernels)."""
-    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
-        raise NotImplementedError(
-            "the GraphConv (GNN) blocks of anemoi_core_amd implement the forward pass only (their backward is scope row f1, "
-            "next); run under torch.no_grad() / torch.inference_mode(), or use the GraphTransformer family."
-        )
-
-
 class Linear(nn.Linear):
     """torch.nn.Linear parameters, MFMA forward (bias fused)."""
 

@@ -28,7 +28,7 @@ from ..distributed.partition import (
 )
 from ..distributed.shapes import BipartiteGraphShardInfo, comm_rank, comm_size, get_shard_sizes, model_is_distributed
 from .block import GraphConvMapperBlock, GraphTransformerMapperBlock
-from .kernels import PaddedLinear, check_inference
+from .kernels import PaddedLinear
 from .mlp import MLP
 from .utils import compute_mlp_hidden_dim, load_layer_kernels
 from ..utils.tensors import version
@@ -207,7 +207,6 @@ class GNNBaseMapper(BaseMapper):
     def mapper_forward(self, x, batch_size, shard_info, edge_attr, edge_index, model_comm_group=None,
                        keep_x_dst_sharded: bool = False, edges_are_dst_sorted: bool = True, **kwargs):
         x_src, x_dst = x
-        check_inference(x_src, x_dst, edge_attr)
         if model_is_distributed(model_comm_group):
             return self._mapper_forward_sharded(x_src, x_dst, shard_info, edge_attr, edge_index, model_comm_group,
                                                 keep_x_dst_sharded, edges_are_dst_sorted)

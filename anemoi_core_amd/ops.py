@@ -276,16 +276,22 @@ def _layer_norm_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], eps: floa
 def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, *, act: Optional[str] = None,
            residual: Optional[Tensor] = None, x2: Optional[Tensor] = None, g1: Optional[Tensor] = None,
            idx1: Optional[Tensor] = None, g2: Optional[Tensor] = None, idx2: Optional[Tensor] = None,
-           out: Optional[Tensor] = None) -> Tensor:
+           out: Optional[Tensor] = None, seg1=None, seg2=None) -> Tensor:
     """y = act([x | x2] @ weight^T + bias + g1[idx1] + g2[idx2]) + residual.  x [N, K1], x2 [N, K2], weight [O, K1+K2].
-    Differentiable (without the gather-add terms): with autograd recording it runs as ``autograd.LinearFunction``."""
+    Differentiable: with autograd recording it runs as ``autograd.LinearFunction``; the gather-add terms then need
+    ``seg1`` / ``seg2`` = (ptr int32 [rows(g)+1], ids int32 [N] or None): the rows of the output grouped by idx value
+    (for a dst-sorted graph: (colptr, None) for idx = dst and (rowptr, edge_ids) for idx = src)."""
     if _needs_grad(x, weight, bias, residual, x2, g1, g2):
-        if g1 is not None or g2 is not None or out is not None:
-            raise NotImplementedError("backward of the gather-add GEMM epilogue (GraphConv training) is scope row f1 (next)")
+        if out is not None:
+            raise ValueError("out= is not supported while autograd is recording")
         from .autograd import LinearFunction
 
         if x2 is not None:
             x = torch.cat([x, x2.to(x.dtype)], dim=1)
+        if g1 is not None or g2 is not None:
+            if (g1 is not None and seg1 is None) or (g2 is not None and seg2 is None):
+                raise ValueError("the backward of the gather-add terms needs seg1 / seg2 (row groups of idx1 / idx2)")
+            return LinearFunction.apply(x, weight, bias, act, residual, g1, idx1, seg1, g2, idx2, seg2)
         return LinearFunction.apply(x, weight, bias, act, residual)
     return _linear_fwd(x, weight, bias, act=act, residual=residual, x2=x2, g1=g1, idx1=idx1, g2=g2, idx2=idx2, out=out)
 
@@ -376,7 +382,16 @@ def gelu_backward(pre: Tensor, d_y: Tensor) -> Tensor:
 
 def edge_ln_residual_segment_sum(z: Tensor, e_old: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], eps: float,
                                  csc: CSC) -> tuple[Tensor, Tensor]:
-    """e_new = LayerNorm(z) + e_old;  agg[d] = sum of e_new over the in-edges of d.  Returns (e_new, agg)."""
+    """e_new = LayerNorm(z) + e_old;  agg[d] = sum of e_new over the in-edges of d.  Returns (e_new, agg).  Differentiable."""
+    if _needs_grad(z, e_old, gamma, beta):
+        from .autograd import EdgeLnResidualSegmentSumFunction
+
+        return EdgeLnResidualSegmentSumFunction.apply(z, e_old, gamma, beta, float(eps), csc)
+    return _edge_ln_residual_segment_sum_fwd(z, e_old, gamma, beta, eps, csc)
+
+
+def _edge_ln_residual_segment_sum_fwd(z: Tensor, e_old: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], eps: float,
+                                      csc: CSC) -> tuple[Tensor, Tensor]:
     _dev(z, e_old, gamma, beta, csc.colptr)
     M, D = z.shape
     if M != csc.num_edges or tuple(e_old.shape) != (M, D):
@@ -389,6 +404,33 @@ def edge_ln_residual_segment_sum(z: Tensor, e_old: Tensor, gamma: Optional[Tenso
         e_new.data_ptr(), D, agg.data_ptr(), D, csc.n_dst, D, _dt(z), _stream())
     _lib.check(rc, "edge_ln_residual_segment_sum_fwd")
     return e_new, agg
+
+
+def segment_sum_rows(x: Tensor, ptr: Tensor, ids: Optional[Tensor] = None) -> Tensor:
+    """out[r] = sum_{i in [ptr[r], ptr[r+1])} x[ids[i] if ids is given else i]; ptr int32 [n_out + 1], ids int32."""
+    _dev(x, ptr, ids)
+    for t in (ptr, ids):
+        if t is not None and (t.dtype != torch.int32 or t.dim() != 1 or not t.is_contiguous()):
+            raise ValueError("ptr / ids must be contiguous int32 vectors")
+    D, n_out = x.shape[1], ptr.shape[0] - 1
+    out = torch.empty((n_out, D), dtype=x.dtype, device=x.device)
+    p, ld = _rows(x, "x")
+    rc = _lib.load().anemoi_segment_sum_rows(p, ld, ptr.data_ptr(), ids.data_ptr() if ids is not None else 0, out.data_ptr(), D, n_out, D,
+                                             _dt(x), _stream())
+    _lib.check(rc, "segment_sum_rows")
+    return out
+
+
+def gather_add_rows(a: Tensor, b: Tensor, idx: Tensor) -> Tensor:
+    """out[i] = a[i] + b[idx[i]] (idx int32 [rows(a)])."""
+    _dev(a, b, idx)
+    if idx.dtype != torch.int32 or idx.shape != (a.shape[0],) or not idx.is_contiguous() or a.shape[1] != b.shape[1]:
+        raise ValueError("idx must be contiguous int32 [rows(a)] and a, b must have the same width")
+    D = a.shape[1]
+    out = torch.empty((a.shape[0], D), dtype=a.dtype, device=a.device)
+    (ap, lda), (bp, ldb) = _rows(a, "a"), _rows(b, "b", a.dtype)
+    _lib.check(_lib.load().anemoi_gather_add_rows(ap, lda, bp, ldb, idx.data_ptr(), out.data_ptr(), D, a.shape[0], D, _dt(a), _stream()), "gather_add_rows")
+    return out
 
 
 def gather_rows(x: Tensor, idx: Tensor) -> Tensor:

@@ -141,6 +141,17 @@ int anemoi_edge_ln_residual_segment_sum_fwd(const void* z, int64_t ldz, const vo
 int anemoi_gather_rows(const void* x, int64_t ldx, const int32_t* idx, void* out, int64_t ldo, int32_t n_out, int32_t D,
                        anemoi_dtype_t dtype, void* stream);
 
+/* out[r] = sum over i in [ptr[r], ptr[r+1]) of x[ids ? ids[i] : i]  (fp32 accumulation; deterministic).
+ * Adjoint of the row gathers: with ids = NULL and ptr = colptr it sums the contiguous in-edge rows of every destination,
+ * with (ptr, ids) = the reverse CSR (rowptr, edge_ids) the out-edge rows of every source.  Replaces: autograd of the
+ * x_i / x_j index_select in GraphConv (layers/conv.py:66-81) and of scatter(sum). */
+int anemoi_segment_sum_rows(const void* x, int64_t ldx, const int32_t* ptr, const int32_t* ids, void* out, int64_t ldo,
+                            int32_t n_out, int32_t D, anemoi_dtype_t dtype, void* stream);
+
+/* out[i] = a[i] + b[idx[i]]: adjoint of scatter(sum) + the carried edge gradient in GraphConv's backward. */
+int anemoi_gather_add_rows(const void* a, int64_t lda, const void* b, int64_t ldb, const int32_t* idx, void* out, int64_t ldo,
+                           int32_t n_out, int32_t D, anemoi_dtype_t dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
