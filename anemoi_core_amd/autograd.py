@@ -109,6 +109,23 @@ class LayerNormFunction(torch.autograd.Function):
                 db.to(weight.dtype) if ctx.has_bias and ctx.needs_input_grad[2] else None, None)
 
 
+class GatherRowsFunction(torch.autograd.Function):
+    """out[i] = x[idx[i]]; backward: d_x[r] = sum of d_out rows with idx == r (fp32 accumulation)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, idx: Tensor):
+        ctx.n = x.shape[0]
+        ctx.save_for_backward(idx)
+        return ops._gather_rows_fwd(x, idx)
+
+    @staticmethod
+    def backward(ctx, d_out: Tensor):
+        (idx,) = ctx.saved_tensors
+        acc = torch.zeros((ctx.n, d_out.shape[1]), dtype=torch.float32, device=d_out.device)
+        acc.index_add_(0, idx.long(), d_out.float())
+        return acc.to(d_out.dtype), None
+
+
 def attention(q: Tensor, k: Tensor, v: Tensor, e: Tensor, csc: "ops.CSC", num_heads: int, reverse) -> Tensor:
     """Differentiable edge attention on [rows, H*C] tensors through the op mirror (materialised E, CSC order)."""
     H = num_heads

@@ -32,28 +32,22 @@ def _all_gather_into_tensor(out: Tensor, inp: Tensor, group) -> None:
     collective(lambda: dist.all_gather_into_tensor(out, inp, group=group))
 
 
-def _forward_only(*tensors) -> None:
-    """The adjoints of the exchanges (reference primitives.py:463-521) are not built yet: refuse to record a graph that
-    would silently drop gradients."""
-    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
-        raise NotImplementedError("the backward of the model-parallel exchanges is scope row f1 (next): train on one GPU per "
-                                  "model instance, or run the sharded forward under torch.no_grad()")
+def _all_reduce_sum(x: Tensor, group) -> None:
+    collective(lambda: dist.all_reduce(x, op=dist.ReduceOp.SUM, group=group))
 
 
-def shard_tensor(x: Tensor, dim: int, shard_sizes: Sequence[int], group) -> Tensor:
-    """Local slice of a replicated tensor (no communication): graph.py:66-103 / primitives.py:24-57."""
-    if comm_size(group) == 1:
-        return x
+def _needs_grad(*tensors) -> bool:
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+# ---------------------------------------------------------------------------------------------- forward primitives
+def _shard(x: Tensor, dim: int, shard_sizes: Sequence[int], group) -> Tensor:
     start = sum(shard_sizes[: comm_rank(group)])
     return x.narrow(dim, start, shard_sizes[comm_rank(group)]).contiguous()
 
 
-def gather_tensor(x: Tensor, dim: int, shard_sizes: Sequence[int], group) -> Tensor:
-    """All-gather shards of possibly unequal size along ``dim``: primitives.py:60-183."""
+def _gather(x: Tensor, dim: int, shard_sizes: Sequence[int], group) -> Tensor:
     world = comm_size(group)
-    if world == 1:
-        return x
-    _forward_only(x)
     x = x.contiguous()
     if dim != 0:
         x = x.transpose(0, dim).contiguous()
@@ -72,11 +66,96 @@ def gather_tensor(x: Tensor, dim: int, shard_sizes: Sequence[int], group) -> Ten
     return out
 
 
-def all_to_all_rows(send: Tensor, send_counts: Sequence[int], recv_counts: Sequence[int], group) -> Tensor:
-    """Variable-count all-to-all over dim 0 of a packed [sum(send_counts), ...] buffer."""
+def _a2a(send: Tensor, send_counts: Sequence[int], recv_counts: Sequence[int], group) -> Tensor:
     recv = send.new_empty((sum(recv_counts),) + tuple(send.shape[1:]))
     _all_to_all_single(recv, send.contiguous(), list(recv_counts), list(send_counts), group)
     return recv
+
+
+# ---------------------------------------------------------------------------------------------- autograd (scope row f1)
+# Convention: every rank back-propagates the loss terms of the rows IT OWNS; parameter gradients are therefore partial sums
+# per rank and are completed by ``reduce_parameter_gradients`` (one all-reduce) after backward.  The adjoints below keep
+# that invariant (reference graph.py:227-500, primitives.py:463-521):
+#   shard (slice of a replicated tensor)      <- zero-expand        (the other ranks add their slices in the all-reduce)
+#   gather, downstream replicated             <- slice              (_GatherParallelSection)
+#   gather, downstream rank-specific ("sync") <- all-reduce + slice (_SyncParallelSection)
+#   all-to-all of rows                        <- the reverse all-to-all (_HaloExchangeParallelSection / _halo_exchange_bwd)
+class _ShardFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dim, sizes, group):
+        ctx.dim, ctx.sizes, ctx.group, ctx.full = dim, sizes, group, x.shape[dim]
+        return _shard(x, dim, sizes, group)
+
+    @staticmethod
+    def backward(ctx, g):
+        start = sum(ctx.sizes[: comm_rank(ctx.group)])
+        shape = list(g.shape)
+        shape[ctx.dim] = ctx.full
+        out = g.new_zeros(shape)
+        out.narrow(ctx.dim, start, g.shape[ctx.dim]).copy_(g)
+        return out, None, None, None
+
+
+class _GatherFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dim, sizes, group, reduce_in_backward):
+        ctx.dim, ctx.sizes, ctx.group, ctx.reduce = dim, sizes, group, reduce_in_backward
+        return _gather(x, dim, sizes, group)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        if ctx.reduce:
+            g = g.clone()
+            _all_reduce_sum(g, ctx.group)
+        return _shard(g, ctx.dim, ctx.sizes, ctx.group), None, None, None, None
+
+
+class _AllToAllRowsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, send, send_counts, recv_counts, group):
+        ctx.send_counts, ctx.recv_counts, ctx.group = list(send_counts), list(recv_counts), group
+        return _a2a(send, send_counts, recv_counts, group)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _a2a(g.contiguous(), ctx.recv_counts, ctx.send_counts, ctx.group), None, None, None
+
+
+def reduce_parameter_gradients(module: torch.nn.Module, group) -> None:
+    """Complete the per-rank partial parameter gradients of a model-parallel backward (sum over the model group)."""
+    if comm_size(group) == 1:
+        return
+    for p in module.parameters():
+        if p.grad is not None:
+            _all_reduce_sum(p.grad, group)
+
+
+def shard_tensor(x: Tensor, dim: int, shard_sizes: Sequence[int], group) -> Tensor:
+    """Local slice of a replicated tensor (no communication): graph.py:66-103 / primitives.py:24-57."""
+    if comm_size(group) == 1:
+        return x
+    if _needs_grad(x):
+        return _ShardFn.apply(x, dim, list(shard_sizes), group)
+    return _shard(x, dim, shard_sizes, group)
+
+
+def gather_tensor(x: Tensor, dim: int, shard_sizes: Sequence[int], group, reduce_in_backward: bool = False) -> Tensor:
+    """All-gather shards of possibly unequal size along ``dim``: primitives.py:60-183.  ``reduce_in_backward``: what
+    follows is rank-specific work on the full tensor (the reference's ``sync_tensor``), so the gradients of all ranks
+    are summed before the local slice is taken."""
+    if comm_size(group) == 1:
+        return x
+    if _needs_grad(x):
+        return _GatherFn.apply(x, dim, list(shard_sizes), group, reduce_in_backward)
+    return _gather(x, dim, shard_sizes, group)
+
+
+def all_to_all_rows(send: Tensor, send_counts: Sequence[int], recv_counts: Sequence[int], group) -> Tensor:
+    """Variable-count all-to-all over dim 0 of a packed [sum(send_counts), ...] buffer (differentiable)."""
+    if _needs_grad(send):
+        return _AllToAllRowsFn.apply(send, list(send_counts), list(recv_counts), group)
+    return _a2a(send, send_counts, recv_counts, group)
 
 
 def halo_exchange(x: Tensor, send_index: Tensor, send_counts: Sequence[int], recv_counts: Sequence[int], group,
@@ -87,7 +166,6 @@ def halo_exchange(x: Tensor, send_index: Tensor, send_counts: Sequence[int], rec
     ``gather_fn(x, idx)`` packs the send buffer (ops.gather_rows on the GPU)."""
     if comm_size(group) == 1:
         return x
-    _forward_only(x)
     packed = gather_fn(x, send_index) if gather_fn is not None else x.index_select(0, send_index.long())
     recv = all_to_all_rows(packed, send_counts, recv_counts, group)
     return torch.cat([x, recv], dim=0)
@@ -102,7 +180,6 @@ def exchange_rows(x_local: Tensor, want_global_ids: Tensor, shard_sizes: Sequenc
     if world == 1:
         rows = gather_fn(x_local, want_global_ids.to(torch.int32)) if gather_fn is not None else x_local.index_select(0, want_global_ids.long())
         return rows, plan
-    _forward_only(x_local)
     if plan is None:
         if segments._ACTIVE is not None:
             raise RuntimeError("exchange_rows: the needed-rows plan must exist before a SegmentedGraph capture (run a warm-up forward first)")

@@ -309,7 +309,7 @@ class GraphConvProcessorBlock(GraphConvBaseBlock):
         if self.emb_edges is not None:
             edge_attr = self.emb_edges(edge_attr)
         if model_is_distributed(model_comm_group):  # block.py:375: all node rows are needed as sources
-            x_in = comm.gather_tensor(x, 0, shard_info.nodes, model_comm_group)
+            x_in = comm.gather_tensor(x, 0, shard_info.nodes, model_comm_group, reduce_in_backward=True)
             n_loc = x.shape[0]
             d0 = sum(shard_info.nodes[: comm_rank(model_comm_group)])
             out_full, edges_new = self._conv_sharded(x_in, x, d0, edge_attr, edge_index, layer_kwargs.get("local_edge_cache"))
@@ -337,7 +337,7 @@ class GraphConvMapperBlock(GraphConvBaseBlock):
         if model_is_distributed(model_comm_group):
             # block.py:441-479: node shards in, this rank's (dst-owned, globally numbered) edges; every source row is made
             # available (the mappers of this package call forward_local with only the rows they need instead)
-            x_src_all = comm.gather_tensor(x_src, 0, shard_info.src_nodes, model_comm_group)
+            x_src_all = comm.gather_tensor(x_src, 0, shard_info.src_nodes, model_comm_group, reduce_in_backward=True)
             d0 = sum(shard_info.dst_nodes[: comm_rank(model_comm_group)])
             ei = torch.stack([edge_index[0], edge_index[1] - d0])
             return self.forward_local(x_src_all, x_dst, x_src, edge_attr, ei)

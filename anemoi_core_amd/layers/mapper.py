@@ -240,7 +240,7 @@ class GNNBaseMapper(BaseMapper):
         if not keep_x_dst_sharded:
             out_dst = comm.gather_tensor(out_dst, 0, g["partition"].dst_splits, group)
         if not src_was_sharded:
-            xs_new = comm.gather_tensor(xs_new, 0, src_sizes, group)
+            xs_new = comm.gather_tensor(xs_new, 0, src_sizes, group, reduce_in_backward=True)  # consumers slice it by THEIR partition
         return xs_new, out_dst
 
     def forward(self, x, batch_size: int, shard_info: BipartiteGraphShardInfo, edge_attr: Tensor, edge_index: Tensor,

@@ -434,7 +434,15 @@ def gather_add_rows(a: Tensor, b: Tensor, idx: Tensor) -> Tensor:
 
 
 def gather_rows(x: Tensor, idx: Tensor) -> Tensor:
-    """out[i] = x[idx[i]] (idx int32)."""
+    """out[i] = x[idx[i]] (idx int32).  Differentiable (adjoint: rows summed back by index)."""
+    if _needs_grad(x):
+        from .autograd import GatherRowsFunction
+
+        return GatherRowsFunction.apply(x, idx)
+    return _gather_rows_fwd(x, idx)
+
+
+def _gather_rows_fwd(x: Tensor, idx: Tensor) -> Tensor:
     _dev(x, idx)
     if idx.dtype != torch.int32 or idx.dim() != 1 or not idx.is_contiguous():
         raise ValueError("idx must be contiguous int32 [n]")

@@ -61,7 +61,7 @@ def layer_norm(x, weight, bias, eps=1e-5, residual=None):
     return y.to(x.dtype)
 
 
-def linear(x, weight, bias=None, *, act=None, residual=None, x2=None, g1=None, idx1=None, g2=None, idx2=None, out=None):
+def linear(x, weight, bias=None, *, act=None, residual=None, x2=None, g1=None, idx1=None, g2=None, idx2=None, out=None, seg1=None, seg2=None):
     a = x.float() if x2 is None else torch.cat([x.float(), x2.float()], 1)
     y = F.linear(a, weight.float(), None if bias is None else bias.float())
     if g1 is not None:
@@ -90,10 +90,25 @@ def gather_rows(x, idx):
     return x.index_select(0, idx.long())
 
 
+def _needs_grad(*tensors):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+def attention_train(q, k, v, e, csc, num_heads, reverse):
+    """Stand-in for anemoi_core_amd.autograd.attention (the differentiable op mirror): plain torch, so autograd works."""
+    return gt_attention(q, k, v, e, csc, num_heads)
+
+
 def install(monkeypatch=None):
     """Patch anemoi_core_amd.ops in the current process (plain setattr when no pytest monkeypatch is given)."""
     names = ["gt_attention", "pack_edge_features", "pack_edge_weights", "gt_attention_fused_edge", "layer_norm", "linear",
              "edge_ln_residual_segment_sum", "gather_rows"]
+    from anemoi_core_amd import autograd as _ag
+
+    if monkeypatch is not None:
+        monkeypatch.setattr(_ag, "attention", attention_train)
+    else:
+        _ag.attention = attention_train
     for n in names:
         if monkeypatch is not None:
             monkeypatch.setattr(real_ops, n, globals()[n])

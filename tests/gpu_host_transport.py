@@ -25,5 +25,13 @@ def install():
             out.reshape(out.shape[0], -1).view(torch.uint8).copy_(r)
         collective(fn)
 
+    def allreduce(x, group):
+        def fn():
+            h = x.detach().float().cpu()
+            dist.all_reduce(h, group=group)
+            x.copy_(h.to(x.dtype))
+        collective(fn)
+
     P._all_to_all_single = a2a
     P._all_gather_into_tensor = allgather
+    P._all_reduce_sum = allreduce

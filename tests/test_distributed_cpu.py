@@ -157,3 +157,57 @@ def test_sharded_gnn_model_matches_reference_output(world):
     c = load_golden("model_tiny.pt")["gnn"]
     for o in _spawn(_model_worker, world, "gnn"):
         assert float((o["out"] - c["out"]).abs().max()) < 2e-4
+
+
+# ---------------------------------------------------------------------------------------------- sharded backward (row f1)
+def _grad_worker(rank, world, group, kind):
+    """Replicated loss on the gathered output; every rank back-propagates its own rows, the partial parameter gradients
+    are completed by one all-reduce (distributed/primitives.py: adjoints of shard / gather / all-to-all)."""
+    from tests import cpu_ops_shim
+
+    cpu_ops_shim.install()
+    from anemoi_core_amd.distributed.primitives import reduce_parameter_gradients
+    from tests.helpers import build_model_from_fixture
+
+    c = load_golden("model_tiny.pt")[kind]
+    model, _ = build_model_from_fixture(c)
+    model.load_state_dict(c["params"], strict=True)
+    x = c["x"].clone().requires_grad_(True)
+    w = torch.randn(c["out"].shape, generator=torch.Generator().manual_seed(2))
+    out = model({"data": x}, model_comm_group=group)["data"]
+    # every rank takes the loss terms of its own block of output rows (the sum over the ranks is the full loss): what runs
+    # AFTER the gather (skip connection, bounding) is replicated work, and only row-local loss terms keep the gradients of
+    # replicated inputs from being counted once per rank
+    sizes = get_balanced_partition_sizes(out.shape[3], world)
+    r0 = sum(sizes[:rank])
+    (out[:, :, :, r0:r0 + sizes[rank]] * w[:, :, :, r0:r0 + sizes[rank]]).sum().backward()
+    reduce_parameter_gradients(model, group)
+    dx = x.grad.clone()
+    dist.all_reduce(dx)  # the input is replicated as well: its gradient is a per-rank partial sum too
+    return dict(out=out.detach(), dx=dx, grads={k: p.grad for k, p in model.named_parameters() if p.grad is not None},
+                names=[k for k, _ in model.named_parameters()])
+
+
+@pytest.mark.parametrize("kind", ["gt", "gnn"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_backward_matches_unsharded_oracle_gradients(world, kind):
+    from oracle import gt_oracle as O
+    from tests.helpers import build_model_from_fixture
+
+    c = load_golden("model_tiny.pt")[kind]
+    _, g = build_model_from_fixture(c)
+    p = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in c["params"].items()}
+    xo = c["x"].clone().requires_grad_(True)
+    w = torch.randn(c["out"].shape, generator=torch.Generator().manual_seed(2))
+    (O.enc_proc_dec_forward(p, c["cfg"], g, xo) * w).sum().backward()
+    for o in _spawn(_grad_worker, world, kind):
+        assert float((o["out"] - c["out"]).abs().max()) < 2e-4
+        assert float((o["dx"] - xo.grad).abs().max()) <= 2e-4 * float(xo.grad.abs().max()) + 1e-6
+        checked = 0
+        for k, ref in p.items():
+            if not isinstance(ref, torch.Tensor) or ref.grad is None or k not in o["names"]:
+                continue  # buffers of the state_dict (coordinates) are not parameters
+            got = o["grads"][k]
+            assert float((got - ref.grad).abs().max()) <= 2e-4 * float(ref.grad.abs().max()) + 1e-6, k
+            checked += 1
+        assert checked >= 60
