@@ -21,11 +21,18 @@ from . import ops
 
 def _t_padded(a: Tensor, mult: int = 64) -> Tensor:
     """[N, C] -> contiguous [C, N_pad] (zero-padded so that the reduction length suits the MFMA path)."""
-    n, c = a.shape
-    n_pad = (n + mult - 1) // mult * mult
-    out = a.new_zeros((c, n_pad))
-    out[:, :n] = a.t()
-    return out
+    return ops.transpose_pad(a, mult)
+
+
+def _weight_grad(dz: Tensor, x: Tensor) -> Tensor:
+    """dW [O, K] = dz^T [O, N] @ x [N, K]: small output, reduction over all rows -> split-K over the CUs (16-bit path)."""
+    n, o = dz.shape
+    k = x.shape[1]
+    if dz.dtype == torch.float32 or k % 4:
+        return ops._linear_fwd(_t_padded(dz), _t_padded(x))
+    tiles = ((o + 63) // 64) * ((k + 127) // 128)
+    splits = max(1, min(((n + 63) // 64) // 4, (512 + tiles - 1) // tiles))
+    return ops.linear_splitk(_t_padded(dz, 64 * splits), _t_padded(x, 64 * splits), splits)
 
 
 class LinearFunction(torch.autograd.Function):
@@ -54,7 +61,7 @@ class LinearFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ops._linear_fwd(dz, weight.t().contiguous())
         if ctx.needs_input_grad[1]:
-            dw = ops._linear_fwd(_t_padded(dz), _t_padded(x.reshape(-1, x.shape[-1]))).to(weight.dtype)
+            dw = _weight_grad(dz, x.reshape(-1, x.shape[-1])).to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = ops.colsum(dz).to(bias.dtype)
         if g1 is not None and ctx.needs_input_grad[5]:

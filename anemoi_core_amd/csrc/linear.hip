@@ -44,6 +44,8 @@ struct LinArgs {
   int n_rows;
   int O;
   int act;
+  int splits = 1;     // persistent kernel only: split-K (see tile_origin)
+  int f32_atomic = 0; // persistent kernel only: y is fp32 and accumulated with atomics (caller zeroes it)
   int tail_rows = 0;  // big-tile kernel only: rows [n_rows, n_rows + tail_rows) are computed on the VALU, a column per wave
 };
 
@@ -422,7 +424,12 @@ __device__ __forceinline__ void mfma_epilogue_band(const LinArgs& a, f32x4 (&acc
 #pragma unroll
         for (int r = 0; r < 8; ++r) vv[r] += to_float(rv[it].v[r]);
       }
-      if (ok) {
+      if (ok && a.f32_atomic) {  // split-K partial: fp32 accumulation in place (no bias / activation / residual here)
+        float* dst32 = (float*)a.y + (int64_t)m * a.ldy + nc;
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+          if (r < ncols) unsafeAtomicAdd(dst32 + r, vv[r]);
+      } else if (ok) {
         T* dst = y + (int64_t)m * a.ldy + nc;
         V8 o8;
 #pragma unroll
@@ -463,16 +470,21 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void linear_mfma_persistent_kernel
   const char* __restrict__ x2b = (const char*)a.x2;
   const char* __restrict__ wb = (const char*)a.w;
   const int K = a.K1 + a.K2;
-  const int nk = K / BK;
+  // split-K: ``num_tiles`` counts (tile, split) pairs; a pair is an ordinary tile of a GEMM over K / splits whose operand
+  // origins are shifted by the split's K offset (it rides on the per-tile byte offsets of the DMA addressing)
+  const int nk = K / BK / a.splits;
   const int my_tiles = (num_tiles - (int)blockIdx.x + G - 1) / G;
   const int total_g = my_tiles * nk;
 
-  auto tile_origin = [&](int j, int& m0, int& n0) {
+  auto tile_origin = [&](int j, int& m0, int& n0) -> int {
     int id = blockIdx.x + j * G;
     const int q = num_tiles >> 3, r = num_tiles & 7, xcd = id & 7, pos = id >> 3;
     id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+    const int split = id % a.splits;
+    id /= a.splits;
     m0 = (id / tiles_n) * TBM;
     n0 = (id % tiles_n) * TBN;
+    return split;
   };
 
   // ---- DMA issue side (runs STAGES-1 K-tiles ahead of the MFMA side, across tile boundaries).  Addresses are a
@@ -481,10 +493,10 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void linear_mfma_persistent_kernel
   int64_t x_toff = 0, x2_toff = 0, w_toff = 0;  // byte offset of the tile being issued (wave-uniform, 64-bit)
   auto setup_issue_tile = [&](int j) {
     int m0, n0;
-    tile_origin(j, m0, n0);
-    x_toff = (int64_t)m0 * a.ldx * 2;
+    const int64_t k_off = (int64_t)tile_origin(j, m0, n0) * nk * BK * 2;
+    x_toff = (int64_t)m0 * a.ldx * 2 + k_off;
     x2_toff = (int64_t)m0 * a.ldx2 * 2;
-    w_toff = (int64_t)n0 * a.ldw * 2;
+    w_toff = (int64_t)n0 * a.ldw * 2 + k_off;
 #pragma unroll
     for (int i = 0; i < kAPW; ++i) {
       const int row = min(wave * kAPW + i, kAPieces - 1) * 8 + (lane >> 3);
@@ -629,7 +641,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void linear_mfma_persistent_kernel
       mfma_epilogue_band<T, EPI>(a, acc, m0, n0, wr, wc, lane, smem + ((g - 1) % STAGES) * kStageBytes + wave * 4096, interior);
       // An interior tile issues exactly kEpiStores stores per wave, and every load of its epilogue has been consumed
       // (waited for, with everything older) before the last store was issued.  Edge tiles predicate their stores.
-      if (interior && nk >= STAGES)
+      if (interior && nk >= STAGES && !a.f32_atomic)
         counted_stores = true;
       else
         drain_all = true;
@@ -901,7 +913,7 @@ static int launch_persistent_wm(const LinArgs& a, hipStream_t st) {
     attr_set = true;
   }
   const int tm = (a.n_rows + 64 * WM - 1) / (64 * WM), tn = (a.O + 64 * WN - 1) / (64 * WN);
-  const int nt = tm * tn;
+  const int nt = tm * tn * a.splits;
   const int per_cu = (160 * 1024) / smem_bytes < 1 ? 1 : (160 * 1024) / smem_bytes;  // small tiles: several workgroups per CU
   const int cap = 256 * (per_cu > 4 ? 4 : per_cu);
   const int grid = nt < cap ? nt : cap;
@@ -993,9 +1005,30 @@ static int launch_mfma(const LinArgs& a, hipStream_t st) {
   return check_launch("linear_mfma_kernel");
 }
 
+template <typename T>
+static int launch_splitk(const LinArgs& a, hipStream_t st) {
+  // 64 x 128 tiles (many tiles from a small output), lock-step schedule, plain epilogue
+  return launch_persistent_wm<T, 0, 1, false, 2>(a, st);
+}
+
 }  // namespace anemoi
 
 using namespace anemoi;
+
+extern "C" int anemoi_linear_splitk_f32(const void* x, int64_t ldx, const void* w, int64_t ldw, float* y, int64_t ldy, int32_t n_rows,
+                                        int32_t O, int32_t K, int32_t splits, anemoi_dtype_t dtype, void* stream) {
+  ANEMOI_REQUIRE(n_rows > 0 && O > 0 && K > 0 && splits >= 1, "linear_splitk_f32: bad sizes n_rows=%d O=%d K=%d splits=%d", n_rows, O, K, splits);
+  ANEMOI_REQUIRE(x && w && y, "linear_splitk_f32: null x/w/y");
+  ANEMOI_REQUIRE(K % (BK * splits) == 0, "linear_splitk_f32: K=%d must be a multiple of %d * splits", K, BK);
+  ANEMOI_REQUIRE(dtype == ANEMOI_BF16 || dtype == ANEMOI_F16, "linear_splitk_f32: 16-bit operands only");
+  ANEMOI_REQUIRE(ldx >= K && ldw >= K && ldy >= O && ldx % 8 == 0 && ldw % 8 == 0 && al(x, 16) && al(w, 16) && al(y, 16) && ldy % 4 == 0,
+                 "linear_splitk_f32: operands must be 16-byte aligned rows (ldx, ldw multiples of 8; ldy of 4)");
+  LinArgs a{x, ldx, K, nullptr, 0, 0, w, ldw, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, 0, y, ldy, n_rows, O, (int)ANEMOI_ACT_NONE};
+  a.splits = splits;
+  a.f32_atomic = 1;
+  hipStream_t st = as_stream(stream);
+  return dtype == ANEMOI_BF16 ? launch_splitk<bf16_t>(a, st) : launch_splitk<f16_t>(a, st);
+}
 
 extern "C" int anemoi_linear_fwd(const void* x, int64_t ldx, int32_t K1, const void* x2, int64_t ldx2, int32_t K2,
                                  const void* w, int64_t ldw, const void* bias, const void* g1, int64_t ldg1,

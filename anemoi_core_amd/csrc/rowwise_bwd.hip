@@ -119,16 +119,30 @@ __global__ __launch_bounds__(64 * kWaves) void rowwise_bwd_kernel(const T* __res
   }
 }
 
-// out[0][c] = sum_w part[w][0][c], out[1][c] = sum_w part[w][1][c]; fixed order
-__global__ void reduce_partials_kernel(const float* __restrict__ part, int nw, int D, float* __restrict__ out0, float* __restrict__ out1) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= 2 * D) return;
+// out0[c] = sum_w part[w][0][c], out1[c] = sum_w part[w][1][c].  One block per 64 columns of the [2D] row: 16 groups of 64
+// threads each add every 16th partial (coalesced 256-byte reads), then a fixed-order tree over the 16 groups in LDS:
+// deterministic, and 64 dependent loads per thread instead of one thread walking all partials.
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ part, int nw, int D, float* __restrict__ out0,
+                                                               float* __restrict__ out1) {
+  __shared__ float red[16][64];
+  const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   float s = 0.f;
-  for (int w = 0; w < nw; ++w) s += part[(int64_t)w * 2 * D + c];
-  if (c < D) {
-    if (out0) out0[c] = s;
-  } else if (out1) {
-    out1[c - D] = s;
+  if (c < 2 * D)
+    for (int w = grp; w < nw; w += 16) s += part[(int64_t)w * 2 * D + c];
+  red[grp][cl] = s;
+  __syncthreads();
+#pragma unroll
+  for (int step = 8; step >= 1; step >>= 1) {
+    if (grp < step) red[grp][cl] += red[grp + step][cl];
+    __syncthreads();
+  }
+  if (grp == 0 && c < 2 * D) {
+    if (c < D) {
+      if (out0) out0[c] = red[0][cl];
+    } else if (out1) {
+      out1[c - D] = red[0][cl];
+    }
   }
 }
 
@@ -196,6 +210,29 @@ __global__ __launch_bounds__(64 * kWaves) void gather_add_rows_kernel(const T* _
   }
 }
 
+// out[c][r] = x[r][c] for r < n_rows, 0 for n_rows <= r < n_pad: the K-contiguous, zero-padded operands of the dW GEMM
+// (reduction over the rows).  64 x 64 tiles through LDS (+1 padding: conflict-free both ways), 16-bit or 32-bit elements.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ out, int64_t ldo,
+                                                            int n_rows, int n_cols, int n_pad) {
+  __shared__ T tile[64][65];
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = r0 + ty + 4 * i, c = c0 + tx;
+    T v = from_float<T>(0.f);
+    if (r < n_rows && c < n_cols) v = x[(int64_t)r * ldx + c];
+    tile[ty + 4 * i][tx] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = c0 + ty + 4 * i, r = r0 + tx;
+    if (c < n_cols && r < n_pad) out[(int64_t)c * ldo + r] = tile[tx][ty + 4 * i];
+  }
+}
+
 template <typename T>
 int pick_vec(int D, std::initializer_list<int64_t> lds, std::initializer_list<const void*> ptrs) {
   int vec = 16 / (int)sizeof(T);
@@ -231,7 +268,7 @@ int launch_rowwise_bwd(const void* x, int64_t ldx, const void* gamma, const void
   const bool want_sums = out0 != nullptr || out1 != nullptr;
   if (n_rows == 0) {  // no rows: the sums are zero
     if (!want_sums) return ANEMOI_OK;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, st, ws, 0, D, out0, out1);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * D + 63) / 64), dim3(1024), 0, st, ws, 0, D, out0, out1);
     return check_launch("reduce_partials_kernel");
   }
 #define RB_CASE(V, C)                                                                                                          \
@@ -246,7 +283,7 @@ int launch_rowwise_bwd(const void* x, int64_t ldx, const void* gamma, const void
 #undef RB_CASE
   int rc = check_launch("rowwise_bwd_kernel");
   if (rc != ANEMOI_OK || !want_sums) return rc;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, st, ws, blocks * kWaves, D, out0, out1);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * D + 63) / 64), dim3(1024), 0, st, ws, blocks * kWaves, D, out0, out1);
   return check_launch("reduce_partials_kernel");
 }
 
@@ -375,4 +412,20 @@ extern "C" int anemoi_gather_add_rows(const void* a, int64_t lda, const void* b,
     case ANEMOI_F16: return launch_gather_add<f16_t>(a, lda, b, ldb, idx, out, ldo, n_out, D, st);
     default: set_error("unknown dtype"); return ANEMOI_E_INVALID;
   }
+}
+
+extern "C" int anemoi_transpose_pad(const void* x, int64_t ldx, void* out, int64_t ldo, int32_t n_rows, int32_t n_cols, int32_t n_pad,
+                                    anemoi_dtype_t dtype, void* stream) {
+  ANEMOI_REQUIRE(n_rows >= 0 && n_cols > 0 && n_pad >= n_rows && ldx >= n_cols && ldo >= n_pad, "transpose_pad: bad sizes");
+  if (n_pad == 0) return ANEMOI_OK;
+  ANEMOI_REQUIRE(x && out, "transpose_pad: null pointer");
+  const dim3 grid((n_pad + 63) / 64, (n_cols + 63) / 64), block(256);
+  hipStream_t st = as_stream(stream);
+  switch (dtype) {
+    case ANEMOI_F32: hipLaunchKernelGGL((transpose_pad_kernel<float>), grid, block, 0, st, (const float*)x, ldx, (float*)out, ldo, n_rows, n_cols, n_pad); break;
+    case ANEMOI_BF16: hipLaunchKernelGGL((transpose_pad_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)x, ldx, (bf16_t*)out, ldo, n_rows, n_cols, n_pad); break;
+    case ANEMOI_F16: hipLaunchKernelGGL((transpose_pad_kernel<f16_t>), grid, block, 0, st, (const f16_t*)x, ldx, (f16_t*)out, ldo, n_rows, n_cols, n_pad); break;
+    default: set_error("unknown dtype"); return ANEMOI_E_INVALID;
+  }
+  return check_launch("transpose_pad_kernel");
 }

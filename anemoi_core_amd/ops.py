@@ -433,6 +433,31 @@ def gather_add_rows(a: Tensor, b: Tensor, idx: Tensor) -> Tensor:
     return out
 
 
+def linear_splitk(a: Tensor, b: Tensor, splits: int) -> Tensor:
+    """fp32 [rows(a), rows(b)] = a @ b^T for 16-bit a [R, K], b [C, K] with the reduction split over ``splits`` groups of
+    CUs (fp32 atomics): the weight-gradient GEMM.  K must be a multiple of 64 * splits."""
+    _dev(a, b)
+    R, K = a.shape
+    Cc = b.shape[0]
+    if b.shape[1] != K or a.dtype != b.dtype or a.dtype not in (torch.bfloat16, torch.float16):
+        raise ValueError("linear_splitk: a [R, K] and b [C, K] must be bf16/fp16 of the same dtype")
+    y = torch.zeros((R, Cc), dtype=torch.float32, device=a.device)
+    (ap, lda), (bp, ldb) = _rows(a, "a"), _rows(b, "b", a.dtype)
+    _lib.check(_lib.load().anemoi_linear_splitk_f32(ap, lda, bp, ldb, y.data_ptr(), Cc, R, Cc, K, int(splits), _dt(a), _stream()), "linear_splitk_f32")
+    return y
+
+
+def transpose_pad(x: Tensor, mult: int = 64) -> Tensor:
+    """[N, C] -> contiguous [C, N_pad] with N_pad = N rounded up to ``mult`` and zeros in the padding."""
+    _dev(x)
+    n, c = x.shape
+    n_pad = (n + mult - 1) // mult * mult
+    out = torch.empty((c, n_pad), dtype=x.dtype, device=x.device)
+    p, ld = _rows(x, "x")
+    _lib.check(_lib.load().anemoi_transpose_pad(p, ld, out.data_ptr(), n_pad, n, c, n_pad, _dt(x), _stream()), "transpose_pad")
+    return out
+
+
 def gather_rows(x: Tensor, idx: Tensor) -> Tensor:
     """out[i] = x[idx[i]] (idx int32).  Differentiable (adjoint: rows summed back by index)."""
     if _needs_grad(x):

@@ -116,6 +116,12 @@ int anemoi_colsum(const void* x, int64_t ldx, float* out, float* workspace, int3
 int anemoi_gelu_bwd(const void* pre, int64_t ldp, const void* d_y, int64_t lddy, void* d_pre, int64_t lddp,
                     int32_t n_rows, int32_t D, anemoi_dtype_t dtype, void* stream);
 
+/* y[n_rows, O] (fp32, ZEROED BY THE CALLER) += x[n_rows, K] @ w[O, K]^T with the reduction split into ``splits`` chunks that
+ * run on different CUs and accumulate with fp32 atomics: the weight-gradient GEMM dW = dZ^T X of torch.nn.Linear's autograd
+ * (small output, reduction over 10^4..10^5 rows).  16-bit operands, K a multiple of 64 * splits. */
+int anemoi_linear_splitk_f32(const void* x, int64_t ldx, const void* w, int64_t ldw, float* y, int64_t ldy, int32_t n_rows,
+                             int32_t O, int32_t K, int32_t splits, anemoi_dtype_t dtype, void* stream);
+
 /* Linear layer with fused epilogue.  Replaces torch.nn.Linear (+ GELU + residual add) as used by
  * get_qkve / projection / MLP (layers/block.py:623-635,1268-1271; layers/mlp.py:158-169).
  *   y[n, o] = act( sum_k A[n,k] * w[o,k] + bias[o] + g1[idx1[n], o] + g2[idx2[n], o] ) + residual[n, o]
@@ -151,6 +157,11 @@ int anemoi_segment_sum_rows(const void* x, int64_t ldx, const int32_t* ptr, cons
 /* out[i] = a[i] + b[idx[i]]: adjoint of scatter(sum) + the carried edge gradient in GraphConv's backward. */
 int anemoi_gather_add_rows(const void* a, int64_t lda, const void* b, int64_t ldb, const int32_t* idx, void* out, int64_t ldo,
                            int32_t n_out, int32_t D, anemoi_dtype_t dtype, void* stream);
+
+/* out[c][r] = x[r][c] (r < n_rows), 0 for n_rows <= r < n_pad.  Builds the K-contiguous operands of the weight-gradient GEMM
+ * dW = dZ^T X (autograd of torch.nn.Linear), whose reduction runs over the rows. */
+int anemoi_transpose_pad(const void* x, int64_t ldx, void* out, int64_t ldo, int32_t n_rows, int32_t n_cols, int32_t n_pad,
+                         anemoi_dtype_t dtype, void* stream);
 
 #ifdef __cplusplus
 }

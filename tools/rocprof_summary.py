@@ -6,6 +6,7 @@ import sys
 
 
 def short(name: str) -> str:
+    name = name.replace("(anonymous namespace)::", "")
     name = re.sub(r"\(.*", "", name)
     name = name.replace("void ", "").replace("anemoi::", "")
     return name[:110]
