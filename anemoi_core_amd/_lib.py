@@ -31,6 +31,7 @@ SIGNATURES = {
     "anemoi_layernorm_bwd": ([_p, _i64, _p, _p, _i64, _p, _i64, _p, _p, _p, _i32, _i32, _f, C.c_int, _p], C.c_int),
     "anemoi_colsum": ([_p, _i64, _p, _p, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_gelu_bwd": ([_p, _i64, _p, _i64, _p, _i64, _i32, _i32, C.c_int, _p], C.c_int),
+    "anemoi_cond_layernorm_fwd": ([_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i32, _i32, _f, C.c_int, _p], C.c_int),
     "anemoi_layernorm_fwd": ([_p, _i64, _p, _p, _p, _i64, _p, _i64, _i32, _i32, _f, C.c_int, _p], C.c_int),
     "anemoi_linear_splitk_f32": ([_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_linear_fwd": ([_p, _i64, _i32, _p, _i64, _i32, _p, _i64, _p, _p, _i64, _p, _p, _i64, _p, _p, _i64, _p, _i64, _i32, _i32, C.c_int, C.c_int, _p], C.c_int),
@@ -38,6 +39,8 @@ SIGNATURES = {
     "anemoi_segment_sum_rows": ([_p, _i64, _p, _p, _p, _i64, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_gather_add_rows": ([_p, _i64, _p, _i64, _p, _p, _i64, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_transpose_pad": ([_p, _i64, _p, _i64, _i32, _i32, _i32, C.c_int, _p], C.c_int),
+    "anemoi_glu_fwd": ([_p, _i64, _p, _i64, _i32, _i32, _i32, C.c_int, _p], C.c_int),
+    "anemoi_glu_bwd": ([_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_gather_rows": ([_p, _i64, _p, _p, _i64, _i32, _i32, C.c_int, _p], C.c_int),
 }
 

@@ -116,6 +116,19 @@ class LayerNormFunction(torch.autograd.Function):
                 db.to(weight.dtype) if ctx.has_bias and ctx.needs_input_grad[2] else None, None)
 
 
+class GluFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gate_value: Tensor, kind: str):
+        ctx.kind = kind
+        ctx.save_for_backward(gate_value)
+        return ops._glu_fwd(gate_value, kind)
+
+    @staticmethod
+    def backward(ctx, d_out: Tensor):
+        (gv,) = ctx.saved_tensors
+        return ops.glu_backward(gv, d_out.contiguous(), ctx.kind), None
+
+
 class GatherRowsFunction(torch.autograd.Function):
     """out[i] = x[idx[i]]; backward: d_x[r] = sum of d_out rows with idx == r (fp32 accumulation)."""
 

@@ -30,7 +30,7 @@ __device__ __forceinline__ void load_row(const T* __restrict__ p, int D, int lan
 // In-register LayerNorm of one row held across the wave: two-pass (mean, then centred variance).
 template <typename T, int VEC, int CH>
 __device__ __forceinline__ void normalise_row(float (&r)[CH][VEC], int D, int lane, const T* __restrict__ gamma,
-                                              const T* __restrict__ beta, float eps) {
+                                              const T* __restrict__ beta, float eps, float gadd = 0.f) {
   float s = 0.f;
 #pragma unroll
   for (int t = 0; t < CH; ++t)
@@ -63,7 +63,7 @@ __device__ __forceinline__ void normalise_row(float (&r)[CH][VEC], int D, int la
         for (int j = 0; j < VEC; ++j) b[j] = 0.f;
       }
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) r[t][j] = fmaf((r[t][j] - mean) * rstd, g[j], b[j]);
+      for (int j = 0; j < VEC; ++j) r[t][j] = fmaf((r[t][j] - mean) * rstd, g[j] + gadd, b[j]);
     }
   }
 }
@@ -98,6 +98,21 @@ __global__ __launch_bounds__(64 * kRowWaves) void layernorm_fwd_kernel(const T* 
 #pragma unroll
       for (int j = 0; j < VEC; ++j) r[t][j] += rs[t][j];
   }
+  store_row<T, VEC, CH>(y + (int64_t)rowi * ldy, D, lane, r);
+}
+
+// ConditionalLayerNorm (reference layers/normalization.py:34-94): y = LN(x) * (scale[row] + 1) + shift[row] with per-row
+// modulation tensors (the two Linear maps of the conditioning, computed by one fused GEMM); lds = 0 broadcasts one row.
+template <typename T, int VEC, int CH>
+__global__ __launch_bounds__(64 * kRowWaves) void cond_layernorm_fwd_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ scale,
+                                                                            int64_t lds, const T* __restrict__ shift, int64_t ldsh,
+                                                                            T* __restrict__ y, int64_t ldy, int n_rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int rowi = blockIdx.x * kRowWaves + (threadIdx.x >> 6);
+  if (rowi >= n_rows) return;
+  float r[CH][VEC];
+  load_row<T, VEC, CH>(x + (int64_t)rowi * ldx, D, lane, r);
+  normalise_row<T, VEC, CH>(r, D, lane, scale + (int64_t)rowi * lds, shift + (int64_t)rowi * ldsh, eps, 1.0f);
   store_row<T, VEC, CH>(y + (int64_t)rowi * ldy, D, lane, r);
 }
 
@@ -198,6 +213,26 @@ static int layernorm_launch(const void* x, int64_t ldx, const void* gamma, const
 }
 
 template <typename T>
+static int cond_layernorm_launch(const void* x, int64_t ldx, const void* scale, int64_t lds, const void* shift, int64_t ldsh, void* y,
+                                 int64_t ldy, int n_rows, int D, float eps, hipStream_t st) {
+  const int vec = pick_vec<T>(D, {ldx, ldy, lds, ldsh}, {x, y, scale, shift});
+  const int ch = pick_chunks(D, vec);
+  ANEMOI_REQUIRE(ch > 0, "cond_layernorm_fwd: D=%d too large for the register-resident row", D);
+  const dim3 grid((n_rows + kRowWaves - 1) / kRowWaves), block(64 * kRowWaves);
+#define CLN_CASE(V, C)                                                                                                      \
+  case V * 16 + C:                                                                                                         \
+    hipLaunchKernelGGL((cond_layernorm_fwd_kernel<T, V, C>), grid, block, 0, st, (const T*)x, ldx, (const T*)scale, lds,   \
+                       (const T*)shift, ldsh, (T*)y, ldy, n_rows, D, eps);                                                 \
+    break;
+  switch (vec * 16 + ch) {
+    ALL_VEC_CH(CLN_CASE)
+    default: set_error("cond_layernorm_fwd: bad vector width"); return ANEMOI_E_INVALID;
+  }
+#undef CLN_CASE
+  return check_launch("cond_layernorm_fwd_kernel");
+}
+
+template <typename T>
 static int edge_launch(const void* z, int64_t ldz, const void* e_old, int64_t lde, const void* gamma, const void* beta,
                        float eps, const int32_t* colptr, void* e_new, int64_t ldn, void* agg, int64_t ldagg, int n_dst,
                        int D, hipStream_t st) {
@@ -278,6 +313,20 @@ extern "C" int anemoi_gather_rows(const void* x, int64_t ldx, const int32_t* idx
     case ANEMOI_F32: return gather_launch<float>(x, ldx, idx, out, ldo, n_out, D, as_stream(stream));
     case ANEMOI_BF16: return gather_launch<bf16_t>(x, ldx, idx, out, ldo, n_out, D, as_stream(stream));
     case ANEMOI_F16: return gather_launch<f16_t>(x, ldx, idx, out, ldo, n_out, D, as_stream(stream));
+    default: set_error("unknown dtype"); return ANEMOI_E_INVALID;
+  }
+}
+
+extern "C" int anemoi_cond_layernorm_fwd(const void* x, int64_t ldx, const void* scale, int64_t lds, const void* shift, int64_t ldsh,
+                                         void* y, int64_t ldy, int32_t n_rows, int32_t D, float eps, anemoi_dtype_t dtype, void* stream) {
+  ANEMOI_REQUIRE(n_rows >= 0 && D > 0 && ldx >= D && ldy >= D && (lds == 0 || lds >= D) && (ldsh == 0 || ldsh >= D), "cond_layernorm_fwd: bad sizes");
+  if (n_rows == 0) return ANEMOI_OK;
+  ANEMOI_REQUIRE(x && y && scale && shift, "cond_layernorm_fwd: null pointer");
+  hipStream_t st = as_stream(stream);
+  switch (dtype) {
+    case ANEMOI_F32: return cond_layernorm_launch<float>(x, ldx, scale, lds, shift, ldsh, y, ldy, n_rows, D, eps, st);
+    case ANEMOI_BF16: return cond_layernorm_launch<bf16_t>(x, ldx, scale, lds, shift, ldsh, y, ldy, n_rows, D, eps, st);
+    case ANEMOI_F16: return cond_layernorm_launch<f16_t>(x, ldx, scale, lds, shift, ldsh, y, ldy, n_rows, D, eps, st);
     default: set_error("unknown dtype"); return ANEMOI_E_INVALID;
   }
 }

@@ -233,6 +233,61 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const T* __restrict_
   }
 }
 
+// Gated feed-forward layers (reference layers/mlp.py:25-59): out = act(gate) * value with [gate | value] the two halves of
+// one fused projection.  kind: 0 sigmoid (GLU), 1 SiLU (SwiGLU), 2 GELU erf (GeGLU), 3 ReLU (ReGLU).
+__device__ __forceinline__ float glu_act(float g, int kind) {
+  switch (kind) {
+    case 0: return 1.0f / (1.0f + __expf(-g));
+    case 1: return g / (1.0f + __expf(-g));
+    case 2: return gelu_erf(g);
+    default: return fmaxf(g, 0.f);
+  }
+}
+__device__ __forceinline__ float glu_act_grad(float g, int kind) {
+  switch (kind) {
+    case 0: {
+      const float sg = 1.0f / (1.0f + __expf(-g));
+      return sg * (1.0f - sg);
+    }
+    case 1: {
+      const float sg = 1.0f / (1.0f + __expf(-g));
+      return sg * (1.0f + g * (1.0f - sg));
+    }
+    case 2: return 0.5f * (1.0f + fast_erf(g * 0.70710678118654752440f)) + g * 0.39894228040143267794f * __expf(-0.5f * g * g);
+    default: return g > 0.f ? 1.0f : 0.f;
+  }
+}
+
+// BWD = false: out[r, c] = act(gv[r, c]) * gv[r, D + c].   BWD = true: d_gv[r, c] = d_out * value * act'(gate),
+// d_gv[r, D + c] = d_out * act(gate)
+template <typename T, int VEC, bool BWD>
+__global__ __launch_bounds__(256) void glu_kernel(const T* __restrict__ gv, int64_t ldgv, const T* __restrict__ d_out, int64_t lddo,
+                                                  T* __restrict__ out, int64_t ldo, int n_rows, int D, int kind) {
+  const int per_row = D / VEC;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)n_rows * per_row) return;
+  const int r = (int)(i / per_row), c = (int)(i % per_row) * VEC;
+  float g[VEC], v[VEC];
+  load_vec<T, VEC>(gv + (int64_t)r * ldgv + c, g);
+  load_vec<T, VEC>(gv + (int64_t)r * ldgv + D + c, v);
+  if constexpr (!BWD) {
+    float o[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) o[j] = glu_act(g[j], kind) * v[j];
+    store_vec<T, VEC>(out + (int64_t)r * ldo + c, o);
+  } else {
+    float d[VEC], dg[VEC], dv[VEC];
+    load_vec<T, VEC>(d_out + (int64_t)r * lddo + c, d);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      dg[j] = d[j] * v[j] * glu_act_grad(g[j], kind);
+      dv[j] = d[j] * glu_act(g[j], kind);
+    }
+    store_vec<T, VEC>(out + (int64_t)r * ldo + c, dg);
+    store_vec<T, VEC>(out + (int64_t)r * ldo + D + c, dv);
+  }
+}
+
 template <typename T>
 int pick_vec(int D, std::initializer_list<int64_t> lds, std::initializer_list<const void*> ptrs) {
   int vec = 16 / (int)sizeof(T);
@@ -337,6 +392,23 @@ int launch_gather_add(const void* a, int64_t lda, const void* b, int64_t ldb, co
   return check_launch("gather_add_rows_kernel");
 }
 
+template <typename T, bool BWD>
+int launch_glu(const void* gv, int64_t ldgv, const void* d_out, int64_t lddo, void* out, int64_t ldo, int n_rows, int D, int kind, hipStream_t st) {
+  const int vec = BWD ? pick_vec<T>(D, {ldgv, lddo, ldo}, {gv, d_out, out}) : pick_vec<T>(D, {ldgv, ldo}, {gv, out});
+  const int64_t n = (int64_t)n_rows * (D / vec);
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+#define GLU_CASE(V)                                                                                                          \
+  case V:                                                                                                                    \
+    hipLaunchKernelGGL((glu_kernel<T, V, BWD>), grid, block, 0, st, (const T*)gv, ldgv, (const T*)d_out, lddo, (T*)out, ldo, n_rows, D, kind); \
+    break;
+  switch (vec) {
+    GLU_CASE(1) GLU_CASE(2) GLU_CASE(4) GLU_CASE(8)
+    default: set_error("glu: bad vector width"); return ANEMOI_E_INVALID;
+  }
+#undef GLU_CASE
+  return check_launch("glu_kernel");
+}
+
 }  // namespace
 }  // namespace anemoi
 
@@ -428,4 +500,32 @@ extern "C" int anemoi_transpose_pad(const void* x, int64_t ldx, void* out, int64
     default: set_error("unknown dtype"); return ANEMOI_E_INVALID;
   }
   return check_launch("transpose_pad_kernel");
+}
+
+extern "C" int anemoi_glu_fwd(const void* gate_value, int64_t ldgv, void* out, int64_t ldo, int32_t n_rows, int32_t D, int32_t kind,
+                              anemoi_dtype_t dtype, void* stream) {
+  ANEMOI_REQUIRE(n_rows >= 0 && D > 0 && ldgv >= 2 * D && ldo >= D && kind >= 0 && kind <= 3, "glu_fwd: bad sizes / kind");
+  if (n_rows == 0) return ANEMOI_OK;
+  ANEMOI_REQUIRE(gate_value && out, "glu_fwd: null pointer");
+  hipStream_t st = as_stream(stream);
+  switch (dtype) {
+    case ANEMOI_F32: return launch_glu<float, false>(gate_value, ldgv, nullptr, 0, out, ldo, n_rows, D, kind, st);
+    case ANEMOI_BF16: return launch_glu<bf16_t, false>(gate_value, ldgv, nullptr, 0, out, ldo, n_rows, D, kind, st);
+    case ANEMOI_F16: return launch_glu<f16_t, false>(gate_value, ldgv, nullptr, 0, out, ldo, n_rows, D, kind, st);
+    default: set_error("unknown dtype"); return ANEMOI_E_INVALID;
+  }
+}
+
+extern "C" int anemoi_glu_bwd(const void* gate_value, int64_t ldgv, const void* d_out, int64_t lddo, void* d_gate_value, int64_t lddgv,
+                              int32_t n_rows, int32_t D, int32_t kind, anemoi_dtype_t dtype, void* stream) {
+  ANEMOI_REQUIRE(n_rows >= 0 && D > 0 && ldgv >= 2 * D && lddo >= D && lddgv >= 2 * D && kind >= 0 && kind <= 3, "glu_bwd: bad sizes / kind");
+  if (n_rows == 0) return ANEMOI_OK;
+  ANEMOI_REQUIRE(gate_value && d_out && d_gate_value, "glu_bwd: null pointer");
+  hipStream_t st = as_stream(stream);
+  switch (dtype) {
+    case ANEMOI_F32: return launch_glu<float, true>(gate_value, ldgv, d_out, lddo, d_gate_value, lddgv, n_rows, D, kind, st);
+    case ANEMOI_BF16: return launch_glu<bf16_t, true>(gate_value, ldgv, d_out, lddo, d_gate_value, lddgv, n_rows, D, kind, st);
+    case ANEMOI_F16: return launch_glu<f16_t, true>(gate_value, ldgv, d_out, lddo, d_gate_value, lddgv, n_rows, D, kind, st);
+    default: set_error("unknown dtype"); return ANEMOI_E_INVALID;
+  }
 }

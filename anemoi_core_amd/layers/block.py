@@ -22,7 +22,7 @@ from ..distributed.partition import build_graph_partition_from_shard_info
 from ..distributed.shapes import BipartiteGraphShardInfo, GraphShardInfo, comm_rank, comm_size, model_is_distributed
 from .conv import GraphConv
 from .graphcache import get_csc, get_edge_features, get_reverse_csr
-from .kernels import PaddedLinear
+from .kernels import PaddedLinear, apply_layer_norm
 from .mlp import MLP
 from .utils import compute_mlp_hidden_dim
 from ..utils.tensors import version
@@ -140,16 +140,11 @@ class GraphTransformerBaseBlock(BaseBlock):
             feat = ops.pack_edge_features(ea)
         return ops.gt_attention_fused_edge(query, key, value, feat, self._fused.packed_edge(self.lin_edge), csc, H, addend=x_r)
 
-    def _post_attention(self, attn_plus_self: Tensor, x_skip: Tensor) -> Tensor:
+    def _post_attention(self, attn_plus_self: Tensor, x_skip: Tensor, cond: Optional[Tensor] = None) -> Tensor:
         out = ops.linear(attn_plus_self, self.projection.weight, self.projection.bias, residual=x_skip)
-        ln = self.layer_norm_mlp_dst
-        h = ops.layer_norm(out, ln.weight, ln.bias, ln.eps)
+        h = apply_layer_norm(self.layer_norm_mlp_dst, out, cond)
         return self.node_dst_mlp(h, residual=out)
 
-    @staticmethod
-    def _unsupported_cond(cond):
-        if cond is not None:
-            raise NotImplementedError("conditional LayerNorm (cond=...) is scope row f3 (next)")
 
 
 class GraphTransformerMapperBlock(GraphTransformerBaseBlock):
@@ -180,7 +175,6 @@ class GraphTransformerMapperBlock(GraphTransformerBaseBlock):
 
     def forward(self, x, edge_attr: Tensor, edge_index: Tensor, shard_info: BipartiteGraphShardInfo, batch_size: int,
                 size, model_comm_group=None, cond=None, edges_are_dst_sorted: bool = True, **layer_kwargs):
-        self._unsupported_cond(cond)
         if self.shard_strategy == "heads" and model_is_distributed(model_comm_group):
             raise NotImplementedError("shard_strategy='heads' (Ulysses all-to-all) is scope row f2 (next); use 'edges'")
         x_src, x_dst = x
@@ -188,17 +182,18 @@ class GraphTransformerMapperBlock(GraphTransformerBaseBlock):
         csc = get_csc(edge_index, size, edges_are_dst_sorted)
         A = self.attn_channels
         ln_s, ln_d = self.layer_norm_attention_src, self.layer_norm_attention_dest
-        xs_n = ops.layer_norm(x_src, ln_s.weight, ln_s.bias, ln_s.eps)
-        xd_n = ops.layer_norm(x_dst, ln_d.weight, ln_d.bias, ln_d.eps)
+        cond_src, cond_dst = cond if cond is not None else (None, None)  # block.py:979-980
+        xs_n = apply_layer_norm(ln_s, x_src, cond_src)
+        xd_n = apply_layer_norm(ln_d, x_dst, cond_dst)
         w_qs, b_qs = self._fused.get("qs", [self.lin_query, self.lin_self])
         w_kv, b_kv = self._fused.get("kv", [self.lin_key, self.lin_value])
         qs = ops.linear(xd_n, w_qs, b_qs)
         kv = ops.linear(xs_n, w_kv, b_kv)
         out = self._attention(qs[:, :A], kv[:, :A], kv[:, A:], qs[:, A:], edge_attr, csc)
-        nodes_new_dst = self._post_attention(out, x_dst)
+        nodes_new_dst = self._post_attention(out, x_dst, cond_dst)
         if self.update_src_nodes:
             ln = self.layer_norm_mlp_src
-            nodes_new_src = self.node_src_mlp(ops.layer_norm(x_src, ln.weight, ln.bias, ln.eps), residual=x_src)
+            nodes_new_src = self.node_src_mlp(apply_layer_norm(ln, x_src, cond_src), residual=x_src)
         else:
             nodes_new_src = x_src
         return (nodes_new_src, nodes_new_dst), edge_attr
@@ -242,10 +237,9 @@ class GraphTransformerProcessorBlock(GraphTransformerBaseBlock):
     def forward(self, x: Tensor, edge_attr: Tensor, edge_index: Tensor, shard_info: GraphShardInfo, batch_size: int,
                 size, model_comm_group=None, cond=None, edges_are_dst_sorted: bool = True, halo_cache: Optional[dict] = None,
                 **kwargs):
-        self._unsupported_cond(cond)
         A = self.attn_channels
         ln = self.layer_norm_attention
-        xn = ops.layer_norm(x, ln.weight, ln.bias, ln.eps)
+        xn = apply_layer_norm(ln, x, cond)
         if model_is_distributed(model_comm_group):
             if self.shard_strategy != "edges":
                 raise NotImplementedError("shard_strategy='heads' (Ulysses all-to-all) is scope row f2 (next); use 'edges'")
@@ -265,7 +259,7 @@ class GraphTransformerProcessorBlock(GraphTransformerBaseBlock):
             q, k, v, x_r = qkvs[:, :A], qkvs[:, A:2 * A], qkvs[:, 2 * A:3 * A], qkvs[:, 3 * A:]
             csc = get_csc(edge_index, (n, n), edges_are_dst_sorted)
         out = self._attention(q, k, v, x_r, edge_attr, csc)
-        return self._post_attention(out, x), edge_attr
+        return self._post_attention(out, x, cond), edge_attr
 
 
 class HaloPlan:

@@ -116,8 +116,6 @@ class GraphTransformerBaseMapper(BaseMapper):
     # subclasses: pre_process(x_src_compact, x_dst) -> embedded pair, post_process(x_dst)
     def forward(self, x, batch_size: int, shard_info: BipartiteGraphShardInfo, edge_attr: Tensor, edge_index: Tensor,
                 model_comm_group=None, keep_x_dst_sharded: bool = False, edges_are_dst_sorted: bool = True, cond=None, **kwargs):
-        if cond is not None:
-            raise NotImplementedError("conditional LayerNorm (cond=...) is scope row f3 (next)")
         if self.shard_strategy == "heads" and model_is_distributed(model_comm_group):
             raise NotImplementedError("shard_strategy='heads' (Ulysses all-to-all) is scope row f2 (next); use 'edges'")
         x_src, x_dst = x
@@ -137,6 +135,15 @@ class GraphTransformerBaseMapper(BaseMapper):
             x_src_c = x_src
         else:
             x_src_c = ops.gather_rows(x_src, g["src_ids32"])
+        if cond is not None:  # (cond_src, cond_dst) rows follow their nodes (reference mapper.py:279-329)
+            c_src, c_dst = cond
+            if sharded and not shard_info.dst_is_sharded():
+                c_dst = c_dst[d0:d1]
+            if sharded and shard_info.src_is_sharded():
+                c_src, _ = comm.exchange_rows(c_src, g["src_ids"], shard_info.src_nodes, model_comm_group, gather_fn=ops.gather_rows, plan=self._plan)
+            elif not g["all_connected"]:
+                c_src = ops.gather_rows(c_src, g["src_ids32"])
+            kwargs["cond"] = (c_src, c_dst)
         xs, xd = self.pre_process((x_src_c, x_dst))
         (_, x_dst_out), _ = self.proc((xs, xd), g["edge_attr"], g["edge_index"], shard_info, batch_size,
                                       (xs.shape[0], xd.shape[0]), model_comm_group, edges_are_dst_sorted=True, **kwargs)

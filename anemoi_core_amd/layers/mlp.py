@@ -1,13 +1,36 @@
-"""MLP — mirror of reference layers/mlp.py:97-179 (mlp_implementation="mlp"), same state_dict keys
-(``mlp.<2i>.{weight,bias}``, ``layer_norm.*``), with GELU / LayerNorm / residual fused into the kernel epilogues."""
+"""MLP — mirror of reference layers/mlp.py:25-179, same state_dict keys (``mlp.<2i>.{weight,bias}`` for "mlp",
+``mlp.<i>.{gate_proj,value_proj}.{weight,bias}`` for the gated variants, ``layer_norm.*``), with GELU / LayerNorm / residual
+fused into the kernel epilogues; a gated layer is ONE fused [gate | value] projection followed by the gating kernel."""
 from __future__ import annotations
 
 from typing import Optional
 
 from torch import Tensor, nn
 
+import torch
+
 from .. import ops
 from .kernels import GELU
+
+
+class GatedMLPLayer(nn.Module):
+    """gating(gate_proj(x)) * value_proj(x) (reference mlp.py:38-53)."""
+
+    def __init__(self, in_features: int, out_features: int, layer_kernels, mlp_implementation: str) -> None:
+        super().__init__()
+        if mlp_implementation not in ops.GLU_KINDS:
+            raise ValueError(f"`mlp_implementation` must be one of {tuple(ops.GLU_KINDS)}, got '{mlp_implementation}'.")
+        self.gate_proj = layer_kernels.Linear(in_features, out_features)
+        self.value_proj = layer_kernels.Linear(in_features, out_features)
+        self.kind = mlp_implementation
+
+    def fused_weights(self):
+        return torch.cat([self.gate_proj.weight, self.value_proj.weight], 0), torch.cat([self.gate_proj.bias, self.value_proj.bias], 0)
+
+    def forward(self, x: Tensor, x2: Optional[Tensor] = None) -> Tensor:
+        w, b = self.fused_weights()
+        h = x.reshape(-1, x.shape[-1])
+        return ops.glu(ops.linear(h, w, b, x2=x2), self.kind).view(*x.shape[:-1], -1)
 
 
 class MLP(nn.Module):
@@ -16,18 +39,25 @@ class MLP(nn.Module):
         super().__init__()
         if n_extra_layers < 0:
             raise ValueError(f"`n_extra_layers` must be >= 0, got {n_extra_layers}.")
-        if mlp_implementation != "mlp":
-            raise NotImplementedError(f"mlp_implementation='{mlp_implementation}' (GLU variants) is scope row f3 (next)")
         Linear, LayerNorm = layer_kernels.Linear, layer_kernels.LayerNorm
-        act = layer_kernels.Activation()
-        if not isinstance(act, GELU):
-            raise NotImplementedError("only GELU activations are fused")
-        layers: list[nn.Module] = [Linear(in_features, hidden_dim), act]
-        for _ in range(n_extra_layers):
-            layers += [Linear(hidden_dim, hidden_dim), layer_kernels.Activation()]
-        layers.append(Linear(hidden_dim, out_features))
-        if final_activation:
-            layers.append(layer_kernels.Activation())
+        self.mlp_implementation = mlp_implementation
+        if mlp_implementation == "mlp":
+            act = layer_kernels.Activation()
+            if not isinstance(act, GELU):
+                raise NotImplementedError("only GELU activations are fused")
+            layers: list[nn.Module] = [Linear(in_features, hidden_dim), act]
+            for _ in range(n_extra_layers):
+                layers += [Linear(hidden_dim, hidden_dim), layer_kernels.Activation()]
+            layers.append(Linear(hidden_dim, out_features))
+            if final_activation:
+                layers.append(layer_kernels.Activation())
+        else:  # gated variants: layer_kernels.Activation is ignored (mlp.py:88-94)
+            if final_activation:
+                raise NotImplementedError("final_activation with a gated mlp_implementation is not used on the hot path")
+            layers = [GatedMLPLayer(in_features, hidden_dim, layer_kernels, mlp_implementation)]
+            for _ in range(n_extra_layers):
+                layers.append(GatedMLPLayer(hidden_dim, hidden_dim, layer_kernels, mlp_implementation))
+            layers.append(Linear(hidden_dim, out_features))
         self.mlp = nn.Sequential(*layers)
         self.layer_norm = LayerNorm(normalized_shape=out_features) if layer_norm else None
 
@@ -39,6 +69,8 @@ class MLP(nn.Module):
         (LayerNorm if present, else last Linear); ``skip_first``: the caller already applied layer 0 (+GELU) — used by
         GraphConv, whose first edge layer is a gather-add GEMM; ``skip_layer_norm``: caller fuses the LayerNorm."""
         mods = list(self.mlp)
+        if self.mlp_implementation != "mlp":
+            return self._forward_gated(x, mods, x2, residual, skip_layer_norm, skip_first)
         lin_idx = [i for i, m in enumerate(mods) if isinstance(m, nn.Linear)]
         h = x.reshape(-1, x.shape[-1])
         wdt = mods[lin_idx[0]].weight.dtype
@@ -57,6 +89,25 @@ class MLP(nn.Module):
             if last and ln is None and residual is not None:
                 kw["residual"] = residual.reshape(-1, residual.shape[-1])
             h = ops.linear(h, lin.weight, lin.bias, act=act, **kw)
+        if ln is not None:
+            h = ops.layer_norm(h, ln.weight, ln.bias, ln.eps, None if residual is None else residual.reshape(-1, residual.shape[-1]))
+        return h.view(*x.shape[:-1], h.shape[-1])
+
+    def _forward_gated(self, x, mods, x2, residual, skip_layer_norm, skip_first):
+        if skip_first:
+            raise NotImplementedError("GraphConv with a gated edge MLP is not supported (its first layer is a gather-add GEMM)")
+        h = x.reshape(-1, x.shape[-1])
+        wdt = mods[0].gate_proj.weight.dtype
+        if h.dtype != wdt:
+            h = h.to(wdt)
+        ln = None if skip_layer_norm else self.layer_norm
+        for n, m in enumerate(mods[:-1]):
+            h = m(h, x2=x2 if n == 0 else None)
+        last = mods[-1]
+        kw = {}
+        if ln is None and residual is not None:
+            kw["residual"] = residual.reshape(-1, residual.shape[-1])
+        h = ops.linear(h, last.weight, last.bias, **kw)
         if ln is not None:
             h = ops.layer_norm(h, ln.weight, ln.bias, ln.eps, None if residual is None else residual.reshape(-1, residual.shape[-1]))
         return h.view(*x.shape[:-1], h.shape[-1])

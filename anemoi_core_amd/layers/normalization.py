@@ -1,2 +1,2 @@
 """Module path mirror of the reference's ``anemoi.models.layers.normalization``."""
-from .kernels import AutocastLayerNorm, LayerNorm  # noqa: F401
+from .kernels import AutocastLayerNorm, ConditionalLayerNorm, LayerNorm  # noqa: F401

@@ -16,6 +16,9 @@ _ALIASES = {
     "anemoi.models.layers.normalization.AutocastLayerNorm": kernels.AutocastLayerNorm,
     "anemoi_core_amd.layers.normalization.AutocastLayerNorm": kernels.AutocastLayerNorm,
     "anemoi_core_amd.layers.normalization.LayerNorm": kernels.LayerNorm,
+    "anemoi.models.layers.normalization.ConditionalLayerNorm": kernels.ConditionalLayerNorm,
+    "anemoi_core_amd.layers.normalization.ConditionalLayerNorm": kernels.ConditionalLayerNorm,
+    "anemoi_core_amd.layers.kernels.ConditionalLayerNorm": kernels.ConditionalLayerNorm,
     "anemoi_core_amd.layers.kernels.Linear": kernels.Linear,
     "anemoi_core_amd.layers.kernels.LayerNorm": kernels.LayerNorm,
     "anemoi_core_amd.layers.kernels.AutocastLayerNorm": kernels.AutocastLayerNorm,

@@ -241,6 +241,22 @@ def gt_attention_fused_edge(q: Tensor, k: Tensor, v: Tensor, edge_feat: Tensor, 
     return (out, lse) if return_lse else out
 
 
+def cond_layer_norm(x: Tensor, scale: Tensor, shift: Tensor, eps: float = 1e-5) -> Tensor:
+    """y = LayerNorm(x) * (scale + 1) + shift over the last dim, per-row scale / shift [N, D] (column slices allowed)."""
+    if _needs_grad(x, scale, shift):
+        raise NotImplementedError("the backward of ConditionalLayerNorm is not built yet (scope row f3 covers its forward)")
+    _dev(x, scale, shift)
+    D = x.shape[-1]
+    x2 = x.reshape(-1, D)
+    if tuple(scale.shape) != tuple(x2.shape) or tuple(shift.shape) != tuple(x2.shape):
+        raise ValueError("scale / shift must be [rows(x), D]")
+    y = torch.empty((x2.shape[0], D), dtype=x.dtype, device=x.device)
+    (p, ld), (sp, lds), (bp, ldb) = _rows(x2, "x"), _rows(scale, "scale", x.dtype), _rows(shift, "shift", x.dtype)
+    _lib.check(_lib.load().anemoi_cond_layernorm_fwd(p, ld, sp, lds, bp, ldb, y.data_ptr(), D, x2.shape[0], D, float(eps), _dt(x), _stream()),
+               "cond_layernorm_fwd")
+    return y.view(x.shape)
+
+
 def _needs_grad(*tensors) -> bool:
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
@@ -445,6 +461,36 @@ def linear_splitk(a: Tensor, b: Tensor, splits: int) -> Tensor:
     (ap, lda), (bp, ldb) = _rows(a, "a"), _rows(b, "b", a.dtype)
     _lib.check(_lib.load().anemoi_linear_splitk_f32(ap, lda, bp, ldb, y.data_ptr(), Cc, R, Cc, K, int(splits), _dt(a), _stream()), "linear_splitk_f32")
     return y
+
+
+GLU_KINDS = {"glu": 0, "swiglu": 1, "geglu": 2, "reglu": 3}
+
+
+def glu(gate_value: Tensor, kind: str) -> Tensor:
+    """out = act(gate) * value for gate_value = [gate | value] [N, 2D]; kind in GLU_KINDS.  Differentiable."""
+    if _needs_grad(gate_value):
+        from .autograd import GluFunction
+
+        return GluFunction.apply(gate_value, kind)
+    return _glu_fwd(gate_value, kind)
+
+
+def _glu_fwd(gate_value: Tensor, kind: str) -> Tensor:
+    _dev(gate_value)
+    N, D2 = gate_value.shape
+    out = torch.empty((N, D2 // 2), dtype=gate_value.dtype, device=gate_value.device)
+    p, ld = _rows(gate_value, "gate_value")
+    _lib.check(_lib.load().anemoi_glu_fwd(p, ld, out.data_ptr(), D2 // 2, N, D2 // 2, GLU_KINDS[kind], _dt(gate_value), _stream()), "glu_fwd")
+    return out
+
+
+def glu_backward(gate_value: Tensor, d_out: Tensor, kind: str) -> Tensor:
+    _dev(gate_value, d_out)
+    N, D2 = gate_value.shape
+    out = torch.empty((N, D2), dtype=gate_value.dtype, device=gate_value.device)
+    (p, ld), (gp, ldg) = _rows(gate_value, "gate_value"), _rows(d_out, "d_out", gate_value.dtype)
+    _lib.check(_lib.load().anemoi_glu_bwd(p, ld, gp, ldg, out.data_ptr(), D2, N, D2 // 2, GLU_KINDS[kind], _dt(gate_value), _stream()), "glu_bwd")
+    return out
 
 
 def transpose_pad(x: Tensor, mult: int = 64) -> Tensor:

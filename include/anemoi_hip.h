@@ -99,6 +99,12 @@ int anemoi_layernorm_fwd(const void* x, int64_t ldx, const void* gamma, const vo
                          int64_t ldr, void* y, int64_t ldy, int32_t n_rows, int32_t D, float eps, anemoi_dtype_t dtype,
                          void* stream);
 
+/* ConditionalLayerNorm forward (layers/normalization.py:34-94): y = LN(x) * (scale[row] + 1) + shift[row]; scale / shift are
+ * per-row modulation tensors [n_rows, D] (leading dimension 0 = one row for all), e.g. the two halves of one fused
+ * Linear(cond).  No affine parameters of its own. */
+int anemoi_cond_layernorm_fwd(const void* x, int64_t ldx, const void* scale, int64_t lds, const void* shift, int64_t ldsh,
+                              void* y, int64_t ldy, int32_t n_rows, int32_t D, float eps, anemoi_dtype_t dtype, void* stream);
+
 /* LayerNorm backward.  Replaces: autograd of layer_kernels.LayerNorm (layers/utils.py:107-121).
  *   d_x [n_rows, D] (same dtype), d_gamma / d_beta fp32 [D] (either may be NULL; both NULL: no column sums);
  *   workspace: anemoi_reduce_workspace_bytes(D) bytes of fp32 scratch (per-wave partial column sums, added in a fixed
@@ -162,6 +168,14 @@ int anemoi_gather_add_rows(const void* a, int64_t lda, const void* b, int64_t ld
  * dW = dZ^T X (autograd of torch.nn.Linear), whose reduction runs over the rows. */
 int anemoi_transpose_pad(const void* x, int64_t ldx, void* out, int64_t ldo, int32_t n_rows, int32_t n_cols, int32_t n_pad,
                          anemoi_dtype_t dtype, void* stream);
+
+/* Gated feed-forward layers (GatedMLPLayer, layers/mlp.py:25-59): out[r, c] = act(gv[r, c]) * gv[r, D + c], with
+ * gv = [gate_proj(x) | value_proj(x)] from ONE fused projection.  kind: 0 sigmoid ("glu"), 1 SiLU ("swiglu"), 2 GELU erf
+ * ("geglu"), 3 ReLU ("reglu").  anemoi_glu_bwd returns d_gv [n_rows, 2D] = [d_out * value * act'(gate) | d_out * act(gate)]. */
+int anemoi_glu_fwd(const void* gate_value, int64_t ldgv, void* out, int64_t ldo, int32_t n_rows, int32_t D, int32_t kind,
+                   anemoi_dtype_t dtype, void* stream);
+int anemoi_glu_bwd(const void* gate_value, int64_t ldgv, const void* d_out, int64_t lddo, void* d_gate_value, int64_t lddgv,
+                   int32_t n_rows, int32_t D, int32_t kind, anemoi_dtype_t dtype, void* stream);
 
 #ifdef __cplusplus
 }

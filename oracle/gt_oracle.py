@@ -58,17 +58,39 @@ def gelu(x: Tensor) -> Tensor:
     return F.gelu(x)  # exact erf form = torch.nn.GELU default (layers/utils.py:111)
 
 
-def mlp(p: Params, prefix: str, x: Tensor) -> Tensor:
-    """layers/mlp.py:97-179 with mlp_implementation="mlp": Linear, GELU, (Linear, GELU)*, Linear
-    [, LayerNorm].  The Sequential indices of the Linear layers are 0, 2, 4, ... ."""
-    idx = sorted(int(k[len(prefix) + 5:].split(".")[0]) for k in p if k.startswith(prefix + ".mlp.") and k.endswith(".weight"))
-    for n, i in enumerate(idx):
-        x = linear(p, f"{prefix}.mlp.{i}", x)
-        if n < len(idx) - 1:
-            x = gelu(x)
-    if prefix + ".layer_norm.weight" in p:
-        x = layer_norm(p, prefix + ".layer_norm", x)
+_GATING = {"glu": torch.sigmoid, "swiglu": F.silu, "geglu": F.gelu, "reglu": F.relu}
+
+
+def mlp(p: Params, prefix: str, x: Tensor, cond: Optional[Tensor] = None) -> Tensor:
+    """layers/mlp.py:97-179.  mlp_implementation="mlp": Linear, GELU, (Linear, GELU)*, Linear [, LayerNorm]; the Sequential
+    indices of the Linear layers are 0, 2, 4, ... .  Gated variants (mlp.py:25-59, keys ``mlp.<i>.gate_proj/value_proj``):
+    gating(gate_proj(x)) * value_proj(x) per hidden layer, then a plain Linear; the variant name is not recoverable from the
+    parameters, so gated fixtures carry it as p["__mlp_implementation__"]."""
+    pre = prefix + ".mlp."
+    gated = sorted({int(k[len(pre):].split(".")[0]) for k in p if k.startswith(pre) and ".gate_proj.weight" in k})
+    if gated:
+        act = _GATING[p["__mlp_implementation__"]]
+        for i in gated:
+            x = act(linear(p, f"{prefix}.mlp.{i}.gate_proj", x)) * linear(p, f"{prefix}.mlp.{i}.value_proj", x)
+        x = linear(p, f"{prefix}.mlp.{gated[-1] + 1}", x)
+    else:
+        idx = sorted(int(k[len(pre):].split(".")[0]) for k in p if k.startswith(pre) and k.endswith(".weight"))
+        for n, i in enumerate(idx):
+            x = linear(p, f"{prefix}.mlp.{i}", x)
+            if n < len(idx) - 1:
+                x = gelu(x)
+    if prefix + ".layer_norm.weight" in p or prefix + ".layer_norm.scale.weight" in p:
+        x = any_layer_norm(p, prefix + ".layer_norm", x, cond)
     return x
+
+
+def any_layer_norm(p: Params, prefix: str, x: Tensor, cond: Optional[Tensor] = None, eps: float = 1e-5) -> Tensor:
+    """LayerNorm, or ConditionalLayerNorm when the parameters are ``scale.*`` / ``bias.*`` Linears of the conditioning
+    (layers/normalization.py:34-94): LN(x) without affine, times (scale(cond) + 1), plus bias(cond)."""
+    if prefix + ".scale.weight" in p:
+        out = F.layer_norm(x, (x.shape[-1],), None, None, eps)
+        return out * (linear(p, prefix + ".scale", cond) + 1.0) + linear(p, prefix + ".bias", cond)
+    return layer_norm(p, prefix, x, eps)
 
 
 def segment_softmax(alpha: Tensor, index: Tensor, num_segments: int) -> Tensor:
@@ -145,13 +167,15 @@ def gt_attention_part(p: Params, prefix: str, x_src_n: Tensor, x_dst_n: Tensor, 
     return out.reshape(out.shape[0], -1)
 
 
-def gt_processor_block(p: Params, prefix: str, x: Tensor, edge_attr: Tensor, edge_index: Tensor, num_heads: int) -> Tensor:
-    """GraphTransformerProcessorBlock.forward (layers/block.py:1219-1273), single rank."""
-    xn = layer_norm(p, prefix + ".layer_norm_attention", x)
+def gt_processor_block(p: Params, prefix: str, x: Tensor, edge_attr: Tensor, edge_index: Tensor, num_heads: int,
+                       cond: Optional[Tensor] = None) -> Tensor:
+    """GraphTransformerProcessorBlock.forward (layers/block.py:1219-1273), single rank; ``cond`` feeds the layer norms when
+    they are ConditionalLayerNorms."""
+    xn = any_layer_norm(p, prefix + ".layer_norm_attention", x, cond)
     x_r = linear(p, prefix + ".lin_self", xn)
     out = gt_attention_part(p, prefix, xn, xn, edge_attr, edge_index, num_heads)
     out = linear(p, prefix + ".projection", out + x_r) + x
-    return mlp(p, prefix + ".node_dst_mlp", layer_norm(p, prefix + ".layer_norm_mlp_dst", out)) + out
+    return mlp(p, prefix + ".node_dst_mlp", any_layer_norm(p, prefix + ".layer_norm_mlp_dst", out, cond)) + out
 
 
 def gt_mapper_block(p: Params, prefix: str, x_src: Tensor, x_dst: Tensor, edge_attr: Tensor, edge_index: Tensor, num_heads: int):

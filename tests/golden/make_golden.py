@@ -401,9 +401,58 @@ def gen_sharding():
     save("sharding.pt", out)
 
 
+# ----------------------------------------------------------------------------------- scope row f3 variants
+def gen_variants():
+    """Gated MLP variants (layers/mlp.py:25-59) and ConditionalLayerNorm (layers/normalization.py:34-94)."""
+    from anemoi.models.layers.mlp import MLP
+    from anemoi.models.layers.normalization import ConditionalLayerNorm
+
+    gen = torch.Generator().manual_seed(777)
+    lk = load_layer_kernels()
+    out = {"mlp": {}, "block": {}, "cond": {}}
+    torch.manual_seed(5)
+    for kind in ("glu", "swiglu", "geglu", "reglu"):
+        for extra, ln in ((0, True), (1, False)):
+            m = MLP(64, 96, 48, layer_kernels=lk, n_extra_layers=extra, layer_norm=ln, mlp_implementation=kind).eval()
+            _randomise(m, gen)
+            x = torch.randn(70, 64, generator=gen)
+            out["mlp"][f"{kind}_{extra}_{int(ln)}"] = dict(cfg=dict(in_features=64, hidden_dim=96, out_features=48, n_extra_layers=extra, layer_norm=ln,
+                                                                   mlp_implementation=kind), params=_sd(m), x=x, out=m(x).detach())
+    for kind in ("swiglu", "geglu"):
+        C, hid, H = 64, 128, 4
+        blk = GraphTransformerProcessorBlock(in_channels=C, hidden_dim=hid, out_channels=C, num_heads=H, edge_dim=11, layer_kernels=lk,
+                                             graph_attention_backend="pyg", mlp_implementation=kind).eval()
+        _randomise(blk, gen)
+        N, M = 60, 400
+        ei = _rand_graph(gen, N, N, M, (5,))
+        x, ea = torch.randn(N, C, generator=gen), torch.randn(M, 11, generator=gen)
+        y, _ = blk(x, ea, ei, GraphShardInfo(nodes=[N], edges=[M]), 1, N)
+        out["block"][kind] = dict(cfg=dict(in_channels=C, hidden_dim=hid, out_channels=C, num_heads=H, edge_dim=11, mlp_implementation=kind),
+                                  params=_sd(blk), x=x, edge_attr=ea, edge_index=ei, out=y.detach())
+    # ConditionalLayerNorm alone and inside a processor block (layer_kernels.LayerNorm swapped, as a config would)
+    cln = ConditionalLayerNorm(64, condition_shape=16, zero_init=False).eval()
+    _randomise(cln, gen)
+    x, cond = torch.randn(50, 64, generator=gen), torch.randn(50, 16, generator=gen)
+    out["cond"]["layer"] = dict(cfg=dict(normalized_shape=64, condition_shape=16, zero_init=False), params=_sd(cln), x=x, cond=cond,
+                                out=cln(x, cond).detach())
+    lk_c = load_layer_kernels({"LayerNorm": {"_target_": "anemoi.models.layers.normalization.ConditionalLayerNorm", "condition_shape": 16,
+                                             "zero_init": False}})
+    C, hid, H = 64, 128, 4
+    blk = GraphTransformerProcessorBlock(in_channels=C, hidden_dim=hid, out_channels=C, num_heads=H, edge_dim=11, layer_kernels=lk_c,
+                                         graph_attention_backend="pyg").eval()
+    _randomise(blk, gen)
+    N, M = 60, 400
+    ei = _rand_graph(gen, N, N, M, (5,))
+    x, ea, cond = torch.randn(N, C, generator=gen), torch.randn(M, 11, generator=gen), torch.randn(N, 16, generator=gen)
+    y, _ = blk(x, ea, ei, GraphShardInfo(nodes=[N], edges=[M]), 1, N, cond=cond)
+    out["cond"]["block"] = dict(cfg=dict(in_channels=C, hidden_dim=hid, out_channels=C, num_heads=H, edge_dim=11), params=_sd(blk), x=x, edge_attr=ea,
+                                edge_index=ei, cond=cond, out=y.detach())
+    save("variants.pt", out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ["conv", "blocks", "proc", "model", "sharding"]
+    which = sys.argv[1:] or ["conv", "blocks", "proc", "model", "sharding", "variants"]
     if "conv" in which:
         gen_conv()
     if "blocks" in which:
@@ -414,3 +463,5 @@ if __name__ == "__main__":
         gen_model()
     if "sharding" in which:
         gen_sharding()
+    if "variants" in which:
+        gen_variants()

@@ -121,3 +121,27 @@ def test_sharding_math(golden):
             for a, b in zip(h["send_indices"], ref["send_indices"]):
                 assert torch.equal(a, b)
             assert torch.equal(h["edge_index_local"], ref["edge_index_local"])
+
+
+# ---------------------------------------------------------------------------------------------- scope row f3 variants
+def test_gated_mlp_variants_match_reference(golden):
+    for tag, c in golden("variants.pt")["mlp"].items():
+        p = {"m." + k: v for k, v in c["params"].items()}
+        p["__mlp_implementation__"] = c["cfg"]["mlp_implementation"]
+        assert float((O.mlp(p, "m", c["x"]) - c["out"]).abs().max()) < 1e-5, tag
+
+
+def test_gated_and_conditional_blocks_match_reference(golden):
+    v = golden("variants.pt")
+    for kind, c in v["block"].items():
+        p = {"b." + k: t for k, t in c["params"].items()}
+        p["__mlp_implementation__"] = kind
+        got = O.gt_processor_block(p, "b", c["x"], c["edge_attr"], c["edge_index"], c["cfg"]["num_heads"])
+        assert float((got - c["out"]).abs().max()) < 2e-5, kind
+    c = v["cond"]["layer"]
+    p = {"n." + k: t for k, t in c["params"].items()}
+    assert float((O.any_layer_norm(p, "n", c["x"], c["cond"]) - c["out"]).abs().max()) < 1e-5
+    c = v["cond"]["block"]
+    p = {"b." + k: t for k, t in c["params"].items()}
+    got = O.gt_processor_block(p, "b", c["x"], c["edge_attr"], c["edge_index"], c["cfg"]["num_heads"], cond=c["cond"])
+    assert float((got - c["out"]).abs().max()) < 2e-5
