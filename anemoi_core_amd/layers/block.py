@@ -240,9 +240,9 @@ class GraphTransformerProcessorBlock(GraphTransformerBaseBlock):
         A = self.attn_channels
         ln = self.layer_norm_attention
         xn = apply_layer_norm(ln, x, cond)
+        if model_is_distributed(model_comm_group) and self.shard_strategy == "heads":
+            return self._forward_heads(x, xn, edge_attr, edge_index, shard_info, batch_size, model_comm_group, cond, halo_cache), edge_attr
         if model_is_distributed(model_comm_group):
-            if self.shard_strategy != "edges":
-                raise NotImplementedError("shard_strategy='heads' (Ulysses all-to-all) is scope row f2 (next); use 'edges'")
             plan = self._halo_plan(x, edge_index, shard_info, batch_size, model_comm_group, halo_cache)
             x_plus_halo = comm.halo_exchange(xn, plan.send_index, plan.send_counts, plan.recv_counts, model_comm_group,
                                              gather_fn=ops.gather_rows)
@@ -260,6 +260,59 @@ class GraphTransformerProcessorBlock(GraphTransformerBaseBlock):
             csc = get_csc(edge_index, (n, n), edges_are_dst_sorted)
         out = self._attention(q, k, v, x_r, edge_attr, csc)
         return self._post_attention(out, x, cond), edge_attr
+
+
+    # -- heads ("Ulysses") strategy: reference block.py:689-759, 838-854 ----------------------------------------------
+    def _forward_heads(self, x, xn, edge_attr, edge_index, shard_info, batch_size, group, cond, cache: Optional[dict]):
+        """Nodes sharded for the dense work, HEADS sharded for the attention: q/k/v of the local rows are transposed by one
+        all-to-all each into all rows x (H / P) heads, the attention runs on the whole graph for this rank's heads, and a
+        fourth all-to-all brings the local rows back with all heads.  Unlike the reference the edge term is not moved at
+        all (there: a fourth [M, H*C] transpose per layer): the static edge attributes of the other ranks are gathered
+        once, and the fused-edge kernel applies this rank's rows of ``lin_edge``."""
+        if batch_size != 1:
+            raise ValueError("shard_strategy='heads' requires batch_size=1 when model sharding is enabled.")
+        P, rank = comm_size(group), comm_rank(group)
+        H, C, A = self.num_heads, self.out_channels_conv, self.attn_channels
+        if H % P:
+            raise ValueError(f"shard_strategy='heads': num_heads ({H}) must be divisible by the model-parallel size ({P})")
+        if ops._needs_grad(xn, self.lin_edge.weight):
+            raise NotImplementedError("the backward of the heads strategy is not built; train with shard_strategy='edges'")
+        Hl, sizes = H // P, list(shard_info.nodes)
+        n_loc, n_full = xn.shape[0], sum(sizes)
+        # the whole graph (static): edge slices are dst-owned and contiguous, so rank order = global dst-sorted order
+        key = (edge_index.data_ptr(), version(edge_index), edge_attr.data_ptr(), version(edge_attr), P, rank)
+        full = None if cache is None else cache.get("heads_full")
+        if full is None or full[0] != key:
+            if shard_info.edges_are_sharded():
+                ei_full = comm.gather_tensor(edge_index.t().contiguous(), 0, shard_info.edges, group).t().contiguous()
+                ea_full = comm.gather_tensor(edge_attr.contiguous(), 0, shard_info.edges, group)
+            else:
+                ei_full, ea_full = edge_index, edge_attr
+            full = (key, ei_full, ea_full, (edge_index, edge_attr))
+            if cache is not None:
+                cache["heads_full"] = full
+        _, ei_full, ea_full, _ = full
+        csc = get_csc(ei_full, (n_full, n_full), True)
+
+        def to_heads(t):  # [n_loc, A] all heads -> [n_full, Hl*C] my heads
+            send = t.reshape(n_loc, P, Hl * C).permute(1, 0, 2).reshape(P * n_loc, Hl * C)
+            return comm.all_to_all_rows(send, [n_loc] * P, sizes, group)
+
+        w, b = self._fused.get("qkvs", [self.lin_query, self.lin_key, self.lin_value, self.lin_self])
+        qkvs = ops.linear(xn, w, b)
+        q, k, v = (to_heads(qkvs[:, i * A:(i + 1) * A]) for i in range(3))
+        x_r = qkvs[:, 3 * A:]
+        if self.qk_norm:  # per-head LayerNorm over C: applied to this rank's heads (block.py:748)
+            q = self.q_norm(q.reshape(-1, Hl, C)).view(-1, Hl * C)
+            k = self.k_norm(k.reshape(-1, Hl, C)).view(-1, Hl * C)
+        if not isinstance(self.edge_pre_mlp, nn.Identity):
+            raise NotImplementedError("edge_pre_mlp with shard_strategy='heads'")
+        feat = get_edge_features(ea_full, csc.perm)
+        w_edge = self._fused.packed_edge(self.lin_edge)[rank * Hl * C:(rank + 1) * Hl * C]
+        o = ops.gt_attention_fused_edge(q, k, v, feat, w_edge, csc, Hl)  # [n_full, Hl*C]
+        back = comm.all_to_all_rows(o, sizes, [n_loc] * P, group)  # [P*n_loc, Hl*C]: block r = heads of rank r
+        out = back.reshape(P, n_loc, Hl * C).permute(1, 0, 2).reshape(n_loc, A) + x_r
+        return self._post_attention(out, x, cond)
 
 
 class HaloPlan:

@@ -135,3 +135,24 @@ def test_sharded_backward_on_hip_kernels_matches_oracle_gradients(kind):
             assert float((got - ref).abs().max()) <= 3e-4 * float(ref.abs().max()) + 1e-6, k
             checked += 1
         assert checked >= 60
+
+
+def _heads_worker(rank, world, group):
+    from anemoi_core_amd.distributed.primitives import shard_tensor
+    from anemoi_core_amd.distributed.shapes import GraphShardInfo, get_shard_sizes
+    from anemoi_core_amd.layers.processor import GraphTransformerProcessor
+
+    s = load_golden("sharding.pt")
+    proc = GraphTransformerProcessor(**{**s["cfg"], "shard_strategy": "heads"}).eval().cuda()
+    proc.load_state_dict(s["params"], strict=True)
+    x, ea, ei = s["x"].cuda(), s["edge_attr"].cuda(), s["edge_index"].cuda()
+    sizes = get_shard_sizes(x, 0, group)
+    with torch.no_grad():
+        y = proc(shard_tensor(x, 0, sizes, group), 1, GraphShardInfo(nodes=sizes, edges=None), ea, ei, model_comm_group=group)
+    return dict(out=y.cpu())
+
+
+def test_heads_strategy_on_hip_kernels_equals_unsharded_reference():
+    s = load_golden("sharding.pt")
+    outs = _spawn(_heads_worker, 2)
+    assert float((torch.cat([o["out"] for o in outs]) - s["out"]).abs().max()) < 1e-4
