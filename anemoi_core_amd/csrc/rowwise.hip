@@ -166,6 +166,38 @@ __global__ __launch_bounds__(64 * kRowWaves) void gather_rows_kernel(const T* __
   }
 }
 
+// Output boundings at the model edge (reference layers/bounding.py:81-307), all configured boundings in ONE pass: a thread
+// owns a row and applies the column program in order (ops: int32 [n_ops][4] = kind, column, total column, unused;
+// params: fp32 [n_ops][2] = min / max or the normalised minimum).  kind: 1 relu, 2 leaky relu, 3 relu above a minimum,
+// 4 leaky relu above a minimum, 5 hardtanh, 6 leaky hardtanh, 7 hardtanh * x[total], 8 leaky hardtanh * x[total]
+// (slopes 0.01 as in torch / layers/activations.py:16-42).
+template <typename T>
+__global__ void bound_columns_kernel(T* __restrict__ x, int64_t ldx, int n_rows, const int32_t* __restrict__ ops,
+                                     const float* __restrict__ params, int n_ops) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rows) return;
+  T* row = x + (int64_t)r * ldx;
+  for (int i = 0; i < n_ops; ++i) {
+    const int kind = ops[4 * i], col = ops[4 * i + 1], tot = ops[4 * i + 2];
+    const float p0 = params[2 * i], p1 = params[2 * i + 1];
+    float v = to_float(row[col]);
+    auto leaky = [](float t) { return t > 0.f ? t : 0.01f * t; };
+    auto lht = [&](float t) { return t < p0 ? p0 + 0.01f * (t - p0) : (t > p1 ? p1 + 0.01f * (t - p1) : t); };
+    switch (kind) {
+      case 1: v = fmaxf(v, 0.f); break;
+      case 2: v = leaky(v); break;
+      case 3: v = fmaxf(v - p0, 0.f) + p0; break;
+      case 4: v = leaky(v - p0) + p0; break;
+      case 5: v = fminf(fmaxf(v, p0), p1); break;
+      case 6: v = lht(v); break;
+      case 7: v = to_float(from_float<T>(fminf(fmaxf(v, p0), p1))) * to_float(row[tot]); break;
+      case 8: v = to_float(from_float<T>(lht(v))) * to_float(row[tot]); break;
+      default: break;
+    }
+    row[col] = from_float<T>(v);
+  }
+}
+
 // Pick the widest vector width (in elements) such that rows stay 16-byte-or-narrower aligned and D % VEC == 0.
 template <typename T>
 static int pick_vec(int D, std::initializer_list<int64_t> lds, std::initializer_list<const void*> ptrs) {
@@ -329,4 +361,20 @@ extern "C" int anemoi_cond_layernorm_fwd(const void* x, int64_t ldx, const void*
     case ANEMOI_F16: return cond_layernorm_launch<f16_t>(x, ldx, scale, lds, shift, ldsh, y, ldy, n_rows, D, eps, st);
     default: set_error("unknown dtype"); return ANEMOI_E_INVALID;
   }
+}
+
+extern "C" int anemoi_bound_columns(void* x, int64_t ldx, int32_t n_rows, int32_t n_cols, const int32_t* ops, const float* params,
+                                    int32_t n_ops, anemoi_dtype_t dtype, void* stream) {
+  ANEMOI_REQUIRE(n_rows >= 0 && n_cols > 0 && ldx >= n_cols && n_ops >= 0, "bound_columns: bad sizes");
+  if (n_rows == 0 || n_ops == 0) return ANEMOI_OK;
+  ANEMOI_REQUIRE(x && ops && params, "bound_columns: null pointer");
+  const dim3 grid((n_rows + 255) / 256), block(256);
+  hipStream_t st = as_stream(stream);
+  switch (dtype) {
+    case ANEMOI_F32: hipLaunchKernelGGL((bound_columns_kernel<float>), grid, block, 0, st, (float*)x, ldx, n_rows, ops, params, n_ops); break;
+    case ANEMOI_BF16: hipLaunchKernelGGL((bound_columns_kernel<bf16_t>), grid, block, 0, st, (bf16_t*)x, ldx, n_rows, ops, params, n_ops); break;
+    case ANEMOI_F16: hipLaunchKernelGGL((bound_columns_kernel<f16_t>), grid, block, 0, st, (f16_t*)x, ldx, n_rows, ops, params, n_ops); break;
+    default: set_error("unknown dtype"); return ANEMOI_E_INVALID;
+  }
+  return check_launch("bound_columns_kernel");
 }

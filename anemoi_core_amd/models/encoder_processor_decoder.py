@@ -14,6 +14,7 @@ from typing import Optional
 import torch
 from torch import Tensor, nn
 
+from .. import ops
 from ..distributed.primitives import shard_tensor
 from ..distributed.shapes import BipartiteGraphShardInfo, GraphShardInfo, comm_size, get_shard_sizes
 from ..layers.graph import NamedNodesAttributes
@@ -78,7 +79,8 @@ class AnemoiModelEncProcDec(nn.Module):
         self._build_networks(mc, edges)
         res = mc.get("residual", {}) or {}
         self._skip_step = int(res.get("step", -1))
-        self._relu_bounding_idx = self._build_boundings(mc.get("bounding", []) or [])
+        self.boundings = self._build_boundings(mc.get("bounding", []) or [])
+        self._bound_tables: dict = {}
 
     # -- shapes (models/base.py:96-150) -------------------------------------------------------------------
     def _calculate_shapes_and_indices(self, data_indices: dict) -> None:
@@ -125,14 +127,15 @@ class AnemoiModelEncProcDec(nn.Module):
                                            in_channels_dst=self.target_dim[ds], hidden_dim=self.num_channels,
                                            out_channels_dst=self.output_dim[ds], edge_dim=self.decoder_graph_provider[ds].edge_dim)
 
-    def _build_boundings(self, cfgs) -> dict:
-        out = {ds: [] for ds in self.dataset_names}
-        for c in cfgs:
-            if not str(c.get("_target_", "")).endswith("ReluBounding"):
-                raise NotImplementedError("only ReluBounding is supported at the model edge (scope row f4)")
-            for ds in self.dataset_names:
-                names = self.data_indices[ds].model.output.name_to_index
-                out[ds] += [names[v] for v in c["variables"]]
+    def _build_boundings(self, cfgs) -> nn.ModuleDict:
+        """models/base.py:94-97 / layers/bounding.py:312-400: one ModuleList per dataset, configuration order."""
+        from ..layers.bounding import build_boundings_for
+
+        out = nn.ModuleDict()
+        for ds in self.dataset_names:
+            stats = self.statistics.get(ds) if isinstance(self.statistics, dict) else self.statistics
+            out[ds] = build_boundings_for(cfgs, self.data_indices[ds].model.output.name_to_index, stats,
+                                          self.data_indices[ds].data.input.name_to_index)
         return out
 
     # -- glue (encoder_processor_decoder.py:98-163) ---------------------------------------------------------
@@ -150,9 +153,17 @@ class AnemoiModelEncProcDec(nn.Module):
         x_out = x_out.view(batch_size, ensemble_size, N, self.n_step_output, -1).permute(0, 3, 1, 2, 4).to(dtype=dtype).clone()
         in_idx, out_idx = getattr(self, f"_in_idx_{ds}"), getattr(self, f"_out_idx_{ds}")
         x_out.index_add_(-1, out_idx, x_skip.unsqueeze(1).index_select(-1, in_idx).to(dtype))
-        if self._relu_bounding_idx[ds]:
-            idx = torch.as_tensor(self._relu_bounding_idx[ds], device=x_out.device)
-            x_out[..., idx] = torch.relu(x_out[..., idx])
+        if len(self.boundings[ds]):  # all configured boundings as ONE in-place column program (configuration order)
+            from ..layers.bounding import apply_program_torch, program_tables
+
+            prog = [op for b in self.boundings[ds] for op in b.program()]
+            if torch.is_grad_enabled() and x_out.requires_grad:
+                x_out = apply_program_torch(x_out, prog)
+            else:
+                key = (ds, str(x_out.device))
+                if key not in self._bound_tables:
+                    self._bound_tables[key] = program_tables(prog, x_out.device)
+                ops.bound_columns_(x_out, *self._bound_tables[key])
         return x_out
 
     def forward(self, x: dict, *, model_comm_group=None, grid_shard_sizes: Optional[dict] = None, **kwargs) -> dict:

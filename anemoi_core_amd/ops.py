@@ -493,6 +493,17 @@ def glu_backward(gate_value: Tensor, d_out: Tensor, kind: str) -> Tensor:
     return out
 
 
+def bound_columns_(x: Tensor, op_table: Tensor, param_table: Tensor) -> Tensor:
+    """In place: apply the column program (int32 [n_ops, 4], fp32 [n_ops, 2]; see anemoi_bound_columns) to x [..., V]."""
+    _dev(x, op_table, param_table)
+    if not x.is_contiguous():
+        raise ValueError("bound_columns_: x must be contiguous")
+    V = x.shape[-1]
+    _lib.check(_lib.load().anemoi_bound_columns(x.data_ptr(), V, x.numel() // V, V, op_table.data_ptr(), param_table.data_ptr(),
+                                                op_table.shape[0], _dt(x), _stream()), "bound_columns")
+    return x
+
+
 def transpose_pad(x: Tensor, mult: int = 64) -> Tensor:
     """[N, C] -> contiguous [C, N_pad] with N_pad = N rounded up to ``mult`` and zeros in the padding."""
     _dev(x)

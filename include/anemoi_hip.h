@@ -105,6 +105,13 @@ int anemoi_layernorm_fwd(const void* x, int64_t ldx, const void* gamma, const vo
 int anemoi_cond_layernorm_fwd(const void* x, int64_t ldx, const void* scale, int64_t lds, const void* shift, int64_t ldsh,
                               void* y, int64_t ldy, int32_t n_rows, int32_t D, float eps, anemoi_dtype_t dtype, void* stream);
 
+/* Output boundings at the model edge, in place and in configuration order (layers/bounding.py:81-307;
+ * models/encoder_processor_decoder.py:160-162).  ops: int32 [n_ops][4] = (kind, column, total column, 0); params: fp32
+ * [n_ops][2].  kind 1 ReluBounding, 2 LeakyReluBounding, 3 / 4 Normalized(Leaky)ReluBounding (params[0] = the normalised
+ * minimum), 5 / 6 (Leaky)HardtanhBounding (min, max), 7 / 8 (Leaky)FractionBounding (min, max; times column ``total``). */
+int anemoi_bound_columns(void* x, int64_t ldx, int32_t n_rows, int32_t n_cols, const int32_t* ops, const float* params,
+                         int32_t n_ops, anemoi_dtype_t dtype, void* stream);
+
 /* LayerNorm backward.  Replaces: autograd of layer_kernels.LayerNorm (layers/utils.py:107-121).
  *   d_x [n_rows, D] (same dtype), d_gamma / d_beta fp32 [D] (either may be NULL; both NULL: no column sums);
  *   workspace: anemoi_reduce_workspace_bytes(D) bytes of fp32 scratch (per-wave partial column sums, added in a fixed

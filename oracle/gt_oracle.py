@@ -318,6 +318,50 @@ def enc_proc_dec_forward(p: Params, cfg: dict, graph, x: Tensor) -> Tensor:
 
 
 # ------------------------------------------------------------------------------------------ sharding math (integer)
+def apply_boundings(x: Tensor, specs: list, name_to_index: dict, statistics: Optional[dict] = None,
+                    name_to_index_stats: Optional[dict] = None) -> Tensor:
+    """Output boundings in configuration order (layers/bounding.py:81-307; applied at
+    models/encoder_processor_decoder.py:160-162).  specs: [(class name, kwargs)]."""
+    x = x.clone()
+
+    def idx(variables):  # BaseBounding._create_index: order of name_to_index
+        return [i for n, i in name_to_index.items() if n in variables]
+
+    def lht(v, lo, hi):  # layers/activations.py:16-42
+        y = torch.clamp(v, lo, hi)
+        y = torch.where(v < lo, lo + 0.01 * (v - lo), y)
+        return torch.where(v > hi, hi + 0.01 * (v - hi), y)
+
+    for cls, kw in specs:
+        if cls in ("NormalizedReluBounding", "NormalizedLeakyReluBounding"):
+            kept = [(i, v) for i, v in enumerate(kw["variables"]) if v in name_to_index]
+            cols = [name_to_index[v] for _, v in kept]  # configuration order (bounding.py:151)
+            mins = []
+            for i, v in kept:
+                si, how, m = name_to_index_stats[v], kw["normalizer"][i], kw["min_val"][i]
+                st = {k: float(t[si]) for k, t in statistics.items()}
+                mins.append({"mean-std": (m - st["mean"]) / st["stdev"], "min-max": (m - st["min"]) / (st["max"] - st["min"]),
+                             "max": m / st["max"], "std": m / st["stdev"]}[how])
+            nm = torch.tensor(mins, dtype=torch.float32)
+            f = F.relu if cls == "NormalizedReluBounding" else F.leaky_relu
+            x[..., cols] = f(x[..., cols] - nm) + nm
+            continue
+        cols = idx(kw["variables"])
+        if cls == "ReluBounding":
+            x[..., cols] = F.relu(x[..., cols])
+        elif cls == "LeakyReluBounding":
+            x[..., cols] = F.leaky_relu(x[..., cols])
+        elif cls in ("HardtanhBounding", "FractionBounding"):
+            x[..., cols] = F.hardtanh(x[..., cols], kw["min_val"], kw["max_val"])
+        elif cls in ("LeakyHardtanhBounding", "LeakyFractionBounding"):
+            x[..., cols] = lht(x[..., cols], kw["min_val"], kw["max_val"])
+        else:
+            raise ValueError(cls)
+        if cls.endswith("FractionBounding"):
+            x[..., cols] = x[..., cols] * x[..., idx([kw["total_var"]])]
+    return x
+
+
 def balanced_partition_sizes(total: int, parts: int) -> list:
     """distributed/balanced_partition.py:16-41."""
     base, rem = divmod(total, parts)

@@ -447,6 +447,30 @@ def gen_variants():
     y, _ = blk(x, ea, ei, GraphShardInfo(nodes=[N], edges=[M]), 1, N, cond=cond)
     out["cond"]["block"] = dict(cfg=dict(in_channels=C, hidden_dim=hid, out_channels=C, num_heads=H, edge_dim=11), params=_sd(blk), x=x, edge_attr=ea,
                                 edge_index=ei, cond=cond, out=y.detach())
+    # output boundings (layers/bounding.py:81-307), applied in config order on one tensor
+    from anemoi.models.layers import bounding as B
+
+    names = [f"v{i}" for i in range(10)]
+    n2i = {n: i for i, n in enumerate(names)}
+    n2i_stats = {n: i + 1 for i, n in enumerate(names)}  # statistics are indexed by the DATA input index: different on purpose
+    stats = {k: torch.rand(12, generator=gen).double().numpy() + (1.0 if k in ("stdev", "max") else 0.0) for k in ("mean", "stdev", "min", "max")}
+    stats["max"] = stats["min"] + stats["max"]
+    specs = [
+        ("ReluBounding", dict(variables=["v0", "v3"])),
+        ("LeakyReluBounding", dict(variables=["v1"])),
+        ("NormalizedReluBounding", dict(variables=["v2", "v4"], min_val=[0.1, -0.2], normalizer=["mean-std", "min-max"])),
+        ("NormalizedLeakyReluBounding", dict(variables=["v5", "v9"], min_val=[0.3, 0.0], normalizer=["max", "std"])),
+        ("HardtanhBounding", dict(variables=["v6"], min_val=-0.5, max_val=0.7)),
+        ("LeakyHardtanhBounding", dict(variables=["v7"], min_val=0.0, max_val=1.0)),
+        ("FractionBounding", dict(variables=["v8"], min_val=0.0, max_val=1.0, total_var="v0")),
+        ("LeakyFractionBounding", dict(variables=["v1"], min_val=0.0, max_val=1.0, total_var="v3")),
+    ]
+    x = 1.5 * torch.randn(200, 10, generator=gen)
+    y = x.clone()
+    for cls, kw in specs:
+        y = getattr(B, cls)(name_to_index=n2i, statistics=stats, name_to_index_stats=n2i_stats, **kw)(y)
+    out["bounding"] = dict(specs=specs, name_to_index=n2i, name_to_index_stats=n2i_stats,
+                           statistics={k: torch.as_tensor(v) for k, v in stats.items()}, x=x, out=y)
     save("variants.pt", out)
 
 

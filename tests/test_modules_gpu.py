@@ -216,3 +216,26 @@ def test_gated_and_conditional_processor_blocks_match_reference(golden):
     with torch.no_grad():
         got, _ = blk(c["x"].to(DEV), c["edge_attr"].to(DEV), c["edge_index"].to(DEV), GraphShardInfo(), 1, c["x"].shape[0], cond=c["cond"].to(DEV))
     assert float((got.cpu() - c["out"]).abs().max()) < 1e-4
+
+
+def test_boundings_kernel_matches_reference(golden):
+    """All configured boundings as one in-place column program (anemoi_bound_columns) == the reference's sequence of
+    indexed read-modify-writes (fixture generated from layers/bounding.py); bf16 within one rounding."""
+    from anemoi_core_amd import ops
+    from anemoi_core_amd.layers.bounding import build_boundings_for, program_tables
+
+    c = golden("variants.pt")["bounding"]
+    cfgs = [dict(_target_=f"anemoi.models.layers.bounding.{cls}", **kw) for cls, kw in c["specs"]]
+    mods = build_boundings_for(cfgs, c["name_to_index"], c["statistics"], c["name_to_index_stats"])
+    prog = [op for m in mods for op in m.program()]
+    x = c["x"].to(DEV).clone()
+    ops.bound_columns_(x, *program_tables(prog, DEV))
+    assert float((x.cpu() - c["out"]).abs().max()) < 1e-6
+    y = c["x"].to(DEV)
+    for m in mods.to(DEV):  # module-by-module, as a user of the classes would call them
+        y = m(y)
+    assert float((y.cpu() - c["out"]).abs().max()) < 1e-6
+    xb = c["x"].to(torch.bfloat16).to(DEV)
+    ops.bound_columns_(xb, *program_tables(prog, DEV))
+    want = O.apply_boundings(c["x"].to(torch.bfloat16).float(), c["specs"], c["name_to_index"], c["statistics"], c["name_to_index_stats"])
+    assert float((xb.float().cpu() - want).abs().max()) <= 2e-2 * float(want.abs().max())

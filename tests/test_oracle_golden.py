@@ -145,3 +145,16 @@ def test_gated_and_conditional_blocks_match_reference(golden):
     p = {"b." + k: t for k, t in c["params"].items()}
     got = O.gt_processor_block(p, "b", c["x"], c["edge_attr"], c["edge_index"], c["cfg"]["num_heads"], cond=c["cond"])
     assert float((got - c["out"]).abs().max()) < 2e-5
+
+
+def test_boundings_match_reference(golden):
+    c = golden("variants.pt")["bounding"]
+    got = O.apply_boundings(c["x"], c["specs"], c["name_to_index"], c["statistics"], c["name_to_index_stats"])
+    assert float((got - c["out"]).abs().max()) < 1e-6
+    # host logic of the product classes: their column programs, evaluated with torch, give the same result
+    from anemoi_core_amd.layers.bounding import apply_program_torch, build_boundings_for
+
+    cfgs = [dict(_target_=f"anemoi.models.layers.bounding.{cls}", **kw) for cls, kw in c["specs"]]
+    mods = build_boundings_for(cfgs, c["name_to_index"], c["statistics"], c["name_to_index_stats"])
+    prog = [op for m in mods for op in m.program()]
+    assert float((apply_program_torch(c["x"], prog) - c["out"]).abs().max()) < 1e-6
