@@ -220,6 +220,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void gt_attn_fused_edge_fwd
       Raw kb[PF], vb[PF];
       float fb[PF][FE_PAD];
       auto fetch = [&](int j, Raw& kr, Raw& vr, float (&fr)[FE_PAD]) {
+        j = min(j, n - 1);  // refills past the end re-read the last edge: an UNCONDITIONAL load keeps the ring registers
+                            // free of select/copy code (a conditional one made the compiler wait for the load at once)
         const int s = __builtin_amdgcn_readlane(my_src, j);
         kr = *reinterpret_cast<const Raw*>(k + (int64_t)s * ldk + c0);
         vr = *reinterpret_cast<const Raw*>(v + (int64_t)s * ldv + c0);
@@ -228,8 +230,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void gt_attn_fused_edge_fwd
         for (int f = 0; f < FE_PAD; ++f) fr[f] = a[f];
       };
 #pragma unroll
-      for (int st = 0; st < PF; ++st)
-        if (st < n) fetch(st, kb[st], vb[st], fb[st]);
+      for (int st = 0; st < PF; ++st) fetch(st, kb[st], vb[st], fb[st]);
       for (int j0 = 0; j0 < n; j0 += PF) {
 #pragma unroll
         for (int st = 0; st < PF; ++st) {
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void gt_attn_fused_edge_fwd
             for (int jj = 0; jj < VEC; ++jj) acc[jj] = fmaf(p, to_float(vb[st].v[jj]), acc[jj]);
 #pragma unroll
             for (int f = 0; f < FE_PAD; ++f) sf[f] = fmaf(p, fb[st][f], sf[f]);
-            if (j + PF < n) fetch(j + PF, kb[st], vb[st], fb[st]);
+            fetch(j + PF, kb[st], vb[st], fb[st]);
           }
         }
       }
