@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "liba
 
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_GELU = 0, 1
+E_INVALID, E_UNSUPPORTED, E_LAUNCH = -1, -2, -3
 
 _p, _i64, _i32, _f = C.c_void_p, C.c_int64, C.c_int32, C.c_float
 
@@ -35,6 +36,8 @@ SIGNATURES = {
     "anemoi_bound_columns": ([_p, _i64, _i32, _i32, _p, _p, _i32, C.c_int, _p], C.c_int),
     "anemoi_layernorm_fwd": ([_p, _i64, _p, _p, _p, _i64, _p, _i64, _i32, _i32, _f, C.c_int, _p], C.c_int),
     "anemoi_linear_splitk_f32": ([_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, _i32, C.c_int, _p], C.c_int),
+    "anemoi_linear_stats_fwd": ([_p, _i64, _i32, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i32, _i32, C.c_int, _p], C.c_int),
+    "anemoi_linear_lnfold_fwd": ([_p, _i64, _i32, _p, _i64, _p, _p, _p, _i32, _f, C.c_int, _p, _i64, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_linear_fwd": ([_p, _i64, _i32, _p, _i64, _i32, _p, _i64, _p, _p, _i64, _p, _p, _i64, _p, _p, _i64, _p, _i64, _i32, _i32, C.c_int, C.c_int, _p], C.c_int),
     "anemoi_edge_ln_residual_segment_sum_fwd": ([_p, _i64, _p, _i64, _p, _p, _f, _p, _p, _i64, _p, _i64, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_segment_sum_rows": ([_p, _i64, _p, _p, _p, _i64, _i32, _i32, C.c_int, _p], C.c_int),

@@ -45,6 +45,14 @@ struct LinArgs {
   int O;
   int act;
   int splits = 1;     // persistent kernel only: split-K (see tile_origin)
+  // LayerNorm fold (inference): a producer GEMM leaves per-row partial sums of its OUTPUT, the consumer GEMM applies the
+  // normalisation of its INPUT rows in the epilogue:  LN(x) W^T = rstd (x (W gamma)^T - mean c) + d
+  float* stats_out = nullptr;       // [n_rows][O / 64][2] fp32: sum and sum of squares of every 64-column strip (EPI_STATS)
+  const float* stats_in = nullptr;  // [n_rows][ln_strips][2] of the input rows (EPI_LNFOLD)
+  const float* ln_c = nullptr;      // [O] row sums of the gamma-scaled weight
+  const float* ln_d = nullptr;      // [O] W beta + bias
+  int ln_strips = 0, ln_D = 0;
+  float ln_eps = 0.f;
   int f32_atomic = 0; // persistent kernel only: y is fp32 and accumulated with atomics (caller zeroes it)
   int tail_rows = 0;  // big-tile kernel only: rows [n_rows, n_rows + tail_rows) are computed on the VALU, a column per wave
 };
@@ -328,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(LinArgs a, int tile
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
-enum : int { EPI_RES = 1, EPI_GATHER = 2, EPI_GELU = 4 };
+enum : int { EPI_RES = 1, EPI_GATHER = 2, EPI_GELU = 4, EPI_STATS = 8, EPI_LNFOLD = 16 };
 
 // acc[mi][ni][r] = out[m0 + wr*64 + mi*16 + (lane & 15)][n0 + wc*64 + ni*16 + (lane>>4)*4 + r]
 // epi: this wave's 4 KiB LDS slice (16 rows x 256 B); one 16-row band (mi) at a time.  The band is written in the MFMA
@@ -340,7 +348,7 @@ constexpr int kEpiStores = 8;
 
 template <typename T, int EPI, int MI = 4>
 __device__ __forceinline__ void mfma_epilogue_band(const LinArgs& a, f32x4 (&acc)[MI][4], int m0, int n0, int wr, int wc,
-                                                   int lane, unsigned char* epi, bool interior) {
+                                                   int lane, unsigned char* epi, bool interior, const float* ln_rows = nullptr) {
   const T* __restrict__ bias = (const T*)a.bias;
   T* __restrict__ y = (T*)a.y;
   using V8 = Vec<T, 8>;
@@ -366,9 +374,32 @@ __device__ __forceinline__ void mfma_epilogue_band(const LinArgs& a, f32x4 (&acc
 #pragma unroll
     for (int r = 0; r < 8; ++r) bv[r] = to_float(braw.v[r]);
   }
+  float lc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if constexpr ((EPI & EPI_LNFOLD) != 0) {  // O % 8 == 0 on this path: c and d (fp32) for this lane's 8 columns
+    if (ncols == 8) {
+      const f32x4 c0 = *reinterpret_cast<const f32x4*>(a.ln_c + nc), c1 = *reinterpret_cast<const f32x4*>(a.ln_c + nc + 4);
+      const f32x4 d0 = *reinterpret_cast<const f32x4*>(a.ln_d + nc), d1 = *reinterpret_cast<const f32x4*>(a.ln_d + nc + 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        lc[r] = c0[r];
+        lc[4 + r] = c1[r];
+        bv[r] = d0[r];  // d already contains the bias
+        bv[4 + r] = d1[r];
+      }
+    }
+  }
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     V8 rv[2], t1[2], t2[2];
+    float ln_mu[2] = {0.f, 0.f}, ln_rs[2] = {1.f, 1.f};
+    if constexpr ((EPI & EPI_LNFOLD) != 0) {  // mean / rstd of this tile's rows were put into LDS at the start of the tile
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int rl = wr * (16 * MI) + (lane >> 3) + mi * 16 + it * 8;
+        ln_mu[it] = ln_rows[2 * rl];
+        ln_rs[it] = ln_rows[2 * rl + 1];
+      }
+    }
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int m = mrow0 + mi * 16 + it * 8;
@@ -410,8 +441,13 @@ __device__ __forceinline__ void mfma_epilogue_band(const LinArgs& a, f32x4 (&acc
       const int m = mrow0 + mi * 16 + it * 8;
       const bool ok = (interior || m < a.n_rows) && ncols > 0;
       float vv[8];
+      if constexpr ((EPI & EPI_LNFOLD) != 0) {
 #pragma unroll
-      for (int r = 0; r < 8; ++r) vv[r] = c[it][r >> 2][r & 3] + bv[r];
+        for (int r = 0; r < 8; ++r) vv[r] = fmaf(ln_rs[it], fmaf(-ln_mu[it], lc[r], c[it][r >> 2][r & 3]), bv[r]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) vv[r] = c[it][r >> 2][r & 3] + bv[r];
+      }
       if constexpr ((EPI & EPI_GATHER) != 0) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) vv[r] += to_float(t1[it].v[r]) + to_float(t2[it].v[r]);
@@ -434,6 +470,24 @@ __device__ __forceinline__ void mfma_epilogue_band(const LinArgs& a, f32x4 (&acc
         V8 o8;
 #pragma unroll
         for (int r = 0; r < 8; ++r) o8.v[r] = from_float<T>(vv[r]);
+        if constexpr ((EPI & EPI_STATS) != 0) {
+          // sums of what is actually stored (rounded), over this wave's 64-column strip of the row: the 8 lanes that
+          // share the row are adjacent -> DPP butterfly, one plain store per (row, strip): no atomics, every slot written
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const float t = (r < ncols) ? to_float(o8.v[r]) : 0.f;
+            s1 += t;
+            s2 = fmaf(t, t, s2);
+          }
+          s1 = group_sum<8>(s1);
+          s2 = group_sum<8>(s2);
+          if (cp == 0) {
+            float* so = a.stats_out + ((int64_t)m * (a.O >> 6) + ((n0 + wc * 64) >> 6)) * 2;
+            so[0] = s1;
+            so[1] = s2;
+          }
+        }
         if (ncols == 8) {
           *reinterpret_cast<V8*>(dst) = o8;
         } else {
@@ -641,7 +695,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void linear_mfma_persistent_kernel
       mfma_epilogue_band<T, EPI>(a, acc, m0, n0, wr, wc, lane, smem + ((g - 1) % STAGES) * kStageBytes + wave * 4096, interior);
       // An interior tile issues exactly kEpiStores stores per wave, and every load of its epilogue has been consumed
       // (waited for, with everything older) before the last store was issued.  Edge tiles predicate their stores.
-      if (interior && nk >= STAGES && !a.f32_atomic)
+      if (interior && nk >= STAGES && !a.f32_atomic && (EPI & EPI_STATS) == 0)  // the statistics add stores: drain instead of counting
         counted_stores = true;
       else
         drain_all = true;
@@ -687,8 +741,22 @@ __device__ __forceinline__ void tail_rows_valu(const LinArgs& a, int m_begin, in
         }
       }
       acc = wave_sum(acc);
+      float ln_mu = 0.f, ln_rs = 1.f;
+      if (a.stats_in) {  // strip sums of the row: one strip per lane + butterfly instead of a serial walk in lane 0
+        const float* st = a.stats_in + (int64_t)m * a.ln_strips * 2;
+        float s1 = 0.f, s2 = 0.f;
+        for (int q = lane; q < a.ln_strips; q += 64) {
+          s1 += st[2 * q];
+          s2 += st[2 * q + 1];
+        }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        ln_mu = s1 / (float)a.ln_D;
+        ln_rs = rsqrtf(fmaxf(s2 / (float)a.ln_D - ln_mu * ln_mu, 0.f) + a.ln_eps);
+      }
       if (lane == 0) {
         float vv = acc;
+        if (a.stats_in) vv = ln_rs * (vv - ln_mu * a.ln_c[n]) + a.ln_d[n];  // LayerNorm fold, as in the MFMA epilogue
         if (a.bias) vv += to_float(((const T*)a.bias)[n]);
         if (a.g1) vv += to_float(((const T*)a.g1)[(int64_t)a.idx1[m] * a.ldg1 + n]);
         if (a.g2) vv += to_float(((const T*)a.g2)[(int64_t)a.idx2[m] * a.ldg2 + n]);
@@ -833,6 +901,35 @@ __global__ __launch_bounds__(512, 1) void linear_mfma_bigtile_kernel(LinArgs a, 
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float* ln_rows = reinterpret_cast<float*>(smem + STAGES * kStageBytes + 1024) + (j & 1) * TBM * 2;
+    if constexpr ((EPI & EPI_LNFOLD) != 0) {
+      // mean / rstd of the tile's rows from the producer's strip sums (fixed order), one thread per row, while the first
+      // K-tile is in flight; double-buffered over tiles, published by the K-loop's barriers
+      for (int r = tid; r < TBM; r += 64 * NW) {
+        const float* st = a.stats_in + (int64_t)min(m0 + r, a.n_rows - 1) * a.ln_strips * 2;
+        float s1 = 0.f, s2 = 0.f;
+        if (a.ln_strips == 8) {  // D = 512: four 16-byte loads, same summation order as the generic loop
+          f32x4 v[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = reinterpret_cast<const f32x4*>(st)[q];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            s1 += v[q][0];
+            s2 += v[q][1];
+            s1 += v[q][2];
+            s2 += v[q][3];
+          }
+        } else {
+          for (int q = 0; q < a.ln_strips; ++q) {
+            s1 += st[2 * q];
+            s2 += st[2 * q + 1];
+          }
+        }
+        const float inv = 1.0f / (float)a.ln_D, mu = s1 * inv;
+        ln_rows[2 * r] = mu;
+        ln_rows[2 * r + 1] = rsqrtf(fmaxf(s2 * inv - mu * mu, 0.f) + a.ln_eps);
+      }
+    }
 
     for (int kt = 0; kt < nk; ++kt, ++g) {
       // K-tile g must have landed (it is the only DMA in flight); right after an interior epilogue its stores may stay
@@ -865,7 +962,7 @@ __global__ __launch_bounds__(512, 1) void linear_mfma_bigtile_kernel(LinArgs a, 
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     const bool interior = (m0 + TBM <= a.n_rows) && (n0 + TBN <= a.O);
-    mfma_epilogue_band<T, EPI, MI>(a, acc, m0, n0, wr, wc, lane, smem + ((g - 1) % STAGES) * kStageBytes + wave * 4096, interior);
+    mfma_epilogue_band<T, EPI, MI>(a, acc, m0, n0, wr, wc, lane, smem + ((g - 1) % STAGES) * kStageBytes + wave * 4096, interior, ln_rows);
     counted_stores = interior;  // exactly kStores stores per wave, issued after the DMAs of the next K-tile
   }
 }
@@ -924,7 +1021,7 @@ static int launch_persistent_wm(const LinArgs& a, hipStream_t st) {
 template <typename T, int EPI, int MI>
 static int launch_bigtile(const LinArgs& a, hipStream_t st) {
   constexpr int TBM = 32 * MI, TBN = 256;
-  constexpr int smem_bytes = 2 * (TBM + TBN) * BK * 2 + 1024;
+  constexpr int smem_bytes = 2 * (TBM + TBN) * BK * 2 + 1024 + ((EPI & EPI_LNFOLD) ? 2 * TBM * 2 * 4 : 0);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_mfma_bigtile_kernel<T, MI, EPI>),
@@ -1006,6 +1103,27 @@ static int launch_mfma(const LinArgs& a, hipStream_t st) {
 }
 
 template <typename T>
+static int launch_stats_producer(const LinArgs& a, hipStream_t st) {
+  // y = x W^T + b + residual, plus the row statistics of y for the LayerNorm the next GEMM folds in (O = 512-class outputs)
+  const int nk = (a.K1 + a.K2) / BK;
+  const double c4 = tile_cost_us(256, 128, a.n_rows, a.O, nk), c3 = tile_cost_us(192, 128, a.n_rows, a.O, nk);
+  constexpr int EPI = EPI_RES | EPI_STATS;
+  return c3 < c4 ? launch_persistent_wm<T, EPI, 3, true>(a, st) : launch_persistent_wm<T, EPI, 4, true>(a, st);
+}
+
+template <typename T>
+static int launch_lnfold_consumer(const LinArgs& a, hipStream_t st) {
+  constexpr int kBigM = 320, kTail = 32;
+  const int rem = a.n_rows % kBigM;
+  LinArgs m = a;
+  if (rem > 0 && rem <= kTail && a.n_rows > kBigM) {  // as in launch_persistent: tail rows on the VALU, in the same kernel
+    m.n_rows = a.n_rows - rem;
+    m.tail_rows = rem;
+  }
+  return a.act == ANEMOI_ACT_GELU ? launch_bigtile<T, EPI_LNFOLD | EPI_GELU, 10>(m, st) : launch_bigtile<T, EPI_LNFOLD, 10>(m, st);
+}
+
+template <typename T>
 static int launch_splitk(const LinArgs& a, hipStream_t st) {
   // 64 x 128 tiles (many tiles from a small output), lock-step schedule, plain epilogue
   return launch_persistent_wm<T, 0, 1, false, 2>(a, st);
@@ -1028,6 +1146,48 @@ extern "C" int anemoi_linear_splitk_f32(const void* x, int64_t ldx, const void* 
   a.f32_atomic = 1;
   hipStream_t st = as_stream(stream);
   return dtype == ANEMOI_BF16 ? launch_splitk<bf16_t>(a, st) : launch_splitk<f16_t>(a, st);
+}
+
+extern "C" int anemoi_linear_stats_fwd(const void* x, int64_t ldx, int32_t K, const void* w, int64_t ldw, const void* bias,
+                                       const void* residual, int64_t ldr, void* y, int64_t ldy, float* stats_out, int32_t n_rows,
+                                       int32_t O, anemoi_dtype_t dtype, void* stream) {
+  ANEMOI_REQUIRE(n_rows > 0 && O > 0 && K > 0 && x && w && y && residual && stats_out, "linear_stats_fwd: bad arguments");
+  ANEMOI_REQUIRE(dtype == ANEMOI_BF16 || dtype == ANEMOI_F16, "linear_stats_fwd: 16-bit operands only");
+  ANEMOI_REQUIRE(O % 64 == 0 && K % BK == 0, "linear_stats_fwd: O=%d and K=%d must be multiples of 64", O, K);
+  LinArgs a{x, ldx, K, nullptr, 0, 0, w, ldw, bias, nullptr, 0, nullptr, nullptr, 0, nullptr, residual, ldr, y, ldy, n_rows, O, (int)ANEMOI_ACT_NONE};
+  a.stats_out = stats_out;
+  const bool ok = dtype == ANEMOI_BF16 ? (mfma_eligible<bf16_t>(a) && ring_eligible<bf16_t>(a)) : (mfma_eligible<f16_t>(a) && ring_eligible<f16_t>(a));
+  if (!ok) {
+    set_error("linear_stats_fwd: operands not eligible for the ring kernel (alignment)");
+    return ANEMOI_E_UNSUPPORTED;
+  }
+  hipStream_t st = as_stream(stream);
+  return dtype == ANEMOI_BF16 ? launch_stats_producer<bf16_t>(a, st) : launch_stats_producer<f16_t>(a, st);
+}
+
+extern "C" int anemoi_linear_lnfold_fwd(const void* x, int64_t ldx, int32_t K, const void* w_scaled, int64_t ldw, const float* ln_c,
+                                        const float* ln_d, const float* stats_in, int32_t strips, float eps, anemoi_act_t act, void* y,
+                                        int64_t ldy, int32_t n_rows, int32_t O, anemoi_dtype_t dtype, void* stream) {
+  ANEMOI_REQUIRE(n_rows > 0 && O > 0 && K > 0 && x && w_scaled && y && ln_c && ln_d && stats_in && strips > 0, "linear_lnfold_fwd: bad arguments");
+  ANEMOI_REQUIRE(dtype == ANEMOI_BF16 || dtype == ANEMOI_F16, "linear_lnfold_fwd: 16-bit operands only");
+  ANEMOI_REQUIRE(O % 8 == 0 && K % BK == 0 && strips * 64 == K, "linear_lnfold_fwd: O %% 8, K %% 64 and strips * 64 == K required (K=%d strips=%d)", K, strips);
+  ANEMOI_REQUIRE(act == ANEMOI_ACT_NONE || act == ANEMOI_ACT_GELU, "linear_lnfold_fwd: unknown activation");
+  LinArgs a{x, ldx, K, nullptr, 0, 0, w_scaled, ldw, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, 0, y, ldy, n_rows, O, (int)act};
+  a.stats_in = stats_in;
+  a.ln_c = ln_c;
+  a.ln_d = ln_d;
+  a.ln_strips = strips;
+  a.ln_D = K;
+  a.ln_eps = eps;
+  const bool ok = dtype == ANEMOI_BF16 ? (mfma_eligible<bf16_t>(a) && ring_eligible<bf16_t>(a)) : (mfma_eligible<f16_t>(a) && ring_eligible<f16_t>(a));
+  if (!ok || (reinterpret_cast<uintptr_t>(ln_c) & 15) || (reinterpret_cast<uintptr_t>(ln_d) & 15)) {
+    set_error("linear_lnfold_fwd: operands not eligible for the big-tile kernel (alignment)");
+    return ANEMOI_E_UNSUPPORTED;
+  }
+  hipStream_t st = as_stream(stream);
+  const int rc = dtype == ANEMOI_BF16 ? launch_lnfold_consumer<bf16_t>(a, st) : launch_lnfold_consumer<f16_t>(a, st);
+  if (rc == ANEMOI_E_UNSUPPORTED) set_error("linear_lnfold_fwd: n_rows=%d leaves tail rows (not a multiple of 320 within 32)", n_rows);
+  return rc;
 }
 
 extern "C" int anemoi_linear_fwd(const void* x, int64_t ldx, int32_t K1, const void* x2, int64_t ldx2, int32_t K2,

@@ -28,6 +28,7 @@ from .utils import compute_mlp_hidden_dim
 from ..utils.tensors import version
 
 ANEMOI_DEBUG_SHARDING = os.environ.get("ANEMOI_DEBUG_SHARDING", "") != ""
+_LN_FOLD = os.environ.get("ANEMOI_LN_FOLD", "1") != "0"  # developer switch: LayerNorm folded into the neighbouring GEMMs
 
 
 class _FusedWeights:
@@ -50,6 +51,23 @@ class _FusedWeights:
             b = torch.cat([lin.bias if lin.bias is not None else lin.weight.new_zeros(lin.out_features) for lin in linears]).contiguous()
         self._cache[tag] = (sig, w, b)
         return w, b
+
+    def ln_folded(self, tag: str, linears: list, ln) -> tuple[Tensor, Tensor, Tensor]:
+        """(W diag(gamma) in the model dtype, c = its fp32 row sums, d = W beta + b in fp32) for a LayerNorm folded into the
+        GEMM that follows it (ops.linear_ln_folded); rebuilt only when a parameter changes."""
+        ps = [p for lin in linears for p in (lin.weight, lin.bias) if p is not None] + [p for p in (ln.weight, ln.bias) if p is not None]
+        sig = tuple((p.data_ptr(), version(p), p.dtype, str(p.device)) for p in ps)
+        hit = self._cache.get("ln:" + tag)
+        if hit is not None and hit[0] == sig:
+            return hit[1]
+        with torch.no_grad():
+            w = torch.cat([lin.weight for lin in linears], dim=0).float()
+            b = torch.cat([lin.bias.float() if lin.bias is not None else w.new_zeros(lin.out_features) for lin in linears])
+            ws = (w * ln.weight.float()).to(linears[0].weight.dtype).contiguous()
+            c = ws.float().sum(1).contiguous()
+            d = (b if ln.bias is None else w @ ln.bias.float() + b).contiguous()
+        self._cache["ln:" + tag] = (sig, (ws, c, d))
+        return ws, c, d
 
     def packed_edge(self, lin_edge) -> Tensor:
         """fp32 [D, fe_pad] image of lin_edge for the fused attention, rebuilt only when the parameters change."""
@@ -140,11 +158,34 @@ class GraphTransformerBaseBlock(BaseBlock):
             feat = ops.pack_edge_features(ea)
         return ops.gt_attention_fused_edge(query, key, value, feat, self._fused.packed_edge(self.lin_edge), csc, H, addend=x_r)
 
-    def _post_attention(self, attn_plus_self: Tensor, x_skip: Tensor, cond: Optional[Tensor] = None) -> Tensor:
-        out = ops.linear(attn_plus_self, self.projection.weight, self.projection.bias, residual=x_skip)
-        h = apply_layer_norm(self.layer_norm_mlp_dst, out, cond)
-        return self.node_dst_mlp(h, residual=out)
+    def _ln_fold_ok(self, ln, x: Tensor) -> bool:
+        """The LayerNorm-fold path: inference, 16-bit, plain affine LayerNorm (see include/anemoi_hip.h)."""
+        return (_LN_FOLD and type(ln).__name__ in ("LayerNorm", "AutocastLayerNorm") and x.dtype != torch.float32 and x.is_cuda
+                and not (torch.is_grad_enabled() and (x.requires_grad or ln.weight.requires_grad)))
 
+    def _post_attention(self, attn_plus_self: Tensor, x_skip: Tensor, cond: Optional[Tensor] = None, chain: Optional[dict] = None) -> Tensor:
+        """projection + residual, LayerNorm, MLP + residual.  Inference: the projection GEMM also emits the row statistics of
+        its output and the MLP's first GEMM applies the LayerNorm from them (no LayerNorm launch); with ``chain`` the last
+        GEMM does the same for the NEXT block's first LayerNorm."""
+        ln, mlp = self.layer_norm_mlp_dst, self.node_dst_mlp
+        plain_mlp = mlp.mlp_implementation == "mlp" and len(mlp.mlp) == 3 and mlp.layer_norm is None
+        if plain_mlp and self._ln_fold_ok(ln, attn_plus_self):
+            r = ops.linear_with_row_stats(attn_plus_self, self.projection.weight, self.projection.bias, x_skip)
+            if r is not None:
+                out, stats = r
+                lin1, lin2 = mlp.mlp[0], mlp.mlp[2]
+                ws, c, d = self._fused.ln_folded("mlp1", [lin1], ln)
+                h = ops.linear_ln_folded(out, ws, c, d, stats, ln.eps, act="gelu")
+                if h is None:
+                    h = ops.linear(ops.layer_norm(out, ln.weight, ln.bias, ln.eps), lin1.weight, lin1.bias, act="gelu")
+                r2 = ops.linear_with_row_stats(h, lin2.weight, lin2.bias, out) if chain is not None else None
+                if r2 is not None:
+                    chain["x"], chain["stats"] = r2
+                    return r2[0]
+                return ops.linear(h, lin2.weight, lin2.bias, residual=out)
+        out = ops.linear(attn_plus_self, self.projection.weight, self.projection.bias, residual=x_skip)
+        h = apply_layer_norm(ln, out, cond)
+        return self.node_dst_mlp(h, residual=out)
 
 
 class GraphTransformerMapperBlock(GraphTransformerBaseBlock):
@@ -239,6 +280,20 @@ class GraphTransformerProcessorBlock(GraphTransformerBaseBlock):
                 **kwargs):
         A = self.attn_channels
         ln = self.layer_norm_attention
+        chain = kwargs.get("ln_chain")
+        if not model_is_distributed(model_comm_group) and chain is not None and self._ln_fold_ok(ln, x):
+            qkvs = None
+            if chain.get("x") is x:  # the previous block's last GEMM left the row statistics of x
+                ws, c, d = self._fused.ln_folded("qkvs", [self.lin_query, self.lin_key, self.lin_value, self.lin_self], ln)
+                qkvs = ops.linear_ln_folded(x, ws, c, d, chain["stats"], ln.eps)
+            if qkvs is None:
+                w, b = self._fused.get("qkvs", [self.lin_query, self.lin_key, self.lin_value, self.lin_self])
+                qkvs = ops.linear(ops.layer_norm(x, ln.weight, ln.bias, ln.eps), w, b)
+            chain.clear()
+            q, k, v, x_r = qkvs[:, :A], qkvs[:, A:2 * A], qkvs[:, 2 * A:3 * A], qkvs[:, 3 * A:]
+            csc = get_csc(edge_index, (x.shape[0], x.shape[0]), edges_are_dst_sorted)
+            out = self._attention(q, k, v, x_r, edge_attr, csc)
+            return self._post_attention(out, x, cond, chain), edge_attr
         xn = apply_layer_norm(ln, x, cond)
         if model_is_distributed(model_comm_group) and self.shard_strategy == "heads":
             return self._forward_heads(x, xn, edge_attr, edge_index, shard_info, batch_size, model_comm_group, cond, halo_cache), edge_attr

@@ -463,6 +463,45 @@ def linear_splitk(a: Tensor, b: Tensor, splits: int) -> Tensor:
     return y
 
 
+def linear_with_row_stats(x: Tensor, weight: Tensor, bias: Optional[Tensor], residual: Tensor):
+    """(y, stats) with y = x W^T + bias + residual and stats [N, O/64, 2] fp32 = per 64-column strip (sum, sum of squares) of
+    the stored rows of y — what ``linear_ln_folded`` needs to apply the LayerNorm of y.  None if the shape is not eligible."""
+    _dev(x, weight, bias, residual)
+    N, K = x.shape
+    O = weight.shape[0]
+    if x.dtype == torch.float32 or O % 64 or K % 64:
+        return None
+    y = torch.empty((N, O), dtype=x.dtype, device=x.device)
+    stats = torch.empty((N, O // 64, 2), dtype=torch.float32, device=x.device)
+    dt = x.dtype
+    (xp, ldx), (wp, ldw), (rp, ldr) = _rows(x, "x"), _rows(weight, "weight", dt), _rows(residual, "residual", dt)
+    rc = _lib.load().anemoi_linear_stats_fwd(xp, ldx, K, wp, ldw, _vec(bias, "bias", O, dt), rp, ldr, y.data_ptr(), O, stats.data_ptr(), N, O,
+                                             _dt(x), _stream())
+    if rc == _lib.E_UNSUPPORTED:
+        return None
+    _lib.check(rc, "linear_stats_fwd")
+    return y, stats
+
+
+def linear_ln_folded(x: Tensor, w_scaled: Tensor, c: Tensor, d: Tensor, stats: Tensor, eps: float, act: Optional[str] = None):
+    """act(LayerNorm(x) W^T + b) from raw x, w_scaled = W * gamma, c = rowsum(w_scaled) (fp32), d = W beta + b (fp32) and the
+    producer's row statistics of x.  None if the shape is not eligible (caller: LayerNorm + linear)."""
+    _dev(x, w_scaled, c, d, stats)
+    N, K = x.shape
+    O = w_scaled.shape[0]
+    if tuple(stats.shape) != (N, K // 64, 2) or stats.dtype != torch.float32 or not stats.is_contiguous():
+        raise ValueError("stats must be contiguous fp32 [N, K/64, 2]")
+    y = torch.empty((N, O), dtype=x.dtype, device=x.device)
+    dt = x.dtype
+    (xp, ldx), (wp, ldw) = _rows(x, "x"), _rows(w_scaled, "w_scaled", dt)
+    rc = _lib.load().anemoi_linear_lnfold_fwd(xp, ldx, K, wp, ldw, c.data_ptr(), d.data_ptr(), stats.data_ptr(), K // 64, float(eps),
+                                              _lib.ACT_GELU if act == "gelu" else _lib.ACT_NONE, y.data_ptr(), O, N, O, _dt(x), _stream())
+    if rc == _lib.E_UNSUPPORTED:
+        return None
+    _lib.check(rc, "linear_lnfold_fwd")
+    return y
+
+
 GLU_KINDS = {"glu": 0, "swiglu": 1, "geglu": 2, "reglu": 3}
 
 

@@ -129,6 +129,24 @@ int anemoi_colsum(const void* x, int64_t ldx, float* out, float* workspace, int3
 int anemoi_gelu_bwd(const void* pre, int64_t ldp, const void* d_y, int64_t lddy, void* d_pre, int64_t lddp,
                     int32_t n_rows, int32_t D, anemoi_dtype_t dtype, void* stream);
 
+/* LayerNorm folded into the GEMMs around it (inference).  For y = LN(x; gamma, beta) W^T + b:
+ *     y = rstd (x (W diag gamma)^T - mean c) + d,   c = row sums of W diag(gamma),  d = W beta + b
+ * so the normalisation needs only the per-row mean / rstd of x, and those come for free from the GEMM that PRODUCED x:
+ *  - anemoi_linear_stats_fwd: y = x W^T + bias + residual (as anemoi_linear_fwd) and stats_out[n_rows][O/64][2] (fp32) =
+ *    (sum, sum of squares) of every 64-column strip of the stored (rounded) output row.  Plain stores, one per (row, strip):
+ *    no atomics, no zeroing, deterministic.  O and K multiples of 64.
+ *  - anemoi_linear_lnfold_fwd: y = act(LN(x) W^T + b) from raw x [n_rows, K], w_scaled = W diag(gamma) [O, K], fp32 c, d [O]
+ *    and stats_in = the producer's statistics of x (strips * 64 == K).  Partials are added in a fixed order.
+ * Replaces the two LayerNorm launches of a GraphTransformerProcessorBlock (layer_norm_attention / layer_norm_mlp_dst,
+ * layers/block.py:1237, 1271) in the unsharded inference path.  Returns ANEMOI_E_UNSUPPORTED for shapes / alignments the
+ * ring kernels do not take (the caller falls back to LayerNorm + anemoi_linear_fwd). */
+int anemoi_linear_stats_fwd(const void* x, int64_t ldx, int32_t K, const void* w, int64_t ldw, const void* bias,
+                            const void* residual, int64_t ldr, void* y, int64_t ldy, float* stats_out, int32_t n_rows,
+                            int32_t O, anemoi_dtype_t dtype, void* stream);
+int anemoi_linear_lnfold_fwd(const void* x, int64_t ldx, int32_t K, const void* w_scaled, int64_t ldw, const float* ln_c,
+                             const float* ln_d, const float* stats_in, int32_t strips, float eps, anemoi_act_t act, void* y,
+                             int64_t ldy, int32_t n_rows, int32_t O, anemoi_dtype_t dtype, void* stream);
+
 /* y[n_rows, O] (fp32, ZEROED BY THE CALLER) += x[n_rows, K] @ w[O, K]^T with the reduction split into ``splits`` chunks that
  * run on different CUs and accumulate with fp32 atomics: the weight-gradient GEMM dW = dZ^T X of torch.nn.Linear's autograd
  * (small output, reduction over 10^4..10^5 rows).  16-bit operands, K a multiple of 64 * splits. */

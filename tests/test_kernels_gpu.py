@@ -320,3 +320,35 @@ def test_cpu_tensor_fails_loudly(ops):
     x = torch.randn(4, 64)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.layer_norm(x, torch.ones(64), torch.zeros(64))
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm fold
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N", [10242, 640, 4000, 330])  # 320-row tiles + 2 tail rows / whole tiles / partial last tile / tail of 10
+def test_layernorm_folded_into_neighbouring_gemms(ops, dtype, N):
+    """anemoi_linear_stats_fwd + anemoi_linear_lnfold_fwd: y = h W2^T + b2 + res with row statistics, then
+    act(LN(y) W1^T + b1) from the raw y — against fp32 torch, and the producer's y bit-equal to the plain GEMM."""
+    gen = torch.Generator().manual_seed(N)
+    D, Hd = 512, 2048
+    h = torch.randn(N, Hd, generator=gen).to(dtype)
+    w2, b2 = (torch.randn(D, Hd, generator=gen) / 45).to(dtype), (0.1 * torch.randn(D, generator=gen)).to(dtype)
+    res = (2.0 * torch.randn(N, D, generator=gen) + 0.5).to(dtype)
+    gamma, beta = (1 + 0.2 * torch.randn(D, generator=gen)).to(dtype), (0.1 * torch.randn(D, generator=gen)).to(dtype)
+    w1, b1 = (torch.randn(Hd, D, generator=gen) / 22).to(dtype), (0.1 * torch.randn(Hd, generator=gen)).to(dtype)
+    d = lambda t: t.to(DEV)  # noqa: E731
+    r = ops.linear_with_row_stats(d(h), d(w2), d(b2), d(res))
+    assert r is not None
+    y, stats = r
+    assert torch.equal(y, ops.linear(d(h), d(w2), d(b2), residual=d(res)))
+    yf = y.float()
+    s = stats.sum(1)
+    assert float((s[:, 0] - yf.sum(1)).abs().max()) < 1e-3 and float((s[:, 1] - (yf * yf).sum(1)).abs().max()) < 1e-3 * float((yf * yf).sum(1).max())
+    ws = (w1.float() * gamma.float()).to(dtype)
+    c, dd = ws.float().sum(1).contiguous(), (w1.float() @ beta.float() + b1.float()).contiguous()
+    for act in (None, "gelu"):
+        out = ops.linear_ln_folded(y, d(ws), d(c), d(dd), stats, 1e-5, act)
+        assert out is not None
+        ref = F.linear(F.layer_norm(yf.cpu(), (D,), gamma.float(), beta.float()), w1.float(), b1.float())
+        ref = F.gelu(ref) if act else ref
+        assert_close(out, ref, dtype, f"fold act={act} N={N}")
+        assert torch.equal(out, ops.linear_ln_folded(y, d(ws), d(c), d(dd), stats, 1e-5, act))  # deterministic
