@@ -21,6 +21,7 @@
 namespace anemoi {
 
 constexpr int kWavesPerBlock = 4;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 
 template <int VEC>
 struct EdgeRow {
@@ -162,8 +163,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void gt_attn_fused_edge_fwd
     for (int it = 0; it < kIter; ++it) {
       const int idx = threadIdx.x + it * 64 * kWavesPerBlock;
       if (idx < kTotal) {
-        const int c = idx / kQ, qq = idx % kQ;
-        *reinterpret_cast<float4*>(w_lds + (c / VEC) * L::kChunk + (c % VEC) * FE_PAD + qq * 4) = tmp[it];
+        const int c = idx / kQ, qq = idx % kQ;  // channel c, features 4 qq .. 4 qq + 3 -> chunk layout [feature][channel]
+        float* dst = w_lds + (c / VEC) * L::kChunk + (qq * 4) * VEC + (c % VEC);
+        dst[0] = tmp[it].x;
+        dst[VEC] = tmp[it].y;
+        dst[2 * VEC] = tmp[it].z;
+        dst[3 * VEC] = tmp[it].w;
       }
     }
   }
@@ -204,9 +209,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void gt_attn_fused_edge_fwd
     float qw[FE_PAD], sf[FE_PAD];
 #pragma unroll
     for (int f = 0; f < FE_PAD; ++f) {
+      // W' is stored [feature][channel] per lane: the VEC channels of a feature are contiguous (16-byte LDS reads) and
+      // the channel pairs map onto packed FMAs without shuffles, here and in the final W' * sum(p a)
       float t = 0.f;
+      if constexpr (VEC % 2 == 0) {
+        f32x2 t2 = {0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) t = fmaf(qv[j], wl[j * FE_PAD + f], t);
+        for (int j = 0; j < VEC; j += 2)
+          t2 = __builtin_elementwise_fma(f32x2{qv[j], qv[j + 1]}, *reinterpret_cast<const f32x2*>(wl + f * VEC + j), t2);
+        t = t2[0] + t2[1];
+      } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) t = fmaf(qv[j], wl[f * VEC + j], t);
+      }
       qw[f] = group_sum<LPH>(t) * (1.0f / LPH);
       sf[f] = 0.f;
     }
@@ -265,12 +280,29 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void gt_attn_fused_edge_fwd
     asm volatile("" ::: "memory");
     const float inv = (end > beg) ? 1.0f / l : 0.f;
     float o[VEC];
+    if constexpr (VEC % 2 == 0) {
+      f32x2 o2[VEC / 2];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      float t = acc[j];
+      for (int j = 0; j < VEC; j += 2) o2[j / 2] = f32x2{acc[j], acc[j + 1]};
 #pragma unroll
-      for (int f = 0; f < FE_PAD; ++f) t = fmaf(sf[f], wl[j * FE_PAD + f], t);
-      o[j] = t * inv;
+      for (int f = 0; f < FE_PAD; ++f) {
+        const f32x2 s2 = {sf[f], sf[f]};
+#pragma unroll
+        for (int j = 0; j < VEC; j += 2) o2[j / 2] = __builtin_elementwise_fma(s2, *reinterpret_cast<const f32x2*>(wl + f * VEC + j), o2[j / 2]);
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; j += 2) {
+        o[j] = o2[j / 2][0] * inv;
+        o[j + 1] = o2[j / 2][1] * inv;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float t = acc[j];
+#pragma unroll
+        for (int f = 0; f < FE_PAD; ++f) t = fmaf(sf[f], wl[f * VEC + j], t);
+        o[j] = t * inv;
+      }
     }
     if (addend != nullptr) {
       float ad[VEC];
