@@ -28,7 +28,10 @@ from .utils import compute_mlp_hidden_dim
 from ..utils.tensors import version
 
 ANEMOI_DEBUG_SHARDING = os.environ.get("ANEMOI_DEBUG_SHARDING", "") != ""
-_LN_FOLD = os.environ.get("ANEMOI_LN_FOLD", "1") != "0"  # developer switch: LayerNorm folded into the neighbouring GEMMs
+# LayerNorm folded into the neighbouring GEMMs (anemoi_linear_stats_fwd / anemoi_linear_lnfold_fwd).  Opt-in: it removes 32 of
+# the 39 LayerNorm launches of the O96 forward but makes the consuming GEMMs' epilogues heavier (the 160-accumulator big-tile
+# kernel has no registers to spare): -1.4 % forward time in a same-box A/B, nothing on another box.
+_LN_FOLD = os.environ.get("ANEMOI_LN_FOLD", "0") == "1"
 
 
 class _FusedWeights:

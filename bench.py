@@ -168,7 +168,12 @@ def profile_forward(step, dtype):
     def ln_work(out, x, *a, **kw):
         return "layernorm_fwd_kernel", 2 * x.numel() * es, "byte"
 
-    saved = {n: getattr(ops, n) for n in ("linear", "gt_attention_fused_edge", "layer_norm")}
+    def gemm_work(out, x, w, *a, **kw):  # the LayerNorm-fold GEMMs (statistics producer / folding consumer)
+        return "linear_mfma_*", 2.0 * x.shape[0] * w.shape[1] * w.shape[0], "flop"
+
+    saved = {n: getattr(ops, n) for n in ("linear", "gt_attention_fused_edge", "layer_norm", "linear_with_row_stats", "linear_ln_folded")}
+    ops.linear_with_row_stats = wrap("linear_stats", saved["linear_with_row_stats"], gemm_work)
+    ops.linear_ln_folded = wrap("linear_lnfold", saved["linear_ln_folded"], gemm_work)
     ops.linear = wrap("linear", saved["linear"], lin_work)
     ops.gt_attention_fused_edge = wrap("attn", saved["gt_attention_fused_edge"], attn_work)
     ops.layer_norm = wrap("ln", saved["layer_norm"], ln_work)
