@@ -10,7 +10,7 @@ from torch import Tensor, nn
 import torch
 
 from .. import ops
-from .kernels import GELU
+from .kernels import GELU, PaddedLinear
 
 
 class GatedMLPLayer(nn.Module):
@@ -59,6 +59,7 @@ class MLP(nn.Module):
                 layers.append(GatedMLPLayer(hidden_dim, hidden_dim, layer_kernels, mlp_implementation))
             layers.append(Linear(hidden_dim, out_features))
         self.mlp = nn.Sequential(*layers)
+        self._pad_first = PaddedLinear()
         self.layer_norm = LayerNorm(normalized_shape=out_features) if layer_norm else None
 
     def forward(self, x: Tensor, *, x2: Optional[Tensor] = None, residual: Optional[Tensor] = None,
@@ -88,7 +89,11 @@ class MLP(nn.Module):
                 kw["x2"] = x2
             if last and ln is None and residual is not None:
                 kw["residual"] = residual.reshape(-1, residual.shape[-1])
-            h = ops.linear(h, lin.weight, lin.bias, act=act, **kw)
+            if n == 0 and h.shape[1] % 8 and h.dtype != torch.float32 and kw.get("x2") is None:
+                # e.g. the 11 raw edge attributes entering a GNN's edge embedding: zero-pad K onto the MFMA path
+                h = self._pad_first(h, lin, act=act, **{k: v for k, v in kw.items() if k != "x2"})
+            else:
+                h = ops.linear(h, lin.weight, lin.bias, act=act, **kw)
         if ln is not None:
             h = ops.layer_norm(h, ln.weight, ln.bias, ln.eps, None if residual is None else residual.reshape(-1, residual.shape[-1]))
         return h.view(*x.shape[:-1], h.shape[-1])
