@@ -32,6 +32,7 @@ SIGNATURES = {
     "anemoi_layernorm_bwd": ([_p, _i64, _p, _p, _i64, _p, _i64, _p, _p, _p, _i32, _i32, _f, C.c_int, _p], C.c_int),
     "anemoi_colsum": ([_p, _i64, _p, _p, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_gelu_bwd": ([_p, _i64, _p, _i64, _p, _i64, _i32, _i32, C.c_int, _p], C.c_int),
+    "anemoi_cond_layernorm_bwd": ([_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i32, _i32, _f, C.c_int, _p], C.c_int),
     "anemoi_cond_layernorm_fwd": ([_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i32, _i32, _f, C.c_int, _p], C.c_int),
     "anemoi_bound_columns": ([_p, _i64, _i32, _i32, _p, _p, _i32, C.c_int, _p], C.c_int),
     "anemoi_layernorm_fwd": ([_p, _i64, _p, _p, _p, _i64, _p, _i64, _i32, _i32, _f, C.c_int, _p], C.c_int),

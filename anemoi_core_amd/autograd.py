@@ -116,6 +116,23 @@ class LayerNormFunction(torch.autograd.Function):
                 db.to(weight.dtype) if ctx.has_bias and ctx.needs_input_grad[2] else None, None)
 
 
+class CondLayerNormFunction(torch.autograd.Function):
+    """y = LN(x) (scale + 1) + shift with per-row scale / shift."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, scale: Tensor, shift: Tensor, eps: float):
+        ctx.eps = eps
+        ctx.save_for_backward(x, scale)
+        return ops._cond_layer_norm_fwd(x, scale, shift, eps)
+
+    @staticmethod
+    def backward(ctx, d_y: Tensor):
+        x, scale = ctx.saved_tensors
+        d_y = d_y.contiguous()
+        dx, ds = ops.cond_layer_norm_backward(d_y, x, scale, ctx.eps)
+        return dx, ds, d_y.reshape(ds.shape), None
+
+
 class GluFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gate_value: Tensor, kind: str):

@@ -119,6 +119,69 @@ __global__ __launch_bounds__(64 * kWaves) void rowwise_bwd_kernel(const T* __res
   }
 }
 
+// ConditionalLayerNorm backward (reference layers/normalization.py:34-94): y = x^ (scale[row] + 1) + shift[row].
+//   g = dy (scale + 1);  dx = rstd (g - mean(g) - x^ mean(g x^));  d_scale[row] = dy x^;  (d_shift[row] = dy: no kernel)
+template <typename T, int VEC, int CH>
+__global__ __launch_bounds__(64 * kWaves) void cond_layernorm_bwd_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ scale,
+                                                                         int64_t lds, const T* __restrict__ dy, int64_t lddy,
+                                                                         T* __restrict__ dx, int64_t lddx, T* __restrict__ dscale,
+                                                                         int64_t ldds, int n_rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * kWaves + (threadIdx.x >> 6);
+  if (r >= n_rows) return;
+  float xv[CH][VEC], gv[CH][VEC], sc[CH][VEC];
+  load_row<T, VEC, CH>(x + (int64_t)r * ldx, D, lane, xv);
+  load_row<T, VEC, CH>(dy + (int64_t)r * lddy, D, lane, gv);
+  load_row<T, VEC, CH>(scale + (int64_t)r * lds, D, lane, sc);
+  const float inv_d = 1.0f / (float)D;
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < CH; ++t)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s += xv[t][j];
+  const float mean = wave_sum(s) * inv_d;
+  float ss = 0.f;
+#pragma unroll
+  for (int t = 0; t < CH; ++t) {
+    const int c = (t * 64 + lane) * VEC;
+    if (c < D) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        xv[t][j] -= mean;
+        ss = fmaf(xv[t][j], xv[t][j], ss);
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(ss) * inv_d + eps);
+  float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+  for (int t = 0; t < CH; ++t) {
+    const int c = (t * 64 + lane) * VEC;
+    float ds[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      xv[t][j] *= rstd;
+      ds[j] = gv[t][j] * xv[t][j];
+      gv[t][j] *= (c < D) ? sc[t][j] + 1.0f : 0.f;
+      c1 += gv[t][j];
+      c2 = fmaf(gv[t][j], xv[t][j], c2);
+    }
+    if (c < D) store_vec<T, VEC>(dscale + (int64_t)r * ldds + c, ds);
+  }
+  c1 = wave_sum(c1) * inv_d;
+  c2 = wave_sum(c2) * inv_d;
+#pragma unroll
+  for (int t = 0; t < CH; ++t) {
+    const int c = (t * 64 + lane) * VEC;
+    if (c < D) {
+      float o[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) o[j] = rstd * (gv[t][j] - c1 - xv[t][j] * c2);
+      store_vec<T, VEC>(dx + (int64_t)r * lddx + c, o);
+    }
+  }
+}
+
 // out0[c] = sum_w part[w][0][c], out1[c] = sum_w part[w][1][c].  One block per 64 columns of the [2D] row: 16 groups of 64
 // threads each add every 16th partial (coalesced 256-byte reads), then a fixed-order tree over the 16 groups in LDS:
 // deterministic, and 64 dependent loads per thread instead of one thread walking all partials.
@@ -409,6 +472,26 @@ int launch_glu(const void* gv, int64_t ldgv, const void* d_out, int64_t lddo, vo
   return check_launch("glu_kernel");
 }
 
+template <typename T>
+int launch_cond_ln_bwd(const void* x, int64_t ldx, const void* scale, int64_t lds, const void* dy, int64_t lddy, void* dx, int64_t lddx,
+                       void* dscale, int64_t ldds, int n_rows, int D, float eps, hipStream_t st) {
+  const int vec = pick_vec<T>(D, {ldx, lds, lddy, lddx, ldds}, {x, scale, dy, dx, dscale});
+  const int ch = pick_chunks(D, vec);
+  ANEMOI_REQUIRE(ch > 0, "cond_layernorm_bwd: D=%d too large for the register-resident row", D);
+  const dim3 grid((n_rows + kWaves - 1) / kWaves), block(64 * kWaves);
+#define CB_CASE(V, C)                                                                                                        \
+  case V * 16 + C:                                                                                                           \
+    hipLaunchKernelGGL((cond_layernorm_bwd_kernel<T, V, C>), grid, block, 0, st, (const T*)x, ldx, (const T*)scale, lds,     \
+                       (const T*)dy, lddy, (T*)dx, lddx, (T*)dscale, ldds, n_rows, D, eps);                                  \
+    break;
+  switch (vec * 16 + ch) {
+    ALL_VEC_CH(CB_CASE)
+    default: set_error("cond_layernorm_bwd: bad vector width"); return ANEMOI_E_INVALID;
+  }
+#undef CB_CASE
+  return check_launch("cond_layernorm_bwd_kernel");
+}
+
 }  // namespace
 }  // namespace anemoi
 
@@ -526,6 +609,21 @@ extern "C" int anemoi_glu_bwd(const void* gate_value, int64_t ldgv, const void* 
     case ANEMOI_F32: return launch_glu<float, true>(gate_value, ldgv, d_out, lddo, d_gate_value, lddgv, n_rows, D, kind, st);
     case ANEMOI_BF16: return launch_glu<bf16_t, true>(gate_value, ldgv, d_out, lddo, d_gate_value, lddgv, n_rows, D, kind, st);
     case ANEMOI_F16: return launch_glu<f16_t, true>(gate_value, ldgv, d_out, lddo, d_gate_value, lddgv, n_rows, D, kind, st);
+    default: set_error("unknown dtype"); return ANEMOI_E_INVALID;
+  }
+}
+
+extern "C" int anemoi_cond_layernorm_bwd(const void* x, int64_t ldx, const void* scale, int64_t lds, const void* d_y, int64_t lddy,
+                                         void* d_x, int64_t lddx, void* d_scale, int64_t ldds, int32_t n_rows, int32_t D, float eps,
+                                         anemoi_dtype_t dtype, void* stream) {
+  ANEMOI_REQUIRE(n_rows >= 0 && D > 0 && ldx >= D && lds >= D && lddy >= D && lddx >= D && ldds >= D, "cond_layernorm_bwd: bad sizes");
+  if (n_rows == 0) return ANEMOI_OK;
+  ANEMOI_REQUIRE(x && scale && d_y && d_x && d_scale, "cond_layernorm_bwd: null pointer");
+  hipStream_t st = as_stream(stream);
+  switch (dtype) {
+    case ANEMOI_F32: return launch_cond_ln_bwd<float>(x, ldx, scale, lds, d_y, lddy, d_x, lddx, d_scale, ldds, n_rows, D, eps, st);
+    case ANEMOI_BF16: return launch_cond_ln_bwd<bf16_t>(x, ldx, scale, lds, d_y, lddy, d_x, lddx, d_scale, ldds, n_rows, D, eps, st);
+    case ANEMOI_F16: return launch_cond_ln_bwd<f16_t>(x, ldx, scale, lds, d_y, lddy, d_x, lddx, d_scale, ldds, n_rows, D, eps, st);
     default: set_error("unknown dtype"); return ANEMOI_E_INVALID;
   }
 }

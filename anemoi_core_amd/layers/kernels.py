@@ -41,7 +41,7 @@ class AutocastLayerNorm(LayerNorm):
 class ConditionalLayerNorm(nn.Module):
     """Reference layers/normalization.py:34-94: ``LN(x) * (scale(cond) + 1) + bias(cond)``, same parameters and
     state_dict keys (``scale.*``, ``bias.*``; ``norm`` has none).  The two Linear maps of the conditioning run as ONE fused
-    GEMM [N, 2D] whose halves feed the modulated LayerNorm kernel.  Forward only for now."""
+    GEMM [N, 2D] whose halves feed the modulated LayerNorm kernel (forward and backward)."""
 
     def __init__(self, normalized_shape, condition_shape: int = 16, zero_init: bool = True, autocast: bool = True) -> None:
         super().__init__()

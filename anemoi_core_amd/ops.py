@@ -244,7 +244,13 @@ def gt_attention_fused_edge(q: Tensor, k: Tensor, v: Tensor, edge_feat: Tensor, 
 def cond_layer_norm(x: Tensor, scale: Tensor, shift: Tensor, eps: float = 1e-5) -> Tensor:
     """y = LayerNorm(x) * (scale + 1) + shift over the last dim, per-row scale / shift [N, D] (column slices allowed)."""
     if _needs_grad(x, scale, shift):
-        raise NotImplementedError("the backward of ConditionalLayerNorm is not built yet (scope row f3 covers its forward)")
+        from .autograd import CondLayerNormFunction
+
+        return CondLayerNormFunction.apply(x, scale, shift, float(eps))
+    return _cond_layer_norm_fwd(x, scale, shift, eps)
+
+
+def _cond_layer_norm_fwd(x: Tensor, scale: Tensor, shift: Tensor, eps: float = 1e-5) -> Tensor:
     _dev(x, scale, shift)
     D = x.shape[-1]
     x2 = x.reshape(-1, D)
@@ -255,6 +261,19 @@ def cond_layer_norm(x: Tensor, scale: Tensor, shift: Tensor, eps: float = 1e-5) 
     _lib.check(_lib.load().anemoi_cond_layernorm_fwd(p, ld, sp, lds, bp, ldb, y.data_ptr(), D, x2.shape[0], D, float(eps), _dt(x), _stream()),
                "cond_layernorm_fwd")
     return y.view(x.shape)
+
+
+def cond_layer_norm_backward(d_y: Tensor, x: Tensor, scale: Tensor, eps: float = 1e-5):
+    """(dx, d_scale) of cond_layer_norm, both [N, D]; d_shift is d_y itself."""
+    _dev(d_y, x, scale)
+    D = x.shape[-1]
+    x2, g2 = x.reshape(-1, D), d_y.reshape(-1, D)
+    dx = torch.empty((x2.shape[0], D), dtype=x.dtype, device=x.device)
+    ds = torch.empty((x2.shape[0], D), dtype=x.dtype, device=x.device)
+    (xp, ldx), (sp, lds), (gp, ldg) = _rows(x2, "x"), _rows(scale, "scale", x.dtype), _rows(g2, "d_y", x.dtype)
+    _lib.check(_lib.load().anemoi_cond_layernorm_bwd(xp, ldx, sp, lds, gp, ldg, dx.data_ptr(), D, ds.data_ptr(), D, x2.shape[0], D, float(eps),
+                                                     _dt(x), _stream()), "cond_layernorm_bwd")
+    return dx.view(x.shape), ds
 
 
 def _needs_grad(*tensors) -> bool:

@@ -105,6 +105,12 @@ int anemoi_layernorm_fwd(const void* x, int64_t ldx, const void* gamma, const vo
 int anemoi_cond_layernorm_fwd(const void* x, int64_t ldx, const void* scale, int64_t lds, const void* shift, int64_t ldsh,
                               void* y, int64_t ldy, int32_t n_rows, int32_t D, float eps, anemoi_dtype_t dtype, void* stream);
 
+/* Backward of the above: d_x [n_rows, D] and d_scale [n_rows, D] = d_y * x^ (per row; d_shift = d_y needs no kernel); the
+ * gradients of the conditioning's two Linear maps follow from d_scale / d_shift through anemoi_linear_fwd. */
+int anemoi_cond_layernorm_bwd(const void* x, int64_t ldx, const void* scale, int64_t lds, const void* d_y, int64_t lddy,
+                              void* d_x, int64_t lddx, void* d_scale, int64_t ldds, int32_t n_rows, int32_t D, float eps,
+                              anemoi_dtype_t dtype, void* stream);
+
 /* Output boundings at the model edge, in place and in configuration order (layers/bounding.py:81-307;
  * models/encoder_processor_decoder.py:160-162).  ops: int32 [n_ops][4] = (kind, column, total column, 0); params: fp32
  * [n_ops][2].  kind 1 ReluBounding, 2 LeakyReluBounding, 3 / 4 Normalized(Leaky)ReluBounding (params[0] = the normalised
