@@ -203,6 +203,49 @@ def profile_forward(step, dtype):
     return fam
 
 
+def component_times(model, step, n_data, n_hidden, channels, layers):
+    """Device time of encoder / processor / decoder in one more eager forward (events on forward hooks, queue backed up by a
+    sleep kernel as in profile_forward) and the per-component N*D/t of SURVEY.md 8(d)."""
+    marks, handles = {}, []
+
+    def pre(name):
+        def f(mod, args, kwargs):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            marks[name] = [e, None]
+        return f
+
+    def post(name):
+        def f(mod, args, kwargs, out):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            marks[name][1] = e
+        return f
+
+    mods = {"encoder": next(iter(model.encoder.values())), "processor": model.processor, "decoder": next(iter(model.decoder.values()))}
+    for n, m in mods.items():
+        handles.append(m.register_forward_pre_hook(pre(n), with_kwargs=True))
+        handles.append(m.register_forward_hook(post(n), with_kwargs=True))
+    try:
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        torch.cuda._sleep(1_000_000)
+        e1.record()
+        torch.cuda.synchronize()
+        torch.cuda._sleep(int(1_000_000 / max(e0.elapsed_time(e1), 1e-3) * 12.0))
+        step()
+        torch.cuda.synchronize()
+    finally:
+        for h in handles:
+            h.remove()
+    ms = {n: marks[n][0].elapsed_time(marks[n][1]) for n in mods}
+    return {"encoder_ms": round(ms["encoder"], 3), "processor_ms": round(ms["processor"], 3), "decoder_ms": round(ms["decoder"], 3),
+            "processor_nodes_channels_layers_per_s": n_hidden * channels * layers / (ms["processor"] * 1e-3),
+            "encoder_nodes_channels_per_s": n_data * channels / (ms["encoder"] * 1e-3),
+            "decoder_nodes_channels_per_s": n_data * channels / (ms["decoder"] * 1e-3)}
+
+
 def gpu_eager_baseline(model_fp32_params, cfg, g, x, device, steps=5):
     """The same restatement (oracle = op sequence of the reference's "pyg" backend: index_select gathers, elementwise
     temporaries, segment softmax, index_add; torch.nn.functional Linear / LayerNorm / GELU through rocBLAS / MIOpen) run
@@ -421,6 +464,10 @@ def main():
             with torch.inference_mode():
                 fam = profile_forward(step, dtype)
                 res["kernels"] = time_kernels(model, g, args, dtype, device)
+                try:
+                    res["components"] = component_times(model, step, g.num_data, g.num_hidden, args.channels, args.layers)
+                except Exception as e:  # noqa: BLE001  (an informational leg must never take the benchmark line down)
+                    res["components"] = {"error": f"{type(e).__name__}: {e}"}
             res["kernel_families"] = {k: {"calls": v["calls"], "total_us": round(v["us"], 1), "avg_us": round(v["us"] / v["calls"], 2),
                                           "work": v["work"], "unit": v["unit"]} for k, v in fam.items()}
             traffic = {}

@@ -8,3 +8,4 @@ for k, v in d.get("kernel_families", {}).items():
 print("roofline:", {k: v for k, v in d.get("roofline", {}).items() if k != "note"})
 print("cpu:", d.get("cpu_baseline"))
 print("gpu eager:", d.get("gpu_eager_baseline"), "speedup", d.get("speedup_vs_gpu_eager"))
+print("components:", d.get("components"))
