@@ -34,6 +34,7 @@ SIGNATURES = {
     "anemoi_gelu_bwd": ([_p, _i64, _p, _i64, _p, _i64, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_cond_layernorm_bwd": ([_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i32, _i32, _f, C.c_int, _p], C.c_int),
     "anemoi_cond_layernorm_fwd": ([_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i32, _i32, _f, C.c_int, _p], C.c_int),
+    "anemoi_assemble_output": ([_p, _i64, _p, _i64, _p, _p, _i64, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_bound_columns": ([_p, _i64, _i32, _i32, _p, _p, _i32, C.c_int, _p], C.c_int),
     "anemoi_layernorm_fwd": ([_p, _i64, _p, _p, _p, _i64, _p, _i64, _i32, _i32, _f, C.c_int, _p], C.c_int),
     "anemoi_linear_splitk_f32": ([_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, _i32, C.c_int, _p], C.c_int),

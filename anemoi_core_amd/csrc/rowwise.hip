@@ -198,6 +198,21 @@ __global__ void bound_columns_kernel(T* __restrict__ x, int64_t ldx, int n_rows,
   }
 }
 
+// Output assembly at the model edge (reference models/encoder_processor_decoder.py:145-163 for batch = ensemble = time = 1):
+// out[n, v] = x_out[n, v] + (col_map[v] >= 0 ? x_skip[n, col_map[v]] : 0) - the residual (SkipConnection) added onto the
+// prognostic columns - in one pass instead of clone + index_select + index_add_.
+template <typename T>
+__global__ void assemble_output_kernel(const T* __restrict__ x_out, int64_t ldx, const T* __restrict__ skip, int64_t lds,
+                                       const int32_t* __restrict__ col_map, T* __restrict__ out, int64_t ldo, int n_rows, int n_cols) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)n_rows * n_cols) return;
+  const int n = (int)(i / n_cols), v = (int)(i % n_cols);
+  float val = to_float(x_out[(int64_t)n * ldx + v]);
+  const int m = col_map[v];
+  if (m >= 0) val = to_float(from_float<T>(val)) + to_float(skip[(int64_t)n * lds + m]);
+  out[(int64_t)n * ldo + v] = from_float<T>(val);
+}
+
 // Pick the widest vector width (in elements) such that rows stay 16-byte-or-narrower aligned and D % VEC == 0.
 template <typename T>
 static int pick_vec(int D, std::initializer_list<int64_t> lds, std::initializer_list<const void*> ptrs) {
@@ -377,4 +392,21 @@ extern "C" int anemoi_bound_columns(void* x, int64_t ldx, int32_t n_rows, int32_
     default: set_error("unknown dtype"); return ANEMOI_E_INVALID;
   }
   return check_launch("bound_columns_kernel");
+}
+
+extern "C" int anemoi_assemble_output(const void* x_out, int64_t ldx, const void* x_skip, int64_t lds, const int32_t* col_map, void* out,
+                                      int64_t ldo, int32_t n_rows, int32_t n_cols, anemoi_dtype_t dtype, void* stream) {
+  ANEMOI_REQUIRE(n_rows >= 0 && n_cols > 0 && ldx >= n_cols && ldo >= n_cols, "assemble_output: bad sizes");
+  if (n_rows == 0) return ANEMOI_OK;
+  ANEMOI_REQUIRE(x_out && x_skip && col_map && out, "assemble_output: null pointer");
+  const int64_t n = (int64_t)n_rows * n_cols;
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  hipStream_t st = as_stream(stream);
+  switch (dtype) {
+    case ANEMOI_F32: hipLaunchKernelGGL((assemble_output_kernel<float>), grid, block, 0, st, (const float*)x_out, ldx, (const float*)x_skip, lds, col_map, (float*)out, ldo, n_rows, n_cols); break;
+    case ANEMOI_BF16: hipLaunchKernelGGL((assemble_output_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)x_out, ldx, (const bf16_t*)x_skip, lds, col_map, (bf16_t*)out, ldo, n_rows, n_cols); break;
+    case ANEMOI_F16: hipLaunchKernelGGL((assemble_output_kernel<f16_t>), grid, block, 0, st, (const f16_t*)x_out, ldx, (const f16_t*)x_skip, lds, col_map, (f16_t*)out, ldo, n_rows, n_cols); break;
+    default: set_error("unknown dtype"); return ANEMOI_E_INVALID;
+  }
+  return check_launch("assemble_output_kernel");
 }

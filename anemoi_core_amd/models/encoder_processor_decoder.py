@@ -101,6 +101,11 @@ class AnemoiModelEncProcDec(nn.Module):
             # the residual scatter involves no host->device copy and the forward is hipGraph-capturable
             self.register_buffer(f"_in_idx_{ds}", torch.tensor(self._internal_input_idx[ds], dtype=torch.long), persistent=False)
             self.register_buffer(f"_out_idx_{ds}", torch.tensor(self._internal_output_idx[ds], dtype=torch.long), persistent=False)
+            cmap = None
+            if len(set(self._internal_output_idx[ds])) == len(self._internal_output_idx[ds]):  # one residual per output column
+                cmap = torch.full((self.num_output_channels[ds],), -1, dtype=torch.int32)
+                cmap[torch.tensor(self._internal_output_idx[ds], dtype=torch.long)] = torch.tensor(self._internal_input_idx[ds], dtype=torch.int32)
+            self.register_buffer(f"_col_map_{ds}", cmap, persistent=False)
 
     def _build_networks(self, mc, edges) -> None:
         hid = self._graph_name_hidden
@@ -150,9 +155,15 @@ class AnemoiModelEncProcDec(nn.Module):
 
     def _assemble_output(self, x_out: Tensor, x_skip: Tensor, batch_size: int, ensemble_size: int, dtype, ds: str) -> Tensor:
         N = x_out.shape[0] // (batch_size * ensemble_size)
-        x_out = x_out.view(batch_size, ensemble_size, N, self.n_step_output, -1).permute(0, 3, 1, 2, 4).to(dtype=dtype).clone()
         in_idx, out_idx = getattr(self, f"_in_idx_{ds}"), getattr(self, f"_out_idx_{ds}")
-        x_out.index_add_(-1, out_idx, x_skip.unsqueeze(1).index_select(-1, in_idx).to(dtype))
+        col_map = getattr(self, f"_col_map_{ds}")
+        if (col_map is not None and batch_size == 1 and ensemble_size == 1 and self.n_step_output == 1 and x_out.is_cuda and x_out.dtype == dtype
+                and x_skip.dtype == dtype and not (torch.is_grad_enabled() and (x_out.requires_grad or x_skip.requires_grad))):
+            # one kernel for cast / residual on the prognostic columns (instead of clone + index_select + index_add_)
+            x_out = ops.assemble_output(x_out, x_skip.reshape(N, -1), col_map).view(1, 1, 1, N, -1)
+        else:
+            x_out = x_out.view(batch_size, ensemble_size, N, self.n_step_output, -1).permute(0, 3, 1, 2, 4).to(dtype=dtype).clone()
+            x_out.index_add_(-1, out_idx, x_skip.unsqueeze(1).index_select(-1, in_idx).to(dtype))
         if len(self.boundings[ds]):  # all configured boundings as ONE in-place column program (configuration order)
             from ..layers.bounding import apply_program_torch, program_tables
 

@@ -551,6 +551,17 @@ def glu_backward(gate_value: Tensor, d_out: Tensor, kind: str) -> Tensor:
     return out
 
 
+def assemble_output(x_out: Tensor, x_skip: Tensor, col_map: Tensor) -> Tensor:
+    """out[n, v] = x_out[n, v] + x_skip[n, col_map[v]] (where col_map[v] >= 0); x_out [N, V_out], x_skip [N, V_in] (row
+    stride allowed), col_map int32 [V_out]."""
+    _dev(x_out, x_skip, col_map)
+    N, V = x_out.shape
+    out = torch.empty((N, V), dtype=x_out.dtype, device=x_out.device)
+    (xp, ldx), (sp, lds) = _rows(x_out, "x_out"), _rows(x_skip, "x_skip", x_out.dtype)
+    _lib.check(_lib.load().anemoi_assemble_output(xp, ldx, sp, lds, col_map.data_ptr(), out.data_ptr(), V, N, V, _dt(x_out), _stream()), "assemble_output")
+    return out
+
+
 def bound_columns_(x: Tensor, op_table: Tensor, param_table: Tensor) -> Tensor:
     """In place: apply the column program (int32 [n_ops, 4], fp32 [n_ops, 2]; see anemoi_bound_columns) to x [..., V]."""
     _dev(x, op_table, param_table)

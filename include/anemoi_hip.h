@@ -118,6 +118,12 @@ int anemoi_cond_layernorm_bwd(const void* x, int64_t ldx, const void* scale, int
 int anemoi_bound_columns(void* x, int64_t ldx, int32_t n_rows, int32_t n_cols, const int32_t* ops, const float* params,
                          int32_t n_ops, anemoi_dtype_t dtype, void* stream);
 
+/* Output assembly at the model edge for batch = ensemble = output steps = 1 (models/encoder_processor_decoder.py:145-163):
+ * out[n, v] = x_out[n, v] + x_skip[n, col_map[v]] where col_map[v] >= 0 (the SkipConnection residual on the prognostic
+ * columns), else x_out[n, v].  Replaces clone + index_select + index_add_. */
+int anemoi_assemble_output(const void* x_out, int64_t ldx, const void* x_skip, int64_t lds, const int32_t* col_map, void* out,
+                           int64_t ldo, int32_t n_rows, int32_t n_cols, anemoi_dtype_t dtype, void* stream);
+
 /* LayerNorm backward.  Replaces: autograd of layer_kernels.LayerNorm (layers/utils.py:107-121).
  *   d_x [n_rows, D] (same dtype), d_gamma / d_beta fp32 [D] (either may be NULL; both NULL: no column sums);
  *   workspace: anemoi_reduce_workspace_bytes(D) bytes of fp32 scratch (per-wave partial column sums, added in a fixed
