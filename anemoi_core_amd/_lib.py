@@ -37,6 +37,8 @@ SIGNATURES = {
     "anemoi_assemble_output": ([_p, _i64, _p, _i64, _p, _p, _i64, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_bound_columns": ([_p, _i64, _i32, _i32, _p, _p, _i32, C.c_int, _p], C.c_int),
     "anemoi_layernorm_fwd": ([_p, _i64, _p, _p, _p, _i64, _p, _i64, _i32, _i32, _f, C.c_int, _p], C.c_int),
+    "anemoi_linear_wgrad_workspace_bytes": ([_i32, _i32, _i32], _i64),
+    "anemoi_linear_wgrad": ([_p, _i64, _p, _i64, _p, _i64, _p, _p, _i32, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_linear_splitk_f32": ([_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_linear_stats_fwd": ([_p, _i64, _i32, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_linear_lnfold_fwd": ([_p, _i64, _i32, _p, _i64, _p, _p, _p, _i32, _f, C.c_int, _p, _i64, _i32, _i32, C.c_int, _p], C.c_int),

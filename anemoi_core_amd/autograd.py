@@ -4,12 +4,14 @@ carries its own registration (``ops.graph_transformer_attention``).
 
 Linear backward (reference: autograd of torch.nn.Linear as instantiated by layer_kernels, layers/utils.py:107-121):
     dX = dZ W          -> ops.linear(dZ, W^T)              (same MFMA kernels; the weight transpose is a small copy)
-    dW = dZ^T X        -> ops.linear(dZ^T, X^T)            (the reduction runs over the rows: both operands are transposed
-                                                             into K-contiguous, zero-padded [*, N_pad] buffers first)
+    dW = dZ^T X        -> ops.linear_wgrad(dZ, X)          (the reduction runs over the rows: row-major tiles are read with the
+                                                             LDS transpose read; fp32 / odd widths: explicit transposes + GEMM)
     db = column sums of dZ (deterministic two-stage reduction), dZ = dY * gelu'(pre) when GELU was fused (the
     pre-activation is recomputed by one extra GEMM instead of being stored by the forward).
 """
 from __future__ import annotations
+
+import os
 
 from typing import Optional
 
@@ -24,10 +26,24 @@ def _t_padded(a: Tensor, mult: int = 64) -> Tensor:
     return ops.transpose_pad(a, mult)
 
 
+def _granule_rows(t: Tensor) -> Tensor:
+    """Rows that start on 16-byte boundaries (what the LDS-DMA granules of the wgrad kernel need), copying only if necessary."""
+    ok = t.stride(1) == 1 and (t.shape[0] == 1 or t.stride(0) % 8 == 0) and t.data_ptr() % 16 == 0
+    return t if ok else t.contiguous()
+
+
+def _tn_ok(dz: Tensor, x: Tensor) -> bool:
+    return ops.linear_wgrad_eligible(dz, x) and os.environ.get("ANEMOI_WGRAD_TN", "1") == "1"
+
+
 def _weight_grad(dz: Tensor, x: Tensor) -> Tensor:
-    """dW [O, K] = dz^T [O, N] @ x [N, K]: small output, reduction over all rows -> split-K over the CUs (16-bit path)."""
+    """dW [O, K] = dz^T [O, N] @ x [N, K]: small output, reduction over all rows.  16-bit operands with O, K multiples of 8 go
+    to the transpose-read kernel (csrc/wgrad.hip: no HBM transposes, deterministic split reduction); anything else is transposed
+    into K-contiguous buffers for the forward GEMM kernels (split-K with fp32 atomics on the 16-bit path)."""
     n, o = dz.shape
     k = x.shape[1]
+    if _tn_ok(dz, x):
+        return ops.linear_wgrad(_granule_rows(dz), _granule_rows(x))
     if dz.dtype == torch.float32 or k % 4:
         return ops._linear_fwd(_t_padded(dz), _t_padded(x))
     tiles = ((o + 63) // 64) * ((k + 127) // 128)
@@ -60,9 +76,15 @@ class LinearFunction(torch.autograd.Function):
         dx = dw = db = dg1 = dg2 = None
         if ctx.needs_input_grad[0]:
             dx = ops._linear_fwd(dz, weight.t().contiguous())
-        if ctx.needs_input_grad[1]:
-            dw = _weight_grad(dz, x.reshape(-1, x.shape[-1])).to(weight.dtype)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        x2d = x.reshape(-1, x.shape[-1])
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] and want_db and _tn_ok(dz, x2d):  # bias gradient rides along in the wgrad kernel
+            dw, db = ops.linear_wgrad(_granule_rows(dz), _granule_rows(x2d), with_bias_grad=True)
+            dw, db = dw.to(weight.dtype), db.to(bias.dtype)
+            want_db = False
+        elif ctx.needs_input_grad[1]:
+            dw = _weight_grad(dz, x2d).to(weight.dtype)
+        if want_db:
             db = ops.colsum(dz).to(bias.dtype)
         if g1 is not None and ctx.needs_input_grad[5]:
             dg1 = ops.segment_sum_rows(dz, *ctx.seg1)

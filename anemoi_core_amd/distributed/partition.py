@@ -75,18 +75,32 @@ def build_graph_partition_from_shard_info(edge_index: Tensor, x: tuple, shard_in
     return build_graph_partition(edge_index, world, (n_src, n_dst))
 
 
+def edge_shard_plan(edge_index: Tensor, src_size: int, dst_size: int, model_comm_group, edges_are_dst_sorted: bool = True):
+    """Index part of ``shard_edges_1hop`` (a function of the static ``edge_index`` only, so callers cache it):
+    (perm | None, slice | None, local edge_index, edge splits | None).  ``take_edge_rows`` applies it to edge attributes,
+    which in training are a fresh differentiable tensor every step."""
+    world = comm_size(model_comm_group)
+    if world == 1:
+        return None, None, edge_index, None
+    perm = None
+    if not edges_are_dst_sorted:
+        edge_index, perm = sort_edge_index_by_dst(edge_index)
+    part = build_graph_partition(edge_index, world, (src_size, dst_size))
+    r = part.edge_range(comm_rank(model_comm_group))
+    return perm, r, edge_index[:, r], part.edge_splits
+
+
+def take_edge_rows(edge_attr: Tensor, perm, rows) -> Tensor:
+    if perm is not None:
+        edge_attr = edge_attr[perm]
+    return edge_attr if rows is None else edge_attr[rows]
+
+
 def shard_edges_1hop(edge_attr: Tensor, edge_index: Tensor, src_size: int, dst_size: int, model_comm_group,
                      edges_are_dst_sorted: bool = True):
     """Local slice of the dst-sorted edges owned by this rank (no communication): khop_edges.py:266-314."""
-    world = comm_size(model_comm_group)
-    if world == 1:
-        return edge_attr, edge_index, None
-    if not edges_are_dst_sorted:
-        edge_index, perm = sort_edge_index_by_dst(edge_index)
-        edge_attr = edge_attr[perm]
-    part = build_graph_partition(edge_index, world, (src_size, dst_size))
-    r = part.edge_range(comm_rank(model_comm_group))
-    return edge_attr[r], edge_index[:, r], part.edge_splits
+    perm, rows, ei, splits = edge_shard_plan(edge_index, src_size, dst_size, model_comm_group, edges_are_dst_sorted)
+    return take_edge_rows(edge_attr, perm, rows), ei, splits
 
 
 @dataclass(frozen=True)

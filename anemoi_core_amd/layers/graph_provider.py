@@ -11,7 +11,7 @@ from typing import Optional
 import torch
 from torch import Tensor, nn
 
-from ..distributed.partition import shard_edges_1hop, sort_edge_index_by_dst
+from ..distributed.partition import edge_shard_plan, take_edge_rows, sort_edge_index_by_dst
 from .graph import TrainableTensor
 from ..utils.tensors import version
 
@@ -56,21 +56,21 @@ class StaticGraphProvider(nn.Module):
 
     def get_edges(self, batch_size: int, src_coords=None, dst_coords=None, model_comm_group=None, shard_edges: bool = True,
                   act_checkpoint: bool = True):
-        edge_attr = self.trainable(self.edge_attr, batch_size)  # cached by TrainableTensor
-        key = (batch_size, shard_edges, id(model_comm_group), edge_attr.data_ptr(), version(edge_attr), edge_attr.dtype)
+        edge_attr = self.trainable(self.edge_attr, batch_size)  # cached by TrainableTensor outside training
+        key = (batch_size, shard_edges, id(model_comm_group))  # index part only: edge_attr is a fresh tensor per training step
         hit = self._cache.get("edges")
-        if hit is not None and hit[0] == key:
-            return hit[1]
-        if batch_size == 1:
-            edge_index = self.edge_index_base
-        else:
-            edge_index = torch.cat([self.edge_index_base + i * self.edge_inc for i in range(batch_size)], dim=1)
-        out = (edge_attr, edge_index, None)
-        if shard_edges:
-            src_size, dst_size = self._sizes
-            out = shard_edges_1hop(edge_attr, edge_index, src_size * batch_size, dst_size * batch_size, model_comm_group)
-        self._cache["edges"] = (key, out, edge_attr)
-        return out
+        if hit is None or hit[0] != key:
+            if batch_size == 1:
+                edge_index = self.edge_index_base
+            else:
+                edge_index = torch.cat([self.edge_index_base + i * self.edge_inc for i in range(batch_size)], dim=1)
+            plan = (None, None, edge_index, None)
+            if shard_edges:
+                src_size, dst_size = self._sizes
+                plan = edge_shard_plan(edge_index, src_size * batch_size, dst_size * batch_size, model_comm_group)
+            hit = self._cache["edges"] = (key, plan)
+        perm, rows, edge_index, splits = hit[1]
+        return take_edge_rows(edge_attr, perm, rows), edge_index, splits
 
 
 class NoOpGraphProvider(nn.Module):

@@ -66,7 +66,8 @@ class BaseMapper(nn.Module):
     def _local_graph(self, x, shard_info, edge_attr, edge_index, group):
         """Rank-local (dst range, edges, compact sources) — index work only, cached for the static graph."""
         world, rank = comm_size(group), comm_rank(group)
-        key = (edge_index.data_ptr(), version(edge_index), edge_attr.data_ptr(), version(edge_attr), world, rank,
+        # keyed on the static edge_index only: in training edge_attr is a fresh (differentiable) tensor every step
+        key = (edge_index.data_ptr(), version(edge_index), edge_attr.shape[0], world, rank,
                tuple(shard_info.src_nodes or ()), tuple(shard_info.dst_nodes or ()), tuple(shard_info.edges or ()),
                x[0].shape[0], x[1].shape[0])
 
@@ -77,19 +78,22 @@ class BaseMapper(nn.Module):
                 loc = edge_index.long()
                 src_ids, inv = torch.unique(loc[0], return_inverse=True)
                 ei_local = torch.stack([inv, loc[1] - dr.start])
-                ea_local = edge_attr
+                edge_rows = None
             else:
                 lg = local_bipartite_graph(edge_index, partition, rank)
                 src_ids, ei_local = lg.src_ids, lg.edge_index_local
-                ea_local = edge_attr[lg.edge_range[0]: lg.edge_range[1]]
+                edge_rows = slice(lg.edge_range[0], lg.edge_range[1])
+                if edge_rows == slice(0, edge_attr.shape[0]):
+                    edge_rows = None
                 dr = slice(*lg.dst_range)
             n_src_total = partition.num_nodes[0]
             all_connected = src_ids.shape[0] == n_src_total
             return dict(partition=partition, dst_range=(dr.start, dr.stop), src_ids=src_ids, src_ids32=src_ids.to(torch.int32).contiguous(),
-                        edge_index=ei_local.contiguous(), edge_attr=ea_local, all_connected=all_connected,
-                        anchors=(edge_index, edge_attr))
+                        edge_index=ei_local.contiguous(), edge_rows=edge_rows, all_connected=all_connected, anchors=(edge_index,))
 
-        return self._local.get(key, build)
+        g = dict(self._local.get(key, build))
+        g["edge_attr"] = edge_attr if g["edge_rows"] is None else edge_attr[g["edge_rows"]]
+        return g
 
 
 class GraphTransformerBaseMapper(BaseMapper):

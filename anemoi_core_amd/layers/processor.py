@@ -9,7 +9,7 @@ from typing import Optional
 
 from torch import Tensor, nn
 
-from ..distributed.partition import ensure_edges_are_dst_sorted, shard_edges_1hop
+from ..distributed.partition import edge_shard_plan, ensure_edges_are_dst_sorted, sort_edge_index_by_dst, take_edge_rows
 from ..distributed.primitives import gather_tensor
 from ..distributed.shapes import GraphShardInfo
 from .block import GraphConvProcessorBlock, GraphTransformerProcessorBlock
@@ -78,12 +78,12 @@ class GraphTransformerProcessor(BaseProcessor):
             edge_attr, edge_index, edges_are_sharded=shard_info.edges_are_sharded(), model_comm_group=model_comm_group,
             edges_are_dst_sorted=edges_are_dst_sorted,
         )
-        if not shard_info.edges_are_sharded():  # local slice of the dst-sorted edges (no communication), cached
-            key = (edge_index.data_ptr(), version(edge_index), edge_attr.data_ptr(), version(edge_attr), size, id(model_comm_group))
+        if not shard_info.edges_are_sharded():  # local slice of the dst-sorted edges (no communication); index part cached
+            key = (edge_index.data_ptr(), version(edge_index), size, id(model_comm_group))
             if self._shard_cache is None or self._shard_cache[0] != key:
-                self._shard_cache = (key, shard_edges_1hop(edge_attr, edge_index, size, size, model_comm_group, edges_are_dst_sorted=True),
-                                     (edge_attr, edge_index))
-            edge_attr, edge_index, edge_shard_sizes = self._shard_cache[1]
+                self._shard_cache = (key, edge_shard_plan(edge_index, size, size, model_comm_group, edges_are_dst_sorted=True), (edge_index,))
+            perm, rows, edge_index, edge_shard_sizes = self._shard_cache[1]
+            edge_attr = take_edge_rows(edge_attr, perm, rows)
             shard_info = GraphShardInfo(nodes=shard_info.nodes, edges=edge_shard_sizes)
         x, _ = self.run_layers(
             (x, edge_attr), edge_index=edge_index, shard_info=shard_info, batch_size=batch_size, size=size,
@@ -112,15 +112,15 @@ class GNNProcessor(BaseProcessor):
                 model_comm_group=None, edges_are_dst_sorted: bool = True, *args, **kwargs) -> Tensor:
         if not shard_info.edges_are_sharded():  # local slice of the dst-sorted edges (no communication), cached: static graph
             target_nodes = sum(shard_info.nodes) if shard_info.nodes_are_sharded() else x.shape[0]
-            key = (edge_index.data_ptr(), version(edge_index), edge_attr.data_ptr(), version(edge_attr), target_nodes,
-                   id(model_comm_group), edges_are_dst_sorted)
+            key = (edge_index.data_ptr(), version(edge_index), target_nodes, id(model_comm_group), edges_are_dst_sorted)
             if self._shard_cache is None or self._shard_cache[0] != key:
-                ea, ei, edge_shard_sizes = shard_edges_1hop(edge_attr, edge_index, target_nodes, target_nodes, model_comm_group,
-                                                            edges_are_dst_sorted=edges_are_dst_sorted)
+                perm, rows, ei, edge_shard_sizes = edge_shard_plan(edge_index, target_nodes, target_nodes, model_comm_group,
+                                                                   edges_are_dst_sorted=edges_are_dst_sorted)
                 if edge_shard_sizes is None and not edges_are_dst_sorted:
-                    ea, ei = ensure_edges_are_dst_sorted(ea, ei, edges_are_sharded=False, edges_are_dst_sorted=False)
-                self._shard_cache = (key, (ea, ei, edge_shard_sizes), (edge_attr, edge_index))
-            edge_attr, edge_index, edge_shard_sizes = self._shard_cache[1]
+                    ei, perm = sort_edge_index_by_dst(ei)
+                self._shard_cache = (key, (perm, rows, ei, edge_shard_sizes), (edge_index,))
+            perm, rows, edge_index, edge_shard_sizes = self._shard_cache[1]
+            edge_attr = take_edge_rows(edge_attr, perm, rows)
             shard_info = GraphShardInfo(nodes=shard_info.nodes, edges=edge_shard_sizes)
         x, _ = self.run_layers((x, edge_attr), edge_index, shard_info, model_comm_group, local_edge_cache=self._local_edge_cache, **kwargs)
         return x

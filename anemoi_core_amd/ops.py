@@ -482,6 +482,31 @@ def linear_splitk(a: Tensor, b: Tensor, splits: int) -> Tensor:
     return y
 
 
+def linear_wgrad_eligible(dz: Tensor, x: Tensor) -> bool:
+    return (dz.dtype in (torch.bfloat16, torch.float16) and x.dtype == dz.dtype and dz.shape[1] % 8 == 0 and x.shape[1] % 8 == 0
+            and dz.shape[0] > 0)
+
+
+def linear_wgrad(dz: Tensor, x: Tensor, with_bias_grad: bool = False):
+    """dW [O, I] = dz^T x for 16-bit dz [N, O], x [N, I] (the reduction runs over the rows; no transposes in HBM);
+    ``with_bias_grad``: returns (dW, db) with db [O] = column sums of dz from the same kernel."""
+    _dev(dz, x)
+    N, O = dz.shape
+    I = x.shape[1]
+    if x.shape[0] != N or not linear_wgrad_eligible(dz, x):
+        raise ValueError("linear_wgrad: dz [N, O] and x [N, I] must be bf16/fp16 of one dtype with O, I multiples of 8")
+    lib = _lib.load()
+    ws = torch.empty((int(lib.anemoi_linear_wgrad_workspace_bytes(N, O, I)) // 4,), dtype=torch.float32, device=dz.device)
+    dw = torch.empty((O, I), dtype=dz.dtype, device=dz.device)
+    (zp, ldz), (xp, ldx) = _rows(dz, "dz"), _rows(x, "x", dz.dtype)
+    if ldz % 8 or ldx % 8:
+        raise ValueError("linear_wgrad: row strides must be multiples of 8 elements")
+    db = torch.empty((O,), dtype=dz.dtype, device=dz.device) if with_bias_grad else None
+    _lib.check(lib.anemoi_linear_wgrad(zp, ldz, xp, ldx, dw.data_ptr(), I, 0 if db is None else db.data_ptr(), ws.data_ptr(), N, O, I,
+                                       _dt(dz), _stream()), "linear_wgrad")
+    return (dw, db) if with_bias_grad else dw
+
+
 def linear_with_row_stats(x: Tensor, weight: Tensor, bias: Optional[Tensor], residual: Tensor):
     """(y, stats) with y = x W^T + bias + residual and stats [N, O/64, 2] fp32 = per 64-column strip (sum, sum of squares) of
     the stored rows of y — what ``linear_ln_folded`` needs to apply the LayerNorm of y.  None if the shape is not eligible."""

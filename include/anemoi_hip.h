@@ -165,6 +165,15 @@ int anemoi_linear_lnfold_fwd(const void* x, int64_t ldx, int32_t K, const void* 
 int anemoi_linear_splitk_f32(const void* x, int64_t ldx, const void* w, int64_t ldw, float* y, int64_t ldy, int32_t n_rows,
                              int32_t O, int32_t K, int32_t splits, anemoi_dtype_t dtype, void* stream);
 
+/* Weight gradient of torch.nn.Linear without HBM transposes: dw[o, i] = sum_r dz[r, o] * x[r, i] (16-bit operands, fp32
+ * accumulation; O, I, lddz, ldx multiples of 8).  The row-major tiles are read through the LDS transpose read; the reduction is
+ * split over workgroups into fp32 partial tiles in `workspace` (anemoi_linear_wgrad_workspace_bytes bytes) summed in fixed order:
+ * deterministic, no atomics.  `db` (nullable, [O]) receives the bias gradient = column sums of dz, accumulated by the same kernel.
+ * Autograd of block.py:623-635 / mlp.py:158-169 (scope row f1). */
+int64_t anemoi_linear_wgrad_workspace_bytes(int32_t n_rows, int32_t O, int32_t I);
+int anemoi_linear_wgrad(const void* dz, int64_t lddz, const void* x, int64_t ldx, void* dw, int64_t lddw, void* db, void* workspace,
+                        int32_t n_rows, int32_t O, int32_t I, anemoi_dtype_t dtype, void* stream);
+
 /* Linear layer with fused epilogue.  Replaces torch.nn.Linear (+ GELU + residual add) as used by
  * get_qkve / projection / MLP (layers/block.py:623-635,1268-1271; layers/mlp.py:158-169).
  *   y[n, o] = act( sum_k A[n,k] * w[o,k] + bias[o] + g1[idx1[n], o] + g2[idx2[n], o] ) + residual[n, o]

@@ -352,3 +352,30 @@ def test_layernorm_folded_into_neighbouring_gemms(ops, dtype, N):
         ref = F.gelu(ref) if act else ref
         assert_close(out, ref, dtype, f"fold act={act} N={N}")
         assert torch.equal(out, ops.linear_ln_folded(y, d(ws), d(c), d(dd), stats, 1e-5, act))  # deterministic
+
+
+@pytest.mark.parametrize("n,o,i", [(10242, 2048, 512), (10242, 512, 2048), (1000, 24, 16), (4099, 520, 136), (63, 128, 128),
+                                   (257, 8, 8), (40320, 512, 184), (81840, 512, 16)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_wgrad_transpose_read_kernel(n, o, i, dtype):
+    """dW = dZ^T X through the LDS transpose-read kernel == fp32 matmul of the same 16-bit operands; non-symmetric random
+    operands (an operand / output transpose cannot pass), ragged row counts and widths, run-to-run bit-identical."""
+    from anemoi_core_amd import ops
+
+    g = torch.Generator(device="cuda").manual_seed(n + o + i)
+    dz = (torch.randn(n, o, device="cuda", generator=g) * 0.5).to(dtype)
+    x = torch.randn(n, i, device="cuda", generator=g).to(dtype)
+    got, db = ops.linear_wgrad(dz, x, with_bias_grad=True)
+    ref = dz.float().t() @ x.float()
+    ref_b = dz.float().sum(0)
+    assert db.shape == (o,) and db.dtype == dtype
+    assert float((db.float() - ref_b).abs().max()) <= 6e-3 * float(ref_b.abs().max()) + 1e-3
+    scale = float(ref.abs().max())
+    assert got.shape == (o, i) and got.dtype == dtype
+    assert float((got.float() - ref).abs().max()) <= 6e-3 * scale + 1e-3
+    assert torch.equal(got, ops.linear_wgrad(dz, x))  # and without the bias-gradient column sums
+    # row-strided views (a column slab of a wider buffer) are taken in place
+    wide = torch.randn(n, o + 16, device="cuda", generator=g).to(dtype)
+    got2 = ops.linear_wgrad(wide[:, 8:8 + o], x)
+    ref2 = wide[:, 8:8 + o].float().t() @ x.float()
+    assert float((got2.float() - ref2).abs().max()) <= 6e-3 * float(ref2.abs().max()) + 1e-3

@@ -39,5 +39,41 @@ if __name__ == "__main__":
             model(inp)
         torch.cuda.synchronize()
         ms_f = (time.perf_counter() - t0) / n * 1e3
+    # whole step (forward + backward) as one hipGraph: static input / gradient buffers
+    ms_g = float("nan")
+    try:
+        if os.environ.get("TRAIN_GRAPH", "1") != "1":
+            raise RuntimeError("graph leg disabled")
+        model.zero_grad(set_to_none=False)
+
+        def gstep():
+            for p in model.parameters():
+                if p.grad is not None:
+                    p.grad.zero_()
+            out = model(inp)["data"]
+            out.float().square().mean().backward()
+
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                gstep()
+        torch.cuda.current_stream().wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            gstep()
+        for _ in range(3):
+            graph.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            graph.replay()
+        torch.cuda.synchronize()
+        ms_g = (time.perf_counter() - t0) / n * 1e3
+    except Exception as e:  # noqa: BLE001
+        import traceback
+
+        traceback.print_exc()
+    print(f"train step as one hipGraph: {ms_g:.2f} ms")
     print(f"train step (fwd+bwd, eager, bf16): {ms:.2f} ms; inference forward (eager): {ms_f:.2f} ms; parameters without a finite gradient: {len(bad)} {bad[:5]}")
     print(f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB")
