@@ -193,3 +193,41 @@ def attention(q: Tensor, k: Tensor, v: Tensor, e: Tensor, csc: "ops.CSC", num_he
     out, _saved, _m = ops.graph_transformer_attention(q.reshape(-1, H, C), k.reshape(-1, H, C), v.reshape(-1, H, C), e.reshape(-1, H, C),
                                                       csc.row, csc.colptr, rowptr, edge_ids, edge_dst)
     return out.reshape(-1, H * C)
+
+
+class FusedAttentionFunction(torch.autograd.Function):
+    """out = attention(q, k, v, e) + self_term, with q / k / v / self_term given as COLUMN SLABS of the fused projection buffers
+    they were computed into (processor: one [N, 4A] buffer; mapper: [N_dst, 2A] and [N_src, 2A]).  The backward kernels write
+    dq / dk / dv straight into the matching slabs of ONE gradient buffer per projection, so autograd sees a single gradient
+    per GEMM output instead of four zero-filled slice gradients and their sums.
+
+    ``spec``: {"A": width, "q": (buffer index, first column), "k": ..., "v": ..., "s": ...}."""
+
+    @staticmethod
+    def forward(ctx, spec, csc, num_heads, reverse, e, *bufs):
+        A = spec["A"]
+        slab = lambda key: bufs[spec[key][0]][:, spec[key][1]: spec[key][1] + A]  # noqa: E731
+        out, lse = ops.gt_attention(slab("q"), slab("k"), slab("v"), e, csc, num_heads, return_lse=True)
+        ctx.spec, ctx.csc, ctx.H, ctx.reverse = spec, csc, num_heads, reverse
+        ctx.save_for_backward(e, out, lse, *bufs)
+        return out + slab("s")
+
+    @staticmethod
+    def backward(ctx, d_y):
+        e, out, lse, *bufs = ctx.saved_tensors
+        spec, A = ctx.spec, ctx.spec["A"]
+        d_y = d_y.contiguous()
+        covered = [0] * len(bufs)
+        for key in ("q", "k", "v", "s"):
+            covered[spec[key][0]] += A
+        grads = [torch.empty_like(b, memory_format=torch.contiguous_format) if covered[i] == b.shape[1] else torch.zeros_like(b)
+                 for i, b in enumerate(bufs)]
+        slab = lambda ts, key: ts[spec[key][0]][:, spec[key][1]: spec[key][1] + A]  # noqa: E731
+        _, _, _, de = ops.gt_attention_backward(d_y, slab(bufs, "q"), slab(bufs, "k"), slab(bufs, "v"), e, out, lse, ctx.csc, ctx.reverse,
+                                                ctx.H, grads_out=(slab(grads, "q"), slab(grads, "k"), slab(grads, "v")))
+        slab(grads, "s").copy_(d_y)
+        return (None, None, None, None, de, *grads)
+
+
+def fused_attention(spec: dict, bufs, e: Tensor, csc: "ops.CSC", num_heads: int, reverse) -> Tensor:
+    return FusedAttentionFunction.apply(spec, csc, num_heads, reverse, e, *bufs)

@@ -134,8 +134,12 @@ class GraphTransformerBaseBlock(BaseBlock):
         self._pad_edge = PaddedLinear()
 
     # -- pieces ---------------------------------------------------------------------------------------------
-    def _attention(self, query: Tensor, key: Tensor, value: Tensor, x_r: Tensor, edge_attr: Tensor, csc: ops.CSC) -> Tensor:
-        """(attention output + x_r) [N_dst, A]; q/k/v may be column slices of a fused projection buffer."""
+    def _attention(self, query: Tensor, key: Tensor, value: Tensor, x_r: Tensor, edge_attr: Tensor, csc: ops.CSC,
+                   fused: Optional[dict] = None, edge_prep: Optional[dict] = None) -> Tensor:
+        """(attention output + x_r) [N_dst, A]; q/k/v may be column slices of a fused projection buffer.  ``fused`` names
+        those buffers and columns ({"bufs": (...), "q": (buffer, column), "k", "v", "s"}) so that the training path can hand
+        autograd one gradient per buffer; ``edge_prep``: per-forward cache of the prepared (cast, zero-padded) edge attributes
+        shared by the layers of a processor."""
         H, C = self.num_heads, self.out_channels_conv
         if self.qk_norm:  # per-head LayerNorm over C, no bias (block.py:655-660)
             query = self.q_norm(query.reshape(-1, H, C)).view(-1, H * C)
@@ -143,14 +147,26 @@ class GraphTransformerBaseBlock(BaseBlock):
         if ops._needs_grad(query, key, value, x_r, edge_attr, self.lin_edge.weight):
             # training (scope row f1): E = lin_edge(edge_pre_mlp(edge_attr)) is materialised, as in the reference
             # (block.py:623-635), and the attention runs through the op mirror, whose backward is registered
-            from ..autograd import attention
+            from ..autograd import attention, fused_attention
 
-            ea = edge_attr if csc.perm is None else edge_attr.index_select(0, csc.perm)
-            ea = ea.to(self.lin_edge.weight.dtype)
-            # edge_dim (11) is no multiple of 8: zero-pad K so that forward, dX and dW all run on the MFMA kernels
+            wdt = self.lin_edge.weight.dtype
+            pkey = (id(edge_attr), id(csc.perm), wdt)
+            ea = None if edge_prep is None else edge_prep.get(pkey)
+            if ea is None:
+                ea = edge_attr if csc.perm is None else edge_attr.index_select(0, csc.perm)
+                ea = ea.to(wdt)
+                # edge_dim (11) is no multiple of 8: zero-pad K so that forward, dX and dW all run on the MFMA kernels
+                if wdt != torch.float32 and ea.shape[1] % 8:
+                    ea = torch.nn.functional.pad(ea, (0, (-ea.shape[1]) % 8))
+                if edge_prep is not None:
+                    edge_prep[pkey] = ea
+                    edge_prep.setdefault("anchors", []).append((edge_attr, csc.perm))  # keep the ids alive for this forward
             if not isinstance(self.edge_pre_mlp, nn.Identity):
                 ea = self._pad_edge(ea, self.edge_pre_mlp[0], act="gelu")
             e = self._pad_edge(ea, self.lin_edge)
+            if fused is not None and not self.qk_norm:
+                spec = {"A": query.shape[1], **{kk: fused[kk] for kk in ("q", "k", "v", "s")}}
+                return fused_attention(spec, fused["bufs"], e, csc, H, get_reverse_csr(csc))
             return attention(query, key, value, e, csc, H, get_reverse_csr(csc)) + x_r
         if isinstance(self.edge_pre_mlp, nn.Identity):
             feat = get_edge_features(edge_attr, csc.perm)
@@ -233,7 +249,8 @@ class GraphTransformerMapperBlock(GraphTransformerBaseBlock):
         w_kv, b_kv = self._fused.get("kv", [self.lin_key, self.lin_value])
         qs = ops.linear(xd_n, w_qs, b_qs)
         kv = ops.linear(xs_n, w_kv, b_kv)
-        out = self._attention(qs[:, :A], kv[:, :A], kv[:, A:], qs[:, A:], edge_attr, csc)
+        out = self._attention(qs[:, :A], kv[:, :A], kv[:, A:], qs[:, A:], edge_attr, csc,
+                              fused=dict(bufs=(qs, kv), q=(0, 0), s=(0, A), k=(1, 0), v=(1, A)))
         nodes_new_dst = self._post_attention(out, x_dst, cond_dst)
         if self.update_src_nodes:
             ln = self.layer_norm_mlp_src
@@ -309,14 +326,16 @@ class GraphTransformerProcessorBlock(GraphTransformerBaseBlock):
             qs = ops.linear(xn, w_qs, b_qs)
             kv = ops.linear(x_plus_halo, w_kv, b_kv)
             q, k, v, x_r = qs[:, :A], kv[:, :A], kv[:, A:], qs[:, A:]
+            fused = dict(bufs=(qs, kv), q=(0, 0), s=(0, A), k=(1, 0), v=(1, A))
             csc = get_csc(plan.edge_index_local, (plan.info.total_nodes, plan.info.num_local_nodes), True)
         else:
             n = x.shape[0]
             w, b = self._fused.get("qkvs", [self.lin_query, self.lin_key, self.lin_value, self.lin_self])
             qkvs = ops.linear(xn, w, b)
             q, k, v, x_r = qkvs[:, :A], qkvs[:, A:2 * A], qkvs[:, 2 * A:3 * A], qkvs[:, 3 * A:]
+            fused = dict(bufs=(qkvs,), q=(0, 0), k=(0, A), v=(0, 2 * A), s=(0, 3 * A))
             csc = get_csc(edge_index, (n, n), edges_are_dst_sorted)
-        out = self._attention(q, k, v, x_r, edge_attr, csc)
+        out = self._attention(q, k, v, x_r, edge_attr, csc, fused=fused, edge_prep=kwargs.get("edge_prep"))
         return self._post_attention(out, x, cond), edge_attr
 
 

@@ -98,15 +98,17 @@ class PaddedLinear:
         self._w = None
 
     def __call__(self, x: Tensor, lin: nn.Linear, **kw) -> Tensor:
-        K = x.shape[-1]
+        K = lin.weight.shape[1]
         pad = (-K) % 8
         if pad == 0 or x.dtype == torch.float32:
             return ops.linear(x, lin.weight, lin.bias, **kw)
+        if x.shape[-1] == K:  # else: the caller already zero-padded the rows (one padded copy shared by several layers)
+            x = torch.nn.functional.pad(x, (0, pad))
         if torch.is_grad_enabled() and lin.weight.requires_grad:  # training: gradients flow through the padding
-            return ops.linear(torch.nn.functional.pad(x, (0, pad)), torch.nn.functional.pad(lin.weight, (0, pad)), lin.bias, **kw)
+            return ops.linear(x, torch.nn.functional.pad(lin.weight, (0, pad)), lin.bias, **kw)
         sig = (lin.weight.data_ptr(), version(lin.weight), lin.weight.dtype, str(lin.weight.device))
         if self._sig != sig:
             with torch.no_grad():
                 self._w = torch.nn.functional.pad(lin.weight, (0, pad)).contiguous()
             self._sig = sig
-        return ops.linear(torch.nn.functional.pad(x, (0, pad)), self._w, lin.bias, **kw)
+        return ops.linear(x, self._w, lin.bias, **kw)

@@ -87,7 +87,7 @@ class GraphTransformerProcessor(BaseProcessor):
             shard_info = GraphShardInfo(nodes=shard_info.nodes, edges=edge_shard_sizes)
         x, _ = self.run_layers(
             (x, edge_attr), edge_index=edge_index, shard_info=shard_info, batch_size=batch_size, size=size,
-            model_comm_group=model_comm_group, edges_are_dst_sorted=True, halo_cache=self._halo_cache,
+            model_comm_group=model_comm_group, edges_are_dst_sorted=True, halo_cache=self._halo_cache, edge_prep={},
             ln_chain={},  # row statistics handed from a block's last GEMM to the next block's first (LayerNorm fold)
             **kwargs,
         )

@@ -155,9 +155,10 @@ def build_reverse_csr(csc: CSC) -> tuple[Tensor, Tensor, Tensor]:
 
 
 def gt_attention_backward(d_out: Tensor, q: Tensor, k: Tensor, v: Tensor, e: Tensor, out: Tensor, lse: Tensor, csc: CSC,
-                          reverse: tuple[Tensor, Tensor, Tensor], num_heads: int):
+                          reverse: tuple[Tensor, Tensor, Tensor], num_heads: int, grads_out=None):
     """Gradients (dq, dk, dv, de) of ``gt_attention`` with a materialised edge tensor.  All node/edge tensors [rows, D];
-    ``out``/``lse`` are the forward's results; ``reverse`` = build_reverse_csr(csc)."""
+    ``out``/``lse`` are the forward's results; ``reverse`` = build_reverse_csr(csc).  ``grads_out`` = (dq, dk, dv): write
+    the node gradients into these (row-strided) views, e.g. column slabs of one fused-projection gradient buffer."""
     rowptr, edge_ids, edge_dst = reverse
     _dev(d_out, q, k, v, e, out, lse, csc.row, rowptr, edge_ids, edge_dst)
     D = q.shape[1]
@@ -170,8 +171,15 @@ def gt_attention_backward(d_out: Tensor, q: Tensor, k: Tensor, v: Tensor, e: Ten
         raise ValueError("d_out/out must have q's shape and lse must be fp32 [n_dst, H]")
     if rowptr.shape[0] != csc.n_src + 1 or edge_ids.shape[0] != M or edge_dst.shape[0] != M:
         raise ValueError("reverse CSR does not match the graph")
-    dq, dk, dv, de = torch.empty_like(q, memory_format=torch.contiguous_format), torch.empty((csc.n_src, D), dtype=q.dtype, device=q.device), \
-        torch.empty((csc.n_src, D), dtype=q.dtype, device=q.device), torch.empty((M, D), dtype=q.dtype, device=q.device)
+    if grads_out is None:
+        dq, dk, dv = torch.empty_like(q, memory_format=torch.contiguous_format), torch.empty((csc.n_src, D), dtype=q.dtype, device=q.device), \
+            torch.empty((csc.n_src, D), dtype=q.dtype, device=q.device)
+    else:
+        dq, dk, dv = grads_out
+        if dq.shape != q.shape or dk.shape != k.shape or dv.shape != v.shape:
+            raise ValueError("grads_out shapes must equal q, k, v")
+    de = torch.empty((M, D), dtype=q.dtype, device=q.device)
+    (dqp, lddq), (dkp, lddk), (dvp, lddv) = _rows(dq, "dq", q.dtype), _rows(dk, "dk", q.dtype), _rows(dv, "dv", q.dtype)
     ws = torch.empty((2, M, num_heads), dtype=torch.float32, device=q.device)
     (qp, ldq), (kp, ldk), (vp, ldv), (ep, lde) = _rows(q, "q"), _rows(k, "k", q.dtype), _rows(v, "v", q.dtype), _rows(e, "e", q.dtype)
     (op, ldo), (gp, ldg) = _rows(out, "out", q.dtype), _rows(d_out, "d_out", q.dtype)
@@ -179,7 +187,7 @@ def gt_attention_backward(d_out: Tensor, q: Tensor, k: Tensor, v: Tensor, e: Ten
     rowptr, edge_ids, edge_dst = i32(rowptr), i32(edge_ids), i32(edge_dst)
     rc = _lib.load().anemoi_gt_attention_bwd(
         qp, ldq, kp, ldk, vp, ldv, ep, lde, op, ldo, lse.contiguous().data_ptr(), gp, ldg, csc.row.data_ptr(), csc.colptr.data_ptr(),
-        rowptr.data_ptr(), edge_ids.data_ptr(), edge_dst.data_ptr(), dq.data_ptr(), D, dk.data_ptr(), D, dv.data_ptr(), D,
+        rowptr.data_ptr(), edge_ids.data_ptr(), edge_dst.data_ptr(), dqp, lddq, dkp, lddk, dvp, lddv,
         de.data_ptr(), D, ws[0].data_ptr(), ws[1].data_ptr(), csc.n_dst, csc.n_src, M, num_heads, D // num_heads, _dt(q), _stream())
     _lib.check(rc, "gt_attention_bwd")
     return dq, dk, dv, de

@@ -99,6 +99,13 @@ def attention_train(q, k, v, e, csc, num_heads, reverse):
     return gt_attention(q, k, v, e, csc, num_heads)
 
 
+def fused_attention_train(spec, bufs, e, csc, num_heads, reverse):
+    """Stand-in for anemoi_core_amd.autograd.fused_attention: the same column slabs, plain torch."""
+    A = spec["A"]
+    slab = lambda key: bufs[spec[key][0]][:, spec[key][1]: spec[key][1] + A]  # noqa: E731
+    return gt_attention(slab("q"), slab("k"), slab("v"), e, csc, num_heads) + slab("s")
+
+
 def install(monkeypatch=None):
     """Patch anemoi_core_amd.ops in the current process (plain setattr when no pytest monkeypatch is given)."""
     names = ["gt_attention", "pack_edge_features", "pack_edge_weights", "gt_attention_fused_edge", "layer_norm", "linear",
@@ -107,8 +114,10 @@ def install(monkeypatch=None):
 
     if monkeypatch is not None:
         monkeypatch.setattr(_ag, "attention", attention_train)
+        monkeypatch.setattr(_ag, "fused_attention", fused_attention_train)
     else:
         _ag.attention = attention_train
+        _ag.fused_attention = fused_attention_train
     for n in names:
         if monkeypatch is not None:
             monkeypatch.setattr(real_ops, n, globals()[n])
