@@ -4,17 +4,17 @@
 // Reference semantics: autograd of torch.nn.LayerNorm / torch.nn.GELU (exact erf form) / the bias of torch.nn.Linear as
 // the reference's layer_kernels instantiate them (models/src/anemoi/models/layers/utils.py:107-121).
 //   x^ = (x - mean) rstd;  g = dy * gamma;  dx = rstd (g - mean(g) - x^ mean(g x^));  dgamma = sum_rows dy x^;  dbeta = sum_rows dy
-// Column sums are deterministic: a persistent grid of kPartialWaves waves walks the rows, each wave keeps its partial
-// column sums in registers and writes them once to an fp32 workspace [kPartialWaves][2][D]; a second tiny kernel adds the
-// partials in a fixed order (no atomics).
+// Column sums are deterministic: a persistent grid of kPartialBlocks x kBwdWaves waves walks the rows, each wave keeps its
+// partial column sums in registers, the waves of a block add theirs in LDS in wave order and the block writes one row of an
+// fp32 workspace [kPartialBlocks][2][D]; a second tiny kernel adds the partials in a fixed order (no atomics).
 #include "common.h"
 
 namespace anemoi {
 namespace {
 
 constexpr int kWaves = 4;             // waves per block
-constexpr int kPartialBlocks = 256;   // persistent grid: one block per CU
-constexpr int kPartialWaves = kPartialBlocks * kWaves;
+constexpr int kBwdWaves = 8;          // waves per block of the persistent row-walking kernels (16 waves per CU hide the
+constexpr int kPartialBlocks = 512;   // four dependent wave reductions of a LayerNorm-backward row): two blocks per CU
 constexpr int kMaxChunks = 8;
 
 template <typename T, int VEC, int CH>
@@ -33,13 +33,15 @@ __device__ __forceinline__ void load_row(const T* __restrict__ p, int D, int lan
 
 // MODE 0: LayerNorm backward (dx + partial dgamma/dbeta).  MODE 1: column sums of x only (bias gradient).
 template <typename T, int VEC, int CH, int MODE>
-__global__ __launch_bounds__(64 * kWaves) void rowwise_bwd_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ gamma,
+__global__ __launch_bounds__(64 * kBwdWaves) void rowwise_bwd_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ gamma,
                                                                   const T* __restrict__ dy, int64_t lddy, T* __restrict__ dx,
                                                                   int64_t lddx, float* __restrict__ part, int n_rows, int D,
                                                                   float eps) {
   const int lane = threadIdx.x & 63;
-  const int w = blockIdx.x * kWaves + (threadIdx.x >> 6);
-  const int nw = gridDim.x * kWaves;
+  extern __shared__ float block_sums[];  // [2][D]
+  const int wave = threadIdx.x >> 6;
+  const int w = blockIdx.x * kBwdWaves + wave;
+  const int nw = gridDim.x * kBwdWaves;
   float sg[CH][VEC], sb[CH][VEC], g[CH][VEC];
 #pragma unroll
   for (int t = 0; t < CH; ++t)
@@ -103,19 +105,25 @@ __global__ __launch_bounds__(64 * kWaves) void rowwise_bwd_kernel(const T* __res
       }
     }
   }
-  if (part != nullptr) {
-    float* p = part + (int64_t)w * 2 * D;
+  if (part != nullptr) {  // block-uniform
+    for (int k = 0; k < kBwdWaves; ++k) {  // fixed order: wave 0 stores, waves 1.. add
+      if (wave == k) {
 #pragma unroll
-    for (int t = 0; t < CH; ++t) {
-      const int c = (t * 64 + lane) * VEC;
-      if (c < D) {
+        for (int t = 0; t < CH; ++t) {
+          const int c = (t * 64 + lane) * VEC;
+          if (c < D) {
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-          p[c + j] = sg[t][j];
-          p[D + c + j] = sb[t][j];
+            for (int j = 0; j < VEC; ++j) {
+              block_sums[c + j] = k == 0 ? sg[t][j] : block_sums[c + j] + sg[t][j];
+              block_sums[D + c + j] = k == 0 ? sb[t][j] : block_sums[D + c + j] + sb[t][j];
+            }
+          }
         }
       }
+      __syncthreads();
     }
+    float* p = part + (int64_t)blockIdx.x * 2 * D;
+    for (int i = threadIdx.x; i < 2 * D; i += 64 * kBwdWaves) p[i] = block_sums[i];
   }
 }
 
@@ -182,21 +190,30 @@ __global__ __launch_bounds__(64 * kWaves) void cond_layernorm_bwd_kernel(const T
   }
 }
 
-// out0[c] = sum_w part[w][0][c], out1[c] = sum_w part[w][1][c].  One block per 64 columns of the [2D] row: 16 groups of 64
-// threads each add every 16th partial (coalesced 256-byte reads), then a fixed-order tree over the 16 groups in LDS:
-// deterministic, and 64 dependent loads per thread instead of one thread walking all partials.
+// out0[c] = sum_w part[w][0][c], out1[c] = sum_w part[w][1][c].  One block per 16 columns of the [2D] row: 64 groups of 16
+// threads each add every 64th partial row with four independent accumulators (loads in flight together), then a fixed-order
+// tree over the 64 groups in LDS: deterministic.
 __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ part, int nw, int D, float* __restrict__ out0,
                                                                float* __restrict__ out1) {
-  __shared__ float red[16][64];
-  const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
-  float s = 0.f;
-  if (c < 2 * D)
-    for (int w = grp; w < nw; w += 16) s += part[(int64_t)w * 2 * D + c];
-  red[grp][cl] = s;
+  __shared__ float red[64][17];
+  const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < 2 * D) {
+    const int64_t ld = 2 * (int64_t)D;
+    int w = grp;
+    for (; w + 192 < nw; w += 256) {
+      s0 += part[(int64_t)w * ld + c];
+      s1 += part[(int64_t)(w + 64) * ld + c];
+      s2 += part[(int64_t)(w + 128) * ld + c];
+      s3 += part[(int64_t)(w + 192) * ld + c];
+    }
+    for (; w < nw; w += 64) s0 += part[(int64_t)w * ld + c];
+  }
+  red[grp][cl] = (s0 + s1) + (s2 + s3);
   __syncthreads();
 #pragma unroll
-  for (int step = 8; step >= 1; step >>= 1) {
+  for (int step = 32; step >= 1; step >>= 1) {
     if (grp < step) red[grp][cl] += red[grp + step][cl];
     __syncthreads();
   }
@@ -381,17 +398,17 @@ int launch_rowwise_bwd(const void* x, int64_t ldx, const void* gamma, const void
   const int vec = MODE == 0 ? pick_vec<T>(D, {ldx, lddy, lddx}, {x, dy, dx, gamma}) : pick_vec<T>(D, {ldx}, {x});
   const int ch = pick_chunks(D, vec);
   ANEMOI_REQUIRE(ch > 0, "rowwise backward: D=%d too large for the register-resident row", D);
-  int blocks = (n_rows + kWaves - 1) / kWaves;
+  int blocks = (n_rows + kBwdWaves - 1) / kBwdWaves;
   blocks = blocks < kPartialBlocks ? blocks : kPartialBlocks;
   const bool want_sums = out0 != nullptr || out1 != nullptr;
   if (n_rows == 0) {  // no rows: the sums are zero
     if (!want_sums) return ANEMOI_OK;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * D + 63) / 64), dim3(1024), 0, st, ws, 0, D, out0, out1);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * D + 15) / 16), dim3(1024), 0, st, ws, 0, D, out0, out1);
     return check_launch("reduce_partials_kernel");
   }
 #define RB_CASE(V, C)                                                                                                          \
   case V * 16 + C:                                                                                                             \
-    hipLaunchKernelGGL((rowwise_bwd_kernel<T, V, C, MODE>), dim3(blocks), dim3(64 * kWaves), 0, st, (const T*)x, ldx,          \
+    hipLaunchKernelGGL((rowwise_bwd_kernel<T, V, C, MODE>), dim3(blocks), dim3(64 * kBwdWaves), 2 * D * sizeof(float), st, (const T*)x, ldx, \
                        (const T*)gamma, (const T*)dy, lddy, (T*)dx, lddx, want_sums ? ws : nullptr, n_rows, D, eps);           \
     break;
   switch (vec * 16 + ch) {
@@ -401,7 +418,7 @@ int launch_rowwise_bwd(const void* x, int64_t ldx, const void* gamma, const void
 #undef RB_CASE
   int rc = check_launch("rowwise_bwd_kernel");
   if (rc != ANEMOI_OK || !want_sums) return rc;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * D + 63) / 64), dim3(1024), 0, st, ws, blocks * kWaves, D, out0, out1);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * D + 15) / 16), dim3(1024), 0, st, ws, blocks, D, out0, out1);
   return check_launch("reduce_partials_kernel");
 }
 
@@ -497,7 +514,7 @@ int launch_cond_ln_bwd(const void* x, int64_t ldx, const void* scale, int64_t ld
 
 using namespace anemoi;
 
-extern "C" int64_t anemoi_reduce_workspace_bytes(int32_t D) { return (int64_t)kPartialWaves * 2 * (D > 0 ? D : 0) * (int64_t)sizeof(float); }
+extern "C" int64_t anemoi_reduce_workspace_bytes(int32_t D) { return (int64_t)kPartialBlocks * 2 * (D > 0 ? D : 0) * (int64_t)sizeof(float); }
 
 extern "C" int anemoi_layernorm_bwd(const void* x, int64_t ldx, const void* gamma, const void* d_y, int64_t lddy, void* d_x,
                                     int64_t lddx, float* d_gamma, float* d_beta, float* workspace, int32_t n_rows, int32_t D,

@@ -18,6 +18,8 @@
 //    the LDS-DMA, so it is free and replaces a separate two-kernel column reduction per layer;
 //  * the reduction is split over workgroups (a 10k-row, 2048x512 gradient has only 64 tiles for 256 CUs); every split writes
 //    its fp32 partial tile and a second kernel sums the partials in fixed order and converts: deterministic, no atomics.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace anemoi {
@@ -233,7 +235,12 @@ Plan make_plan(int n_rows, int O, int I) {
   p.tiles_m = (O + TM - 1) / TM;
   p.tiles_n = (I + TN - 1) / TN;
   const int nk = (n_rows + TK - 1) / TK, tiles = p.tiles_m * p.tiles_n;
-  int want = (512 + tiles - 1) / tiles;          // two workgroups per CU
+  static const int target = [] {  // workgroups to aim for: two per CU (developer override ANEMOI_WGRAD_WGS)
+    const char* e = getenv("ANEMOI_WGRAD_WGS");
+    const int v = e != nullptr ? atoi(e) : 0;
+    return v > 0 ? v : 512;
+  }();
+  int want = (target + tiles - 1) / tiles;
   want = want < 1 ? 1 : want;
   const int max_splits = nk / 4 > 0 ? nk / 4 : 1;  // at least four steps per split
   if (want > max_splits) want = max_splits;

@@ -21,12 +21,23 @@ if __name__ == "__main__":
     orig = ag._weight_grad
 
     def spy(dz, xx):
-        shapes[(dz.shape[0], dz.shape[1], xx.shape[1])] += 1
+        if not ag._tn_ok(dz, xx):
+            shapes[(dz.shape[0], dz.shape[1], xx.shape[1])] += 1
         return orig(dz, xx)
 
+    from anemoi_core_amd import ops
+
+    orig_tn = ops.linear_wgrad
+
+    def spy_tn(dz, xx, with_bias_grad=False):
+        shapes[(dz.shape[0], dz.shape[1], xx.shape[1])] += 1
+        return orig_tn(dz, xx, with_bias_grad)
+
     ag._weight_grad = spy
+    ops.linear_wgrad = spy_tn
     model(inp)["data"].float().square().mean().backward()
     ag._weight_grad = orig
+    ops.linear_wgrad = orig_tn
     torch.cuda.synchronize()
     total = 0.0
     print(f"{'rows':>8} {'out':>6} {'in':>6} {'calls':>5} {'us/call':>9} {'TFLOP/s':>8} {'ms/step':>8}")
