@@ -999,9 +999,9 @@ static bool ring_eligible(const LinArgs& a) {
   return k_ok && e_ok;
 }
 
-template <typename T, int EPI, int WM, bool PP, int WN = 2>
+template <typename T, int EPI, int WM, bool PP, int WN = 2, int ST = 3>
 static int launch_persistent_wm(const LinArgs& a, hipStream_t st) {
-  constexpr int ST = 3;  // (64*WM) x (64*WN) tile, WM*WN waves, 3-stage ring (144 KiB at 4 x 2: one workgroup per CU)
+  // (64*WM) x (64*WN) tile, WM*WN waves, ST-stage ring (3 stages = 144 KiB at 4 x 2: one workgroup per CU)
   constexpr int smem_bytes = ST * (64 * WM + 64 * WN) * BK * 2 + 1024;
   static bool attr_set = false;
   if (!attr_set) {
@@ -1066,7 +1066,13 @@ static int launch_persistent(const LinArgs& a, hipStream_t st) {
   // few tiles (small M, e.g. one rank's rows of a sharded mesh): 64 x 128 tiles on more CUs; the K-loop of a lone tile
   // is bound by the ~40 cycles a CU needs per 1-KiB LDS-DMA piece, i.e. by the tile's operand bytes, like the model says
   const double c1 = tile_cost_us(64, 128, a.n_rows, a.O, nk);
-  if (c1 < 0.9 * (c3 < c4 ? c3 : c4)) return launch_persistent_wm<T, EPI, 1, false, 2>(a, st);
+  if (c1 < 0.9 * (c3 < c4 ? c3 : c4)) {
+    // a lone small tile walks its K-loop at DMA latency / stages in flight: long K -> deeper ring (24.5 KiB per stage)
+    static const int deep = [] { const char* e = getenv("ANEMOI_GEMM_SMALL_STAGES"); return e ? atoi(e) : 3; }();
+    if (nk >= 16 && deep == 5) return launch_persistent_wm<T, EPI, 1, false, 2, 5>(a, st);
+    if (nk >= 16 && deep == 4) return launch_persistent_wm<T, EPI, 1, false, 2, 4>(a, st);
+    return launch_persistent_wm<T, EPI, 1, false, 2>(a, st);
+  }
   static const bool pp = [] { const char* e = getenv("ANEMOI_GEMM_PP"); return !(e && e[0] == '0'); }();
   if (pp) {
     if (c3 < c4) return launch_persistent_wm<T, EPI, 3, true>(a, st);

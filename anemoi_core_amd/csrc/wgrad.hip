@@ -27,8 +27,6 @@ namespace {
 
 constexpr int TM = 128, TN = 128, TK = 64;
 constexpr int kPiece = 1024;                 // bytes per DMA piece: [8 rows][64 cols] of 16-bit
-constexpr int kOperandBytes = TK * TM * 2;   // 16 KiB: 16 pieces, index (row_group << 1) | col_half
-constexpr int kStageBytes = 2 * kOperandBytes;
 
 using frag8 = __attribute__((ext_vector_type(8))) short;
 using s16x4 = __attribute__((ext_vector_type(4))) short;
@@ -75,8 +73,13 @@ __device__ __forceinline__ frag8 ones_frag<f16_t>() {
 
 // BIAS: the column sums of dZ (the bias gradient) ride along as one more MFMA per 16 columns against an all-ones operand in
 // the waves that own the first 64 input columns of the first tile column - the kernel is bound by the LDS-DMA, not the MFMAs.
-template <typename T, bool BIAS>
+// TKS rows per LDS stage (64 or 32), STAGES-deep ring: the DMA is bound by bytes in flight x latency, so more, smaller stages in
+// the same 64 KiB keep more of it in flight.
+template <typename T, bool BIAS, int TKS, int STAGES>
 __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(WgradArgs a) {
+  constexpr int kOpBytes = TKS * TM * 2;      // one operand of one stage: TKS / 8 row groups x 2 column halves of 1 KiB
+  constexpr int kStage = 2 * kOpBytes;
+  constexpr int PPW = TKS / 16;               // pieces per wave per operand per stage
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -84,11 +87,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(WgradArgs a) {
   const int tiles = a.tiles_m * a.tiles_n;
   const int split = blockIdx.x / tiles, tile = blockIdx.x % tiles;
   const int m0 = (tile / a.tiles_n) * TM, n0 = (tile % a.tiles_n) * TN;
-  const int nk_total = (a.n_rows + TK - 1) / TK;
-  const int kt0 = split * a.steps_per_split;
-  const int nk = min(a.steps_per_split, nk_total - kt0);
+  const int nk_total = (a.n_rows + TKS - 1) / TKS;
+  const int kt0 = split * a.steps_per_split * (TK / TKS);  // the plan counts 64-row steps
+  const int nk = min(a.steps_per_split * (TK / TKS), nk_total - kt0);
 
-  // ---- DMA assignment: wave w fills pieces 4w..4w+3 of each operand: row group 2w + (j >> 1), column half j & 1
+  // ---- DMA assignment: wave w fills pieces PPW w .. PPW w + PPW - 1 of each operand: piece p = row group p >> 1, column half p & 1
   const int k_in = lane >> 3;
   const int gran = (lane & 7) ^ (((k_in >> 1) & 3) << 1);  // granule (8 columns) this lane fetches for its LDS slot
   const unsigned char* zero = g_zero_line + (lane & 7) * 16;
@@ -105,15 +108,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(WgradArgs a) {
   const int64_t a_row_bytes = a.lddz * 2, b_row_bytes = a.ldx * 2;
 
   auto issue = [&](int kt, int stage) {
-    const uint32_t base = smem_l + stage * kStageBytes + wave * 4 * kPiece;
+    const uint32_t base = smem_l + stage * kStage + wave * PPW * kPiece;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = (kt0 + kt) * TK + (2 * wave + (j >> 1)) * 8 + k_in;
+    for (int j = 0; j < PPW; ++j) {
+      const int row = (kt0 + kt) * TKS + ((wave * PPW + j) >> 1) * 8 + k_in;
       const bool rv = row < a.n_rows;
       const unsigned char* sa = (rv && a_col[j & 1] >= 0) ? dzp + row * a_row_bytes + a_col[j & 1] : zero;
       const unsigned char* sb = (rv && b_col[j & 1] >= 0) ? xp + row * b_row_bytes + b_col[j & 1] : zero;
       __builtin_amdgcn_global_load_lds((gbl_void_t*)sa, (lds_void_t*)(size_t)(base + j * kPiece), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)sb, (lds_void_t*)(size_t)(base + kOperandBytes + j * kPiece), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)sb, (lds_void_t*)(size_t)(base + kOpBytes + j * kPiece), 16, 0, 0);
     }
   };
 
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(WgradArgs a) {
     const int slot = ((t ^ s2) << 1) | (q >> 1);
     const uint32_t in_piece = fk * 128 + slot * 16 + (q & 1) * 8;
     a_off[t] = ((g >> 1) * 2 + wr) * kPiece + in_piece;
-    b_off[t] = kOperandBytes + ((g >> 1) * 2 + wc) * kPiece + in_piece;
+    b_off[t] = kOpBytes + ((g >> 1) * 2 + wc) * kPiece + in_piece;
   }
 
   f32x4 acc[4][4];
@@ -148,9 +151,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(WgradArgs a) {
   };
 
   auto compute = [&](int stage) {
-    const uint32_t base = smem_l + stage * kStageBytes;
+    const uint32_t base = smem_l + stage * kStage;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {  // two 32-row MFMA blocks: row groups 4 kb .. 4 kb + 3 -> + 8 KiB
+    for (int kb = 0; kb < TKS / 32; ++kb) {  // 32-row MFMA blocks: row groups 4 kb .. 4 kb + 3 -> + 8 KiB
       frag8 fa[4], fb[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -170,12 +173,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(WgradArgs a) {
     }
   };
 
-  if (nk > 0) issue(0, 0);
+  // ring: stages kt+1 .. kt+STAGES-1 are in flight while stage kt is consumed
+#pragma unroll
+  for (int p = 0; p < STAGES - 1; ++p)
+    if (p < nk) issue(p, p);
   for (int kt = 0; kt < nk; ++kt) {
-    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's pieces of step kt have landed
-    __syncthreads();                     // ... everybody's have, and everybody finished reading the other buffer
-    if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-    compute(kt & 1);
+    if (kt + STAGES - 2 < nk) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * 2 * PPW) : "memory");  // all but the newest STAGES-2 steps landed
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();  // everybody's pieces of step kt are in LDS, and everybody finished reading step kt-1 (raw: a
+                                   // __syncthreads() would drain the DMA queue)
+    if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
+    compute(kt % STAGES);
   }
 
   // ---- partial tile: lane holds dW[m][n .. n+3], m = .. + (lane & 15), n = .. + 4 (lane >> 4)
@@ -251,14 +262,24 @@ Plan make_plan(int n_rows, int O, int I) {
 
 hipStream_t as_hip_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
-template <typename T, bool BIAS>
-int launch_wgrad_kernel(const WgradArgs& a, hipStream_t st) {
+template <typename T, bool BIAS, int TKS, int STAGES>
+int launch_wgrad_cfg(const WgradArgs& a, hipStream_t st) {
+  constexpr int lds = STAGES * 2 * TKS * TM * 2;
   static const int once = [] {
-    return (int)hipFuncSetAttribute((const void*)wgrad_tn_kernel<T, BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStageBytes);
+    return (int)hipFuncSetAttribute((const void*)wgrad_tn_kernel<T, BIAS, TKS, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }();
   (void)once;
-  hipLaunchKernelGGL((wgrad_tn_kernel<T, BIAS>), dim3(a.tiles_m * a.tiles_n * a.splits), dim3(256), 2 * kStageBytes, st, a);
+  hipLaunchKernelGGL((wgrad_tn_kernel<T, BIAS, TKS, STAGES>), dim3(a.tiles_m * a.tiles_n * a.splits), dim3(256), lds, st, a);
   return check_launch("wgrad_tn_kernel");
+}
+
+template <typename T, bool BIAS>
+int launch_wgrad_kernel(const WgradArgs& a, hipStream_t st) {
+  static const int cfg = [] {  // developer switch: 0 = 2 stages of 64 rows, 1 = 4 stages of 32 rows (same 64 KiB)
+    const char* e = getenv("ANEMOI_WGRAD_RING");
+    return e != nullptr ? atoi(e) : 0;  // measured: the deeper ring is 5-15 % slower (twice the barriers)
+  }();
+  return cfg == 0 ? launch_wgrad_cfg<T, BIAS, 64, 2>(a, st) : launch_wgrad_cfg<T, BIAS, 32, 4>(a, st);
 }
 
 template <typename T>
