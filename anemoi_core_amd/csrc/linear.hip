@@ -711,6 +711,109 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void linear_mfma_persistent_kernel
   }
 }
 
+// ---------------------------------------------------------------------------------------------- small M: K split over waves
+// Few output tiles (one rank's rows of a sharded mesh, small meshes): a lone 64 x 128 tile worked by two waves walks its
+// K-loop at ~0.6 us per 64-wide step (DMA issue, fragment reads and 32 MFMAs serialised in each wave), so a K = 2048 GEMM on
+// 1.3 k rows takes 23 us on a mostly idle chip.  Here the tile gets 8 waves = 4 K-groups x 2 column halves: a stage holds 128
+// K elements, group kg multiplies the 32-wide block kg of every stage (16 MFMAs per wave and stage, 6 DMA pieces per wave),
+// and the four partial accumulators are added through LDS in group order (deterministic) before the usual epilogue.
+//   LDS stage = [64 + 128 rows][256 B], 16-byte slots XOR-swizzled with (row & 15): conflict-free fragment ds_read_b128 (16
+//   lanes = 16 rows of one slot column) while a DMA piece stays lane-linear (4 rows x 16 slots, the lane fetches the slot that
+//   belongs at its position).
+constexpr int SK = 128, SM = 64, SN = 128, kSStages = 3;
+constexpr int kSRow = SK * 2, kSA = SM * kSRow, kSStage = (SM + SN) * kSRow;
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(512, 1) void linear_mfma_splitwave_kernel(LinArgs a, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kg = wave >> 1, wc = wave & 1;
+  const int m0 = (blockIdx.x / tiles_n) * SM, n0 = (blockIdx.x % tiles_n) * SN;
+  const int nk = a.K1 / SK;
+  const uint32_t smem_l = (uint32_t)(size_t)(lds_void_t*)smem;
+
+  // DMA: 16 A pieces + 32 W pieces (4 rows x 256 B) per stage, 6 per wave
+  const int pr = lane >> 4, pos = lane & 15;
+  const char* src_row[6];
+  uint32_t dst_off[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int p = wave * 6 + j;
+    const bool is_a = p < 16;
+    const int row_t = (is_a ? p : p - 16) * 4 + pr;
+    const int slot = pos ^ (row_t & 15);
+    const int64_t row_g = is_a ? min(m0 + row_t, a.n_rows - 1) : min(n0 + row_t, a.O - 1);  // clamped rows are never stored
+    src_row[j] = (is_a ? (const char*)a.x + row_g * a.ldx * 2 : (const char*)a.w + row_g * a.ldw * 2) + slot * 16;
+    dst_off[j] = (is_a ? 0 : kSA) + (is_a ? p : p - 16) * 1024;
+  }
+  auto issue = [&](int kt) {
+    const uint32_t base = smem_l + (kt % kSStages) * kSStage;
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(src_row[j] + (int64_t)kt * kSRow), (lds_void_t*)(size_t)(base + dst_off[j]), 16, 0, 0);
+  };
+
+  // fragments: row (lane & 15) of every 16-row block, logical slot 4 kg + (lane >> 4)
+  const int frow = lane & 15;
+  const int fphys = ((kg * 4 + (lane >> 4)) ^ frow) << 4;
+  const int a_rd = frow * kSRow + fphys;
+  const int w_rd = kSA + (wc * 64 + frow) * kSRow + fphys;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int p = 0; p < kSStages - 1; ++p)
+    if (p < nk) issue(p);
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + kSStages - 2 < nk) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kSStages - 2) * 6) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();  // stage kt complete for every wave; stage kt-1 no longer read by anybody
+    if (kt + kSStages - 1 < nk) issue(kt + kSStages - 1);
+    const unsigned char* st = smem + (kt % kSStages) * kSStage;
+    frag8 fa[4], fw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      fa[i] = *reinterpret_cast<const frag8*>(st + a_rd + i * 16 * kSRow);
+      fw[i] = *reinterpret_cast<const frag8*>(st + w_rd + i * 16 * kSRow);
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16<T>(fw[ni], fa[mi], acc[mi][ni]);
+  }
+
+  // add the four K-groups in group order; 16 KiB of LDS per non-leading wave, 4 KiB epilogue bands behind them
+  __syncthreads();
+  if (kg > 0) {
+    f32x4* dst = reinterpret_cast<f32x4*>(smem + (wave - 2) * 16384) + lane;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dst[(i * 4 + j) * 64] = acc[i][j];
+  }
+  __syncthreads();
+  if (kg == 0) {
+#pragma unroll
+    for (int gsrc = 1; gsrc < 4; ++gsrc) {
+      const f32x4* src = reinterpret_cast<const f32x4*>(smem + ((gsrc - 1) * 2 + wc) * 16384) + lane;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += src[(i * 4 + j) * 64];
+    }
+    const bool interior = (m0 + SM <= a.n_rows) && (n0 + SN <= a.O);
+    mfma_epilogue_band<T, EPI>(a, acc, m0, n0, 0, wc, lane, smem + 6 * 16384 + wc * 4096, interior);
+  }
+}
+
+
 // ---------------------------------------------------------------------------------------------- tail rows
 // A handful of rows (the 2 rows by which an icosphere's 10 * 4^r + 2 nodes exceed a multiple of the big tile): one wave
 // per output column, lanes split K in 16-byte chunks, fp32 dot product + butterfly, lane 0 applies the epilogue.
@@ -1018,6 +1121,20 @@ static int launch_persistent_wm(const LinArgs& a, hipStream_t st) {
   return check_launch("linear_mfma_persistent_kernel");
 }
 
+template <typename T, int EPI>
+static int launch_splitwave(const LinArgs& a, hipStream_t st) {
+  constexpr int smem_bytes = kSStages * kSStage;  // 144 KiB (the reduction / epilogue staging reuses it)
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_mfma_splitwave_kernel<T, EPI>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+    attr_set = true;
+  }
+  const int tm = (a.n_rows + SM - 1) / SM, tn = (a.O + SN - 1) / SN;
+  hipLaunchKernelGGL((linear_mfma_splitwave_kernel<T, EPI>), dim3(tm * tn), dim3(512), smem_bytes, st, a, tn);
+  return check_launch("linear_mfma_splitwave_kernel");
+}
+
 template <typename T, int EPI, int MI>
 static int launch_bigtile(const LinArgs& a, hipStream_t st) {
   constexpr int TBM = 32 * MI, TBN = 256;
@@ -1067,6 +1184,12 @@ static int launch_persistent(const LinArgs& a, hipStream_t st) {
   // is bound by the ~40 cycles a CU needs per 1-KiB LDS-DMA piece, i.e. by the tile's operand bytes, like the model says
   const double c1 = tile_cost_us(64, 128, a.n_rows, a.O, nk);
   if (c1 < 0.9 * (c3 < c4 ? c3 : c4)) {
+    if constexpr ((EPI & (EPI_STATS | EPI_LNFOLD)) == 0) {
+      // at most one round of 64 x 128 tiles: give every tile 8 waves (K split over wave groups) instead of 2
+      static const bool sw = [] { const char* e = getenv("ANEMOI_GEMM_SPLITWAVE"); return !(e && e[0] == '0'); }();
+      const int64_t t1 = (int64_t)((a.n_rows + SM - 1) / SM) * ((a.O + SN - 1) / SN);
+      if (sw && t1 <= 256 && a.K2 == 0 && a.K1 % SK == 0 && a.splits == 1 && !a.f32_atomic) return launch_splitwave<T, EPI>(a, st);
+    }
     // a lone small tile walks its K-loop at DMA latency / stages in flight: long K -> deeper ring (24.5 KiB per stage)
     static const int deep = [] { const char* e = getenv("ANEMOI_GEMM_SMALL_STAGES"); return e ? atoi(e) : 3; }();
     if (nk >= 16 && deep == 5) return launch_persistent_wm<T, EPI, 1, false, 2, 5>(a, st);
