@@ -352,23 +352,33 @@ class GraphTransformerProcessorBlock(GraphTransformerBaseBlock):
         H, C, A = self.num_heads, self.out_channels_conv, self.attn_channels
         if H % P:
             raise ValueError(f"shard_strategy='heads': num_heads ({H}) must be divisible by the model-parallel size ({P})")
-        if ops._needs_grad(xn, self.lin_edge.weight):
-            raise NotImplementedError("the backward of the heads strategy is not built; train with shard_strategy='edges'")
+        train = ops._needs_grad(xn, edge_attr, self.lin_edge.weight)
         Hl, sizes = H // P, list(shard_info.nodes)
         n_loc, n_full = xn.shape[0], sum(sizes)
         # the whole graph (static): edge slices are dst-owned and contiguous, so rank order = global dst-sorted order
-        key = (edge_index.data_ptr(), version(edge_index), edge_attr.data_ptr(), version(edge_attr), P, rank)
+        key = (edge_index.data_ptr(), version(edge_index), P, rank)
         full = None if cache is None else cache.get("heads_full")
         if full is None or full[0] != key:
             if shard_info.edges_are_sharded():
                 ei_full = comm.gather_tensor(edge_index.t().contiguous(), 0, shard_info.edges, group).t().contiguous()
-                ea_full = comm.gather_tensor(edge_attr.contiguous(), 0, shard_info.edges, group)
             else:
-                ei_full, ea_full = edge_index, edge_attr
-            full = (key, ei_full, ea_full, (edge_index, edge_attr))
+                ei_full = edge_index
+            full = (key, ei_full, (edge_index,))
             if cache is not None:
                 cache["heads_full"] = full
-        _, ei_full, ea_full, _ = full
+        ei_full = full[1]
+        if not shard_info.edges_are_sharded():
+            ea_full = edge_attr
+        elif train:  # every rank works on every edge (for its heads): the owners' gradients are summed over the ranks
+            ea_full = comm.gather_tensor(edge_attr.contiguous(), 0, shard_info.edges, group, reduce_in_backward=True)
+        else:  # static attributes: gathered once
+            akey = (edge_attr.data_ptr(), version(edge_attr), key)
+            hit = None if cache is None else cache.get("heads_attr")
+            if hit is None or hit[0] != akey:
+                hit = (akey, comm.gather_tensor(edge_attr.contiguous(), 0, shard_info.edges, group), edge_attr)
+                if cache is not None:
+                    cache["heads_attr"] = hit
+            ea_full = hit[1]
         csc = get_csc(ei_full, (n_full, n_full), True)
 
         def to_heads(t):  # [n_loc, A] all heads -> [n_full, Hl*C] my heads
@@ -384,9 +394,22 @@ class GraphTransformerProcessorBlock(GraphTransformerBaseBlock):
             k = self.k_norm(k.reshape(-1, Hl, C)).view(-1, Hl * C)
         if not isinstance(self.edge_pre_mlp, nn.Identity):
             raise NotImplementedError("edge_pre_mlp with shard_strategy='heads'")
-        feat = get_edge_features(ea_full, csc.perm)
-        w_edge = self._fused.packed_edge(self.lin_edge)[rank * Hl * C:(rank + 1) * Hl * C]
-        o = ops.gt_attention_fused_edge(q, k, v, feat, w_edge, csc, Hl)  # [n_full, Hl*C]
+        rows = slice(rank * Hl * C, (rank + 1) * Hl * C)  # this rank's heads of lin_edge
+        if train:  # materialised E for this rank's heads, attention through the differentiable op (scope row f1 x f2)
+            from ..autograd import attention
+
+            lin = self.lin_edge
+            ea = ea_full if csc.perm is None else ea_full.index_select(0, csc.perm)
+            ea = ea.to(lin.weight.dtype)
+            w_e = lin.weight[rows]
+            pad = (-ea.shape[1]) % 8
+            if pad and ea.dtype != torch.float32:  # 16-bit operand rows must be 16-byte aligned
+                ea, w_e = torch.nn.functional.pad(ea, (0, pad)), torch.nn.functional.pad(w_e, (0, pad))
+            e = ops.linear(ea, w_e, None if lin.bias is None else lin.bias[rows])
+            o = attention(q, k, v, e, csc, Hl, get_reverse_csr(csc))
+        else:
+            feat = get_edge_features(ea_full, csc.perm)
+            o = ops.gt_attention_fused_edge(q, k, v, feat, self._fused.packed_edge(self.lin_edge)[rows], csc, Hl)  # [n_full, Hl*C]
         back = comm.all_to_all_rows(o, sizes, [n_loc] * P, group)  # [P*n_loc, Hl*C]: block r = heads of rank r
         out = back.reshape(P, n_loc, Hl * C).permute(1, 0, 2).reshape(n_loc, A) + x_r
         return self._post_attention(out, x, cond)

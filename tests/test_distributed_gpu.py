@@ -156,3 +156,43 @@ def test_heads_strategy_on_hip_kernels_equals_unsharded_reference():
     s = load_golden("sharding.pt")
     outs = _spawn(_heads_worker, 2)
     assert float((torch.cat([o["out"] for o in outs]) - s["out"]).abs().max()) < 1e-4
+
+
+def _heads_grad_worker(rank, world, group):
+    from anemoi_core_amd.distributed.primitives import reduce_parameter_gradients, shard_tensor
+    from anemoi_core_amd.distributed.shapes import GraphShardInfo, get_shard_sizes
+    from anemoi_core_amd.layers.processor import GraphTransformerProcessor
+
+    s = load_golden("sharding.pt")
+    proc = GraphTransformerProcessor(**{**s["cfg"], "shard_strategy": "heads"}).train().cuda()
+    proc.load_state_dict(s["params"], strict=True)
+    x, ea, ei = s["x"].cuda(), s["edge_attr"].cuda(), s["edge_index"].cuda()
+    sizes = get_shard_sizes(x, 0, group)
+    x_loc = shard_tensor(x, 0, sizes, group).clone().requires_grad_(True)
+    w = torch.randn(s["out"].shape, generator=torch.Generator().manual_seed(5)).cuda()
+    y = proc(x_loc, 1, GraphShardInfo(nodes=sizes, edges=None), ea, ei, model_comm_group=group)
+    r0 = sum(sizes[:rank])
+    (y * w[r0:r0 + sizes[rank]]).sum().backward()
+    reduce_parameter_gradients(proc, group)
+    return dict(out=y.detach().cpu(), dx=x_loc.grad.cpu(), grads={k: p.grad.cpu() for k, p in proc.named_parameters()})
+
+
+def test_heads_strategy_backward_on_hip_kernels():
+    """Training through shard_strategy="heads" on the HIP kernels (2 ranks on the one GPU) == the single-GPU gradients of the
+    same module (which tests/test_training_gpu.py pins to oracle autograd)."""
+    from anemoi_core_amd.distributed.shapes import GraphShardInfo
+    from anemoi_core_amd.layers.processor import GraphTransformerProcessor
+
+    s = load_golden("sharding.pt")
+    outs = _spawn(_heads_grad_worker, 2)
+    proc = GraphTransformerProcessor(**s["cfg"]).train().cuda()
+    proc.load_state_dict(s["params"], strict=True)
+    x = s["x"].cuda().requires_grad_(True)
+    w = torch.randn(s["out"].shape, generator=torch.Generator().manual_seed(5)).cuda()
+    (proc(x, 1, GraphShardInfo(), s["edge_attr"].cuda(), s["edge_index"].cuda()) * w).sum().backward()
+    ref = {k: p.grad.cpu() for k, p in proc.named_parameters()}
+    assert float((torch.cat([o["out"] for o in outs]) - s["out"]).abs().max()) < 1e-4
+    assert float((torch.cat([o["dx"] for o in outs]) - x.grad.cpu()).abs().max()) <= 3e-4 * float(x.grad.abs().max())
+    for o in outs:
+        for k, g in o["grads"].items():
+            assert float((g - ref[k]).abs().max()) <= 3e-4 * float(ref[k].abs().max()) + 1e-6, k
