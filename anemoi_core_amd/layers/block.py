@@ -177,6 +177,76 @@ class GraphTransformerBaseBlock(BaseBlock):
             feat = ops.pack_edge_features(ea)
         return ops.gt_attention_fused_edge(query, key, value, feat, self._fused.packed_edge(self.lin_edge), csc, H, addend=x_r)
 
+    # -- heads ("Ulysses") strategy: reference block.py:689-759, 838-854 ----------------------------------------------
+    def _heads_full_graph(self, edge_attr, edge_index, edge_sizes, group, train: bool, cache: Optional[dict]):
+        """(edge_index, edge_attr) of the WHOLE graph on every rank.  Edge slices are dst-owned and contiguous, so rank
+        order = global dst-sorted order.  The index part is cached; static attributes are gathered once, differentiable
+        ones per step with their gradients summed over the ranks (every rank works on every edge, for its heads)."""
+        P, rank = comm_size(group), comm_rank(group)
+        if edge_sizes is None:
+            return edge_index, edge_attr
+        key = (edge_index.data_ptr(), version(edge_index), P, rank)
+        full = None if cache is None else cache.get("heads_full")
+        if full is None or full[0] != key:
+            full = (key, comm.gather_tensor(edge_index.t().contiguous(), 0, edge_sizes, group).t().contiguous(), (edge_index,))
+            if cache is not None:
+                cache["heads_full"] = full
+        if train:
+            return full[1], comm.gather_tensor(edge_attr.contiguous(), 0, edge_sizes, group, reduce_in_backward=True)
+        akey = (edge_attr.data_ptr(), version(edge_attr), key)
+        hit = None if cache is None else cache.get("heads_attr")
+        if hit is None or hit[0] != akey:
+            hit = (akey, comm.gather_tensor(edge_attr.contiguous(), 0, edge_sizes, group), edge_attr)
+            if cache is not None:
+                cache["heads_attr"] = hit
+        return full[1], hit[1]
+
+    def _heads_attention(self, q_loc: Tensor, k_loc: Tensor, v_loc: Tensor, ea_full: Tensor, ei_full: Tensor, src_sizes, dst_sizes,
+                         group, train: bool) -> Tensor:
+        """Nodes sharded for the dense work, HEADS sharded for the attention: q (local destination rows) and k, v (local
+        source rows) are transposed by one all-to-all each into all rows x (H / P) heads, the attention runs on the whole
+        graph for this rank's heads, and a fourth all-to-all brings the local destination rows back with all heads
+        ([n_dst_local, A]).  Unlike the reference the edge term is not moved at all (there: a fourth [M, H*C] transpose
+        per layer): every rank applies its rows of ``lin_edge`` to the (gathered) edge attributes."""
+        P, rank = comm_size(group), comm_rank(group)
+        H, C, A = self.num_heads, self.out_channels_conv, self.attn_channels
+        if H % P:
+            raise ValueError(f"shard_strategy='heads': num_heads ({H}) must be divisible by the model-parallel size ({P})")
+        if not isinstance(self.edge_pre_mlp, nn.Identity):
+            raise NotImplementedError("edge_pre_mlp with shard_strategy='heads'")
+        Hl = H // P
+        src_sizes, dst_sizes = list(src_sizes), list(dst_sizes)
+        csc = get_csc(ei_full, (sum(src_sizes), sum(dst_sizes)), True)
+
+        def to_heads(t, sizes):  # [n_loc, A] all heads -> [n_full, Hl*C] my heads
+            n_loc = t.shape[0]
+            send = t.reshape(n_loc, P, Hl * C).permute(1, 0, 2).reshape(P * n_loc, Hl * C)
+            return comm.all_to_all_rows(send, [n_loc] * P, sizes, group)
+
+        q, k, v = to_heads(q_loc, dst_sizes), to_heads(k_loc, src_sizes), to_heads(v_loc, src_sizes)
+        if self.qk_norm:  # per-head LayerNorm over C: applied to this rank's heads (block.py:748)
+            q = self.q_norm(q.reshape(-1, Hl, C)).view(-1, Hl * C)
+            k = self.k_norm(k.reshape(-1, Hl, C)).view(-1, Hl * C)
+        rows = slice(rank * Hl * C, (rank + 1) * Hl * C)  # this rank's heads of lin_edge
+        if train:  # materialised E for this rank's heads, attention through the differentiable op (scope rows f1 x f2)
+            from ..autograd import attention
+
+            lin = self.lin_edge
+            ea = ea_full if csc.perm is None else ea_full.index_select(0, csc.perm)
+            ea = ea.to(lin.weight.dtype)
+            w_e = lin.weight[rows]
+            pad = (-ea.shape[1]) % 8
+            if pad and ea.dtype != torch.float32:  # 16-bit operand rows must be 16-byte aligned
+                ea, w_e = torch.nn.functional.pad(ea, (0, pad)), torch.nn.functional.pad(w_e, (0, pad))
+            e = ops.linear(ea, w_e, None if lin.bias is None else lin.bias[rows])
+            o = attention(q, k, v, e, csc, Hl, get_reverse_csr(csc))
+        else:
+            feat = get_edge_features(ea_full, csc.perm)
+            o = ops.gt_attention_fused_edge(q, k, v, feat, self._fused.packed_edge(self.lin_edge)[rows], csc, Hl)  # [n_dst_full, Hl*C]
+        n_loc = q_loc.shape[0]
+        back = comm.all_to_all_rows(o, dst_sizes, [n_loc] * P, group)  # [P*n_loc, Hl*C]: block r = heads of rank r
+        return back.reshape(P, n_loc, Hl * C).permute(1, 0, 2).reshape(n_loc, A)
+
     def _ln_fold_ok(self, ln, x: Tensor) -> bool:
         """The LayerNorm-fold path: inference, 16-bit, plain affine LayerNorm (see include/anemoi_hip.h)."""
         return (_LN_FOLD and type(ln).__name__ in ("LayerNorm", "AutocastLayerNorm") and x.dtype != torch.float32 and x.is_cuda
@@ -235,11 +305,14 @@ class GraphTransformerMapperBlock(GraphTransformerBaseBlock):
 
     def forward(self, x, edge_attr: Tensor, edge_index: Tensor, shard_info: BipartiteGraphShardInfo, batch_size: int,
                 size, model_comm_group=None, cond=None, edges_are_dst_sorted: bool = True, **layer_kwargs):
-        if self.shard_strategy == "heads" and model_is_distributed(model_comm_group):
-            raise NotImplementedError("shard_strategy='heads' (Ulysses all-to-all) is scope row f2 (next); use 'edges'")
         x_src, x_dst = x
         size = (size, size) if isinstance(size, int) else tuple(size)
-        csc = get_csc(edge_index, size, edges_are_dst_sorted)
+        heads = self.shard_strategy == "heads" and model_is_distributed(model_comm_group)
+        if heads:  # x_src / x_dst are this rank's rows, edge_index / edge_attr the whole graph (see the mapper)
+            if batch_size != 1:
+                raise ValueError("shard_strategy='heads' requires batch_size=1 when model sharding is enabled.")
+        else:
+            csc = get_csc(edge_index, size, edges_are_dst_sorted)
         A = self.attn_channels
         ln_s, ln_d = self.layer_norm_attention_src, self.layer_norm_attention_dest
         cond_src, cond_dst = cond if cond is not None else (None, None)  # block.py:979-980
@@ -249,8 +322,13 @@ class GraphTransformerMapperBlock(GraphTransformerBaseBlock):
         w_kv, b_kv = self._fused.get("kv", [self.lin_key, self.lin_value])
         qs = ops.linear(xd_n, w_qs, b_qs)
         kv = ops.linear(xs_n, w_kv, b_kv)
-        out = self._attention(qs[:, :A], kv[:, :A], kv[:, A:], qs[:, A:], edge_attr, csc,
-                              fused=dict(bufs=(qs, kv), q=(0, 0), s=(0, A), k=(1, 0), v=(1, A)))
+        if heads:
+            train = ops._needs_grad(qs, kv, edge_attr, self.lin_edge.weight)
+            out = self._heads_attention(qs[:, :A], kv[:, :A], kv[:, A:], edge_attr, edge_index, shard_info.src_nodes,
+                                        shard_info.dst_nodes, model_comm_group, train) + qs[:, A:]
+        else:
+            out = self._attention(qs[:, :A], kv[:, :A], kv[:, A:], qs[:, A:], edge_attr, csc,
+                                  fused=dict(bufs=(qs, kv), q=(0, 0), s=(0, A), k=(1, 0), v=(1, A)))
         nodes_new_dst = self._post_attention(out, x_dst, cond_dst)
         if self.update_src_nodes:
             ln = self.layer_norm_mlp_src
@@ -339,80 +417,19 @@ class GraphTransformerProcessorBlock(GraphTransformerBaseBlock):
         return self._post_attention(out, x, cond), edge_attr
 
 
-    # -- heads ("Ulysses") strategy: reference block.py:689-759, 838-854 ----------------------------------------------
     def _forward_heads(self, x, xn, edge_attr, edge_index, shard_info, batch_size, group, cond, cache: Optional[dict]):
-        """Nodes sharded for the dense work, HEADS sharded for the attention: q/k/v of the local rows are transposed by one
-        all-to-all each into all rows x (H / P) heads, the attention runs on the whole graph for this rank's heads, and a
-        fourth all-to-all brings the local rows back with all heads.  Unlike the reference the edge term is not moved at
-        all (there: a fourth [M, H*C] transpose per layer): the static edge attributes of the other ranks are gathered
-        once, and the fused-edge kernel applies this rank's rows of ``lin_edge``."""
+        """shard_strategy="heads" (see ``_heads_attention``): the fused q/k/v/self projection runs on the local rows."""
         if batch_size != 1:
             raise ValueError("shard_strategy='heads' requires batch_size=1 when model sharding is enabled.")
-        P, rank = comm_size(group), comm_rank(group)
-        H, C, A = self.num_heads, self.out_channels_conv, self.attn_channels
-        if H % P:
-            raise ValueError(f"shard_strategy='heads': num_heads ({H}) must be divisible by the model-parallel size ({P})")
+        A = self.attn_channels
         train = ops._needs_grad(xn, edge_attr, self.lin_edge.weight)
-        Hl, sizes = H // P, list(shard_info.nodes)
-        n_loc, n_full = xn.shape[0], sum(sizes)
-        # the whole graph (static): edge slices are dst-owned and contiguous, so rank order = global dst-sorted order
-        key = (edge_index.data_ptr(), version(edge_index), P, rank)
-        full = None if cache is None else cache.get("heads_full")
-        if full is None or full[0] != key:
-            if shard_info.edges_are_sharded():
-                ei_full = comm.gather_tensor(edge_index.t().contiguous(), 0, shard_info.edges, group).t().contiguous()
-            else:
-                ei_full = edge_index
-            full = (key, ei_full, (edge_index,))
-            if cache is not None:
-                cache["heads_full"] = full
-        ei_full = full[1]
-        if not shard_info.edges_are_sharded():
-            ea_full = edge_attr
-        elif train:  # every rank works on every edge (for its heads): the owners' gradients are summed over the ranks
-            ea_full = comm.gather_tensor(edge_attr.contiguous(), 0, shard_info.edges, group, reduce_in_backward=True)
-        else:  # static attributes: gathered once
-            akey = (edge_attr.data_ptr(), version(edge_attr), key)
-            hit = None if cache is None else cache.get("heads_attr")
-            if hit is None or hit[0] != akey:
-                hit = (akey, comm.gather_tensor(edge_attr.contiguous(), 0, shard_info.edges, group), edge_attr)
-                if cache is not None:
-                    cache["heads_attr"] = hit
-            ea_full = hit[1]
-        csc = get_csc(ei_full, (n_full, n_full), True)
-
-        def to_heads(t):  # [n_loc, A] all heads -> [n_full, Hl*C] my heads
-            send = t.reshape(n_loc, P, Hl * C).permute(1, 0, 2).reshape(P * n_loc, Hl * C)
-            return comm.all_to_all_rows(send, [n_loc] * P, sizes, group)
-
+        sizes = list(shard_info.nodes)
+        ei_full, ea_full = self._heads_full_graph(edge_attr, edge_index, shard_info.edges if shard_info.edges_are_sharded() else None,
+                                                  group, train, cache)
         w, b = self._fused.get("qkvs", [self.lin_query, self.lin_key, self.lin_value, self.lin_self])
         qkvs = ops.linear(xn, w, b)
-        q, k, v = (to_heads(qkvs[:, i * A:(i + 1) * A]) for i in range(3))
-        x_r = qkvs[:, 3 * A:]
-        if self.qk_norm:  # per-head LayerNorm over C: applied to this rank's heads (block.py:748)
-            q = self.q_norm(q.reshape(-1, Hl, C)).view(-1, Hl * C)
-            k = self.k_norm(k.reshape(-1, Hl, C)).view(-1, Hl * C)
-        if not isinstance(self.edge_pre_mlp, nn.Identity):
-            raise NotImplementedError("edge_pre_mlp with shard_strategy='heads'")
-        rows = slice(rank * Hl * C, (rank + 1) * Hl * C)  # this rank's heads of lin_edge
-        if train:  # materialised E for this rank's heads, attention through the differentiable op (scope row f1 x f2)
-            from ..autograd import attention
-
-            lin = self.lin_edge
-            ea = ea_full if csc.perm is None else ea_full.index_select(0, csc.perm)
-            ea = ea.to(lin.weight.dtype)
-            w_e = lin.weight[rows]
-            pad = (-ea.shape[1]) % 8
-            if pad and ea.dtype != torch.float32:  # 16-bit operand rows must be 16-byte aligned
-                ea, w_e = torch.nn.functional.pad(ea, (0, pad)), torch.nn.functional.pad(w_e, (0, pad))
-            e = ops.linear(ea, w_e, None if lin.bias is None else lin.bias[rows])
-            o = attention(q, k, v, e, csc, Hl, get_reverse_csr(csc))
-        else:
-            feat = get_edge_features(ea_full, csc.perm)
-            o = ops.gt_attention_fused_edge(q, k, v, feat, self._fused.packed_edge(self.lin_edge)[rows], csc, Hl)  # [n_full, Hl*C]
-        back = comm.all_to_all_rows(o, sizes, [n_loc] * P, group)  # [P*n_loc, Hl*C]: block r = heads of rank r
-        out = back.reshape(P, n_loc, Hl * C).permute(1, 0, 2).reshape(n_loc, A) + x_r
-        return self._post_attention(out, x, cond)
+        out = self._heads_attention(qkvs[:, :A], qkvs[:, A:2 * A], qkvs[:, 2 * A:3 * A], ea_full, ei_full, sizes, sizes, group, train)
+        return self._post_attention(out + qkvs[:, 3 * A:], x, cond)
 
 
 class HaloPlan:

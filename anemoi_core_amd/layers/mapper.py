@@ -62,6 +62,7 @@ class BaseMapper(nn.Module):
             raise NotImplementedError("cpu_offload is a training memory feature; not needed with 288 GB of HBM")
         self._local = _LocalGraphCache()
         self._plan = None
+        self._heads_cache = None
 
     def _local_graph(self, x, shard_info, edge_attr, edge_index, group):
         """Rank-local (dst range, edges, compact sources) — index work only, cached for the static graph."""
@@ -121,7 +122,8 @@ class GraphTransformerBaseMapper(BaseMapper):
     def forward(self, x, batch_size: int, shard_info: BipartiteGraphShardInfo, edge_attr: Tensor, edge_index: Tensor,
                 model_comm_group=None, keep_x_dst_sharded: bool = False, edges_are_dst_sorted: bool = True, cond=None, **kwargs):
         if self.shard_strategy == "heads" and model_is_distributed(model_comm_group):
-            raise NotImplementedError("shard_strategy='heads' (Ulysses all-to-all) is scope row f2 (next); use 'edges'")
+            return self._forward_heads(x, batch_size, shard_info, edge_attr, edge_index, model_comm_group, keep_x_dst_sharded,
+                                       edges_are_dst_sorted, cond=cond, **kwargs)
         x_src, x_dst = x
         edge_attr, edge_index = ensure_edges_are_dst_sorted(
             edge_attr, edge_index, edges_are_sharded=shard_info.edges_are_sharded(), model_comm_group=model_comm_group,
@@ -154,6 +156,45 @@ class GraphTransformerBaseMapper(BaseMapper):
         out_dst = self.post_process(x_dst_out)
         if sharded and not keep_x_dst_sharded:
             out_dst = comm.gather_tensor(out_dst, 0, g["partition"].dst_splits, model_comm_group)
+        return out_dst
+
+
+    def _forward_heads(self, x, batch_size, shard_info, edge_attr, edge_index, group, keep_x_dst_sharded, edges_are_dst_sorted,
+                       cond=None, **kwargs):
+        """shard_strategy="heads" (reference mapper.py:388-444): source and destination rows sharded for the embeddings,
+        projections and MLP; the attention runs on the whole bipartite graph for this rank's heads
+        (``GraphTransformerBaseBlock._heads_attention``)."""
+        if self.proc.update_src_nodes:
+            raise NotImplementedError("update_src_nodes with shard_strategy='heads'")
+        x_src, x_dst = x
+        edge_attr, edge_index = ensure_edges_are_dst_sorted(
+            edge_attr, edge_index, edges_are_sharded=shard_info.edges_are_sharded(), model_comm_group=group,
+            edges_are_dst_sorted=edges_are_dst_sorted)
+        src_sizes = shard_info.src_nodes if shard_info.src_is_sharded() else get_shard_sizes(x_src, 0, group)
+        dst_sizes = shard_info.dst_nodes if shard_info.dst_is_sharded() else get_shard_sizes(x_dst, 0, group)
+        if not shard_info.src_is_sharded():
+            x_src = comm.shard_tensor(x_src, 0, src_sizes, group)
+        if not shard_info.dst_is_sharded():
+            x_dst = comm.shard_tensor(x_dst, 0, dst_sizes, group)
+        if cond is not None:
+            c_src, c_dst = cond
+            if not shard_info.src_is_sharded():
+                c_src = comm.shard_tensor(c_src, 0, src_sizes, group)
+            if not shard_info.dst_is_sharded():
+                c_dst = comm.shard_tensor(c_dst, 0, dst_sizes, group)
+            kwargs["cond"] = (c_src, c_dst)
+        train = ops._needs_grad(x_src, x_dst, edge_attr, self.proc.lin_edge.weight)
+        if self._heads_cache is None:
+            self._heads_cache = {}
+        ei_full, ea_full = self.proc._heads_full_graph(edge_attr, edge_index, shard_info.edges if shard_info.edges_are_sharded() else None,
+                                                       group, train, self._heads_cache)
+        xs, xd = self.pre_process((x_src, x_dst))
+        info = BipartiteGraphShardInfo(src_nodes=list(src_sizes), dst_nodes=list(dst_sizes), edges=None)
+        (_, x_dst_out), _ = self.proc((xs, xd), ea_full, ei_full, info, batch_size, (sum(src_sizes), sum(dst_sizes)), group,
+                                      edges_are_dst_sorted=True, **kwargs)
+        out_dst = self.post_process(x_dst_out)
+        if not keep_x_dst_sharded:
+            out_dst = comm.gather_tensor(out_dst, 0, list(dst_sizes), group)
         return out_dst
 
 

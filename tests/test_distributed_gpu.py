@@ -196,3 +196,20 @@ def test_heads_strategy_backward_on_hip_kernels():
     for o in outs:
         for k, g in o["grads"].items():
             assert float((g - ref[k]).abs().max()) <= 3e-4 * float(ref[k].abs().max()) + 1e-6, k
+
+
+def _heads_model_worker(rank, world, group):
+    model, c = _model()
+    for m in model.modules():  # encoder / decoder mappers, the processor and all their blocks
+        if hasattr(m, "shard_strategy"):
+            m.shard_strategy = "heads"
+    with torch.inference_mode():
+        y = model({"data": c["x"].cuda()}, model_comm_group=group)["data"]
+    return dict(out=y.cpu())
+
+
+def test_heads_strategy_full_model_on_hip_kernels():
+    """shard_strategy="heads" in encoder, processor and decoder on the HIP kernels (2 ranks on the one GPU) == the reference."""
+    c = load_golden("model_tiny.pt")["gt"]
+    for o in _spawn(_heads_model_worker, 2):
+        assert float((o["out"] - c["out"]).abs().max()) < 2e-4
