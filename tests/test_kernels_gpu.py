@@ -380,3 +380,21 @@ def test_wgrad_transpose_read_kernel(n, o, i, dtype):
     got2 = ops.linear_wgrad(wide[:, 8:8 + o], x)
     ref2 = wide[:, 8:8 + o].float().t() @ x.float()
     assert float((got2.float() - ref2).abs().max()) <= 6e-3 * float(ref2.abs().max()) + 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_assemble_output_residual_columns(ops, dtype):
+    """out[n, v] = x_out[n, v] + x_skip[n, col_map[v]] where col_map[v] >= 0 (reference _assemble_output: index_add_ of the
+    skip connection onto the prognostic columns, encoder_processor_decoder.py:145-163); x_skip may be a row-strided view."""
+    g = torch.Generator().manual_seed(3)
+    N, V_out, V_in = 1000, 37, 53
+    x_out = torch.randn(N, V_out, generator=g).to(dtype)
+    wide = torch.randn(N, V_in + 5, generator=g).to(dtype)
+    x_skip = wide[:, 2:2 + V_in]
+    col_map = torch.full((V_out,), -1, dtype=torch.int32)
+    picks = torch.randperm(V_out, generator=g)[:20]
+    col_map[picks] = torch.randint(0, V_in, (20,), generator=g, dtype=torch.int32)
+    got = ops.assemble_output(x_out.to(DEV), wide.to(DEV)[:, 2:2 + V_in], col_map.to(DEV))
+    ref = x_out.clone()  # the reference adds in the output dtype: cast(x_out) + skip, rounded once more
+    ref[:, picks] = (x_out[:, picks].float() + x_skip[:, col_map[picks].long()].float()).to(dtype)
+    assert got.dtype == dtype and torch.equal(got.cpu(), ref)
