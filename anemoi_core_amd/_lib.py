@@ -9,7 +9,7 @@ import ctypes as C
 import os
 import threading
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libanemoi_hip.so")
 
 F32, BF16, F16 = 0, 1, 2
@@ -37,6 +37,10 @@ SIGNATURES = {
     "anemoi_assemble_output": ([_p, _i64, _p, _i64, _p, _p, _i64, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_bound_columns": ([_p, _i64, _i32, _i32, _p, _p, _i32, C.c_int, _p], C.c_int),
     "anemoi_layernorm_fwd": ([_p, _i64, _p, _p, _p, _i64, _p, _i64, _i32, _i32, _f, C.c_int, _p], C.c_int),
+    "anemoi_gt_attention_fused_edge_bwd_partial_floats": ([_i32, _i32, _i32], _i64),
+    "anemoi_gt_attention_fused_edge_bwd": ([_p, _i64, _p, _i64, _p, _i64, _p, _i32, _p, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p,
+                                            _p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32,
+                                            C.c_int, _p], C.c_int),
     "anemoi_linear_wgrad_workspace_bytes": ([_i32, _i32, _i32], _i64),
     "anemoi_linear_wgrad": ([_p, _i64, _p, _i64, _p, _i64, _p, _p, _i32, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_linear_splitk_f32": ([_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, _i32, C.c_int, _p], C.c_int),

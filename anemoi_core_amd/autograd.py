@@ -231,3 +231,61 @@ class FusedAttentionFunction(torch.autograd.Function):
 
 def fused_attention(spec: dict, bufs, e: Tensor, csc: "ops.CSC", num_heads: int, reverse) -> Tensor:
     return FusedAttentionFunction.apply(spec, csc, num_heads, reverse, e, *bufs)
+
+
+class PackEdgeFeaturesFunction(torch.autograd.Function):
+    """[M, Fe] edge attributes -> fp32 [M, fe_pad] = [attributes | 1 | 0] (the operand of the fused-edge attention); shared by
+    the layers of a processor, so the attribute gradient is accumulated in this layout and sliced once."""
+
+    @staticmethod
+    def forward(ctx, edge_attr: Tensor):
+        ctx.fe, ctx.dtype = edge_attr.shape[1], edge_attr.dtype
+        return ops.pack_edge_features(edge_attr)
+
+    @staticmethod
+    def backward(ctx, d_feat: Tensor):
+        return d_feat[:, :ctx.fe].to(ctx.dtype)
+
+
+class FusedEdgeAttentionFunction(torch.autograd.Function):
+    """out = attention(q, k, v, E = lin_edge(edge attributes)) + self_term with lin_edge FUSED in forward and backward (E and dE
+    are never materialised) and q / k / v / self_term given as column slabs of the fused projection buffers (see
+    ``FusedAttentionFunction``).  Inputs: packed edge features (``PackEdgeFeaturesFunction``), lin_edge weight and bias."""
+
+    @staticmethod
+    def forward(ctx, spec, csc, num_heads, reverse, feat, weight, bias, *bufs):
+        A = spec["A"]
+        slab = lambda key: bufs[spec[key][0]][:, spec[key][1]: spec[key][1] + A]  # noqa: E731
+        wp = ops.pack_edge_weights(weight.contiguous(), bias)
+        out, lse = ops.gt_attention_fused_edge(slab("q"), slab("k"), slab("v"), feat, wp, csc, num_heads, return_lse=True)
+        ctx.spec, ctx.csc, ctx.H, ctx.reverse = spec, csc, num_heads, reverse
+        ctx.fe, ctx.wdt, ctx.bdt = weight.shape[1], weight.dtype, None if bias is None else bias.dtype
+        ctx.save_for_backward(feat, wp, out, lse, *bufs)
+        return out + slab("s")
+
+    @staticmethod
+    def backward(ctx, d_y):
+        feat, wp, out, lse, *bufs = ctx.saved_tensors
+        spec, A = ctx.spec, ctx.spec["A"]
+        d_y = d_y.contiguous()
+        covered = [0] * len(bufs)
+        for key in ("q", "k", "v", "s"):
+            covered[spec[key][0]] += A
+        grads = [torch.empty_like(b, memory_format=torch.contiguous_format) if covered[i] == b.shape[1] else torch.zeros_like(b)
+                 for i, b in enumerate(bufs)]
+        slab = lambda ts, key: ts[spec[key][0]][:, spec[key][1]: spec[key][1] + A]  # noqa: E731
+        _, _, _, d_wp, d_feat = ops.gt_attention_fused_edge_backward(
+            d_y, slab(bufs, "q"), slab(bufs, "k"), slab(bufs, "v"), feat, wp, out, lse, ctx.csc, ctx.reverse, ctx.H,
+            grads_out=(slab(grads, "q"), slab(grads, "k"), slab(grads, "v")), need_feat_grad=ctx.needs_input_grad[4])
+        slab(grads, "s").copy_(d_y)
+        d_w = d_wp[:, :ctx.fe].to(ctx.wdt) if ctx.needs_input_grad[5] else None
+        d_b = d_wp[:, ctx.fe].to(ctx.bdt) if ctx.bdt is not None and ctx.needs_input_grad[6] else None
+        return (None, None, None, None, d_feat, d_w, d_b, *grads)
+
+
+def pack_edge_features(edge_attr: Tensor) -> Tensor:
+    return PackEdgeFeaturesFunction.apply(edge_attr)
+
+
+def fused_edge_attention(spec: dict, bufs, feat: Tensor, lin_edge, csc: "ops.CSC", num_heads: int, reverse) -> Tensor:
+    return FusedEdgeAttentionFunction.apply(spec, csc, num_heads, reverse, feat, lin_edge.weight, lin_edge.bias, *bufs)

@@ -273,6 +273,296 @@ int launch(const BwdArgs& a) {
   return ANEMOI_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------- fused lin_edge backward
+// Backward of the op with lin_edge fused (E_e = W' f_e, W' = [W_e | b_e | 0] fp32 [D, FE_PAD], f_e = [edge_attr_e | 1 | 0]):
+// E is never materialised here either.  With qw_h = W'_h^T q_d, gw_h = W'_h^T dO_d (per head h, FE_PAD values):
+//   <q_d, E_e>_h = <f_e, qw_h>          <dO_d, E_e>_h = <f_e, gw_h>
+//   dq_d   = sum_e dS_e k_s / sqrt(C) + W' (sum_e dS_e f_e / sqrt(C))            [per head sums sfS_h]
+//   dW'    = sum_d dO_d (x) sfP_{d,h(c)} + q_d (x) sfS_{d,h(c)},   sfP_h = sum_e p_e f_e
+//   df_e   = sum_h p_{e,h} gw_{d,h} + dS_{e,h} qw_{d,h} / sqrt(C)
+// Destination pass: dq, the per-edge scalars for the source pass (unchanged), and the per-(destination, head) vectors
+// sfP, sfS (and qw, gw when the edge attributes are trained) into fp32 workspaces; dW' and df are two small streaming kernels.
+template <int VEC, int FE_PAD>
+struct WLayoutB {
+  static constexpr int kChunk = VEC * FE_PAD + 4;
+  static constexpr int kFloats = 64 * kChunk;
+};
+
+template <typename T, int VEC, int LPH, int FE_PAD>
+__global__ __launch_bounds__(64 * kBwdWaves) void gt_attn_bwd_dst_fused_kernel(
+    const T* __restrict__ q, int64_t ldq, const T* __restrict__ k, int64_t ldk, const T* __restrict__ v, int64_t ldv,
+    const float* __restrict__ feat, const float* __restrict__ w_packed, const T* __restrict__ out, int64_t ldo,
+    const float* __restrict__ lse, const T* __restrict__ d_out, int64_t lddo, const int32_t* __restrict__ row,
+    const int32_t* __restrict__ colptr, T* __restrict__ dq, int64_t lddq, float* __restrict__ p_ws, float* __restrict__ ds_ws,
+    float* __restrict__ sf_ws, float* __restrict__ qg_ws, int n_dst, int H, float scale) {
+  using L = WLayoutB<VEC, FE_PAD>;
+  extern __shared__ __attribute__((aligned(16))) float w_lds[];  // [64][kChunk], chunk layout [feature][channel]
+  const int lane = threadIdx.x & 63;
+  const int c0 = lane * VEC;
+  const int h = lane / LPH;
+  for (int idx = threadIdx.x; idx < 64 * VEC * FE_PAD; idx += 64 * kBwdWaves) {
+    const int c = idx / FE_PAD, f = idx % FE_PAD;
+    w_lds[(c / VEC) * L::kChunk + f * VEC + (c % VEC)] = w_packed[idx];
+  }
+  __syncthreads();
+  const float* wl = w_lds + lane * L::kChunk;
+  const int wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * kBwdWaves + (threadIdx.x >> 6));
+  const int nwaves = gridDim.x * kBwdWaves;
+  for (int d = wave0; d < n_dst; d += nwaves) {
+    asm volatile("" ::: "memory");  // keep W' in LDS (see the forward kernel)
+    const int beg = __builtin_amdgcn_readfirstlane(colptr[d]);
+    const int end = __builtin_amdgcn_readfirstlane(colptr[d + 1]);
+    float qv[VEC], gv[VEC], ov[VEC], acc[VEC];
+    load_vec<T, VEC>(q + (int64_t)d * ldq + c0, qv);
+    load_vec<T, VEC>(d_out + (int64_t)d * lddo + c0, gv);
+    load_vec<T, VEC>(out + (int64_t)d * ldo + c0, ov);
+    float dd = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      dd = fmaf(gv[i], ov[i], dd);
+      acc[i] = 0.f;
+    }
+    const float Dj = group_sum<LPH>(dd);
+    float qw[FE_PAD], gw[FE_PAD], sfP[FE_PAD], sfS[FE_PAD];
+#pragma unroll
+    for (int f = 0; f < FE_PAD; ++f) {
+      float tq = 0.f, tg = 0.f;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        tq = fmaf(qv[j], wl[f * VEC + j], tq);
+        tg = fmaf(gv[j], wl[f * VEC + j], tg);
+      }
+      qw[f] = group_sum<LPH>(tq);
+      gw[f] = group_sum<LPH>(tg);
+      sfP[f] = sfS[f] = 0.f;
+    }
+    const float m = lse[(int64_t)d * H + h];
+    for (int ei = beg; ei < end; ++ei) {
+      const int s = __builtin_amdgcn_readfirstlane(row[ei]);
+      float kv[VEC], vv[VEC];
+      load_vec<T, VEC>(k + (int64_t)s * ldk + c0, kv);
+      load_vec<T, VEC>(v + (int64_t)s * ldv + c0, vv);
+      const float* fe = feat + (int64_t)ei * FE_PAD;  // wave-uniform address: scalar loads
+      float ff[FE_PAD];
+#pragma unroll
+      for (int f = 0; f < FE_PAD; ++f) ff[f] = fe[f];
+      float dot = 0.f, da = 0.f;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        dot = fmaf(qv[i], kv[i], dot);
+        da = fmaf(gv[i], vv[i], da);
+      }
+      dot = group_sum<LPH>(dot);
+      da = group_sum<LPH>(da);
+#pragma unroll
+      for (int f = 0; f < FE_PAD; ++f) {
+        dot = fmaf(ff[f], qw[f], dot);
+        da = fmaf(ff[f], gw[f], da);
+      }
+      const float p = __expf(dot * scale - m);
+      const float ds = p * (da - Dj) * scale;  // dS_e / sqrt(C)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] = fmaf(ds, kv[i], acc[i]);
+#pragma unroll
+      for (int f = 0; f < FE_PAD; ++f) {
+        sfP[f] = fmaf(p, ff[f], sfP[f]);
+        sfS[f] = fmaf(ds, ff[f], sfS[f]);
+      }
+      if ((lane % LPH) == 0) {
+        p_ws[(int64_t)ei * H + h] = p;
+        ds_ws[(int64_t)ei * H + h] = ds;
+      }
+    }
+#pragma unroll
+    for (int f = 0; f < FE_PAD; ++f)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] = fmaf(wl[f * VEC + j], sfS[f], acc[j]);
+    store_vec<T, VEC>(dq + (int64_t)d * lddq + c0, acc);
+    if ((lane % LPH) == 0) {  // every (destination, head) slot is written, also with no in-edges (zeros)
+      float* sp = sf_ws + ((int64_t)d * H + h) * 2 * FE_PAD;
+#pragma unroll
+      for (int f = 0; f < FE_PAD; ++f) {
+        sp[f] = sfP[f];
+        sp[FE_PAD + f] = sfS[f];
+      }
+      if (qg_ws != nullptr) {
+        float* gp = qg_ws + ((int64_t)d * H + h) * 2 * FE_PAD;
+#pragma unroll
+        for (int f = 0; f < FE_PAD; ++f) {
+          gp[f] = qw[f];  // the 1/sqrt(C) is already inside dS
+          gp[FE_PAD + f] = gw[f];
+        }
+      }
+    }
+  }
+}
+
+// dW'[c][f] partial sums: persistent waves over the destinations, fixed-order in-block sum, one fp32 row per block.
+constexpr int kWgradBlocks = 256;
+template <typename T, int VEC, int LPH, int FE_PAD>
+__global__ __launch_bounds__(64 * kBwdWaves) void edge_weight_grad_kernel(const T* __restrict__ q, int64_t ldq, const T* __restrict__ d_out,
+                                                                          int64_t lddo, const float* __restrict__ sf_ws,
+                                                                          float* __restrict__ part, int n_dst, int H) {
+  extern __shared__ float block_sum[];  // [64 * VEC][FE_PAD]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = lane * VEC, h = lane / LPH;
+  float dw[FE_PAD][VEC];
+#pragma unroll
+  for (int f = 0; f < FE_PAD; ++f)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) dw[f][j] = 0.f;
+  for (int d = blockIdx.x * kBwdWaves + wave; d < n_dst; d += gridDim.x * kBwdWaves) {
+    float qv[VEC], gv[VEC];
+    load_vec<T, VEC>(q + (int64_t)d * ldq + c0, qv);
+    load_vec<T, VEC>(d_out + (int64_t)d * lddo + c0, gv);
+    const float* sp = sf_ws + ((int64_t)d * H + h) * 2 * FE_PAD;
+#pragma unroll
+    for (int f = 0; f < FE_PAD; ++f) {
+      const float a = sp[f], b = sp[FE_PAD + f];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) dw[f][j] = fmaf(gv[j], a, fmaf(qv[j], b, dw[f][j]));
+    }
+  }
+  for (int kq = 0; kq < kBwdWaves; ++kq) {  // fixed order
+    if (wave == kq) {
+#pragma unroll
+      for (int f = 0; f < FE_PAD; ++f)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          float* dst = block_sum + (c0 + j) * FE_PAD + f;
+          *dst = kq == 0 ? dw[f][j] : *dst + dw[f][j];
+        }
+    }
+    __syncthreads();
+  }
+  float* prow = part + (int64_t)blockIdx.x * 64 * VEC * FE_PAD;
+  for (int i = threadIdx.x; i < 64 * VEC * FE_PAD; i += 64 * kBwdWaves) prow[i] = block_sum[i];
+}
+
+__global__ void sum_partial_rows_kernel(const float* __restrict__ part, int n_part, int n, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = 0;
+  for (; b + 3 < n_part; b += 4) {
+    s0 += part[(int64_t)b * n + i];
+    s1 += part[(int64_t)(b + 1) * n + i];
+    s2 += part[(int64_t)(b + 2) * n + i];
+    s3 += part[(int64_t)(b + 3) * n + i];
+  }
+  for (; b < n_part; ++b) s0 += part[(int64_t)b * n + i];
+  out[i] = (s0 + s1) + (s2 + s3);
+}
+
+// df[e][f] = sum_h p[e,h] gw[d,h,f] + ds[e,h] qw[d,h,f]: 16 lanes per edge (lane = feature), edges sorted by destination.
+__global__ void edge_feat_grad_kernel(const float* __restrict__ p_ws, const float* __restrict__ ds_ws, const float* __restrict__ qg_ws,
+                                      const int32_t* __restrict__ edge_dst, float* __restrict__ d_feat, int n_edges, int H, int fe_pad) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t e = t >> 4;
+  const int f = (int)(t & 15);
+  if (e >= n_edges || f >= fe_pad) return;
+  const int d = edge_dst[e];
+  float s = 0.f;
+  for (int hh = 0; hh < H; ++hh) {
+    const float* gp = qg_ws + ((int64_t)d * H + hh) * 2 * fe_pad;
+    s = fmaf(p_ws[e * H + hh], gp[fe_pad + f], fmaf(ds_ws[e * H + hh], gp[f], s));
+  }
+  d_feat[e * fe_pad + f] = s;
+}
+
+struct FusedBwdArgs {
+  BwdArgs b;
+  const float *feat, *w_packed;
+  int fe_pad;
+  float *d_w_packed, *d_feat, *sf_ws, *qg_ws, *part_ws;
+  int n_edges;
+};
+
+template <typename T, int VEC, int LPH, int FE_PAD>
+int launch_fused_cfg(const FusedBwdArgs& f, float scale) {
+  using L = WLayoutB<VEC, FE_PAD>;
+  const BwdArgs& a = f.b;
+  const dim3 block(64 * kBwdWaves);
+  if (L::kFloats * sizeof(float) > 64 * 1024) return 1;
+  if (a.n_dst > 0) {
+    int blocks = (a.n_dst + kBwdWaves - 1) / kBwdWaves;
+    blocks = blocks < 256 * 6 ? blocks : 256 * 6;
+    hipLaunchKernelGGL((gt_attn_bwd_dst_fused_kernel<T, VEC, LPH, FE_PAD>), dim3(blocks), block, L::kFloats * sizeof(float), a.stream,
+                       (const T*)a.q, a.ldq, (const T*)a.k, a.ldk, (const T*)a.v, a.ldv, f.feat, f.w_packed, (const T*)a.out, a.ldo,
+                       a.lse, (const T*)a.d_out, a.lddo, a.row, a.colptr, (T*)a.dq, a.lddq, a.p_ws, a.ds_ws, f.sf_ws, f.qg_ws, a.n_dst,
+                       a.H, scale);
+    int rc = check_launch("gt_attn_bwd_dst_fused_kernel");
+    if (rc != ANEMOI_OK) return rc;
+  }
+  const int nw = 64 * VEC * FE_PAD;
+  int wb = (a.n_dst + kBwdWaves - 1) / kBwdWaves;
+  wb = wb < kWgradBlocks ? wb : kWgradBlocks;
+  if (wb > 0) {
+    hipLaunchKernelGGL((edge_weight_grad_kernel<T, VEC, LPH, FE_PAD>), dim3(wb), block, nw * sizeof(float), a.stream, (const T*)a.q, a.ldq,
+                       (const T*)a.d_out, a.lddo, f.sf_ws, f.part_ws, a.n_dst, a.H);
+    int rc = check_launch("edge_weight_grad_kernel");
+    if (rc != ANEMOI_OK) return rc;
+  }
+  hipLaunchKernelGGL(sum_partial_rows_kernel, dim3((nw + 255) / 256), dim3(256), 0, a.stream, f.part_ws, wb, nw, f.d_w_packed);
+  int rc = check_launch("sum_partial_rows_kernel");
+  if (rc != ANEMOI_OK) return rc;
+  if (f.d_feat != nullptr && f.n_edges > 0) {
+    const int64_t threads = (int64_t)f.n_edges * 16;
+    hipLaunchKernelGGL(edge_feat_grad_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, a.stream, a.p_ws, a.ds_ws, f.qg_ws,
+                       a.edge_dst, f.d_feat, f.n_edges, a.H, f.fe_pad);
+    rc = check_launch("edge_feat_grad_kernel");
+    if (rc != ANEMOI_OK) return rc;
+  }
+  if (a.n_src > 0) {
+    hipLaunchKernelGGL((gt_attn_bwd_src_kernel<T, VEC, LPH>), dim3((a.n_src + kBwdWaves - 1) / kBwdWaves), block, 0, a.stream,
+                       (const T*)a.q, a.ldq, (const T*)a.d_out, a.lddo, a.rowptr, a.edge_ids, a.edge_dst, a.p_ws, a.ds_ws,
+                       (T*)a.dk, a.lddk, (T*)a.dv, a.lddv, a.n_src, a.H);
+    return check_launch("gt_attn_bwd_src_kernel");
+  }
+  return ANEMOI_OK;
+}
+
+template <typename T, int VEC, int LPH>
+int launch_fused_fe(const FusedBwdArgs& f, float scale) {
+  switch (f.fe_pad) {
+    case 4: return launch_fused_cfg<T, VEC, LPH, 4>(f, scale);
+    case 8: return launch_fused_cfg<T, VEC, LPH, 8>(f, scale);
+    case 12: return launch_fused_cfg<T, VEC, LPH, 12>(f, scale);
+    case 16: return launch_fused_cfg<T, VEC, LPH, 16>(f, scale);
+    default: return 1;
+  }
+}
+
+// The fused backward covers the shapes the production configs use (H*C = 64 * VEC with VEC = 8 for 16-bit / 4 or 8 for fp32
+// models of 256 / 512 channels, and the 64-channel test models); anything else reports ANEMOI_E_UNSUPPORTED and the caller
+// trains through the materialised-E op.
+template <typename T>
+int launch_fused(const FusedBwdArgs& f) {
+  const BwdArgs& a = f.b;
+  const int D = a.H * a.C;
+  const float scale = 1.0f / sqrtf((float)a.C);
+  const int64_t vb = 16 / (int64_t)sizeof(T);
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const bool aligned = a.ldq % vb == 0 && a.ldk % vb == 0 && a.ldv % vb == 0 && a.ldo % vb == 0 && a.lddo % vb == 0 && a.lddq % vb == 0 &&
+                       a.lddk % vb == 0 && a.lddv % vb == 0 && al16(a.q) && al16(a.k) && al16(a.v) && al16(a.out) && al16(a.d_out) &&
+                       al16(a.dq) && al16(a.dk) && al16(a.dv);
+  int rc = 1;
+  if (D % 64 == 0 && aligned) {
+    const int vec = D / 64, lph = a.C % vec == 0 ? a.C / vec : 0;
+    if (vec == 8 && lph == 4) rc = launch_fused_fe<T, 8, 4>(f, scale);        // 512 channels, C = 32
+    else if (vec == 8 && lph == 8) rc = launch_fused_fe<T, 8, 8>(f, scale);   // 512 channels, C = 64
+    else if (vec == 4 && lph == 8) rc = launch_fused_fe<T, 4, 8>(f, scale);   // 256 channels, C = 32
+    else if (vec == 1 && lph == 16) rc = launch_fused_fe<T, 1, 16>(f, scale); // 64 channels, C = 16 (test models)
+    else if (vec == 1 && lph == 8) rc = launch_fused_fe<T, 1, 8>(f, scale);   // 64 channels, C = 8
+  }
+  if (rc > 0) {
+    set_error("gt_attention_fused_edge_bwd: shape H=%d C=%d fe_pad=%d is not covered by the fused backward", a.H, a.C, f.fe_pad);
+    return ANEMOI_E_UNSUPPORTED;
+  }
+  return rc;
+}
+
 }  // namespace
 }  // namespace anemoi
 
@@ -301,6 +591,38 @@ extern "C" int anemoi_gt_attention_bwd(const void* q, int64_t ldq, const void* k
     case ANEMOI_F32: return launch<float>(a);
     case ANEMOI_BF16: return launch<bf16_t>(a);
     case ANEMOI_F16: return launch<f16_t>(a);
+    default: set_error("unknown dtype %d", (int)dtype); return ANEMOI_E_INVALID;
+  }
+}
+
+extern "C" int64_t anemoi_gt_attention_fused_edge_bwd_partial_floats(int32_t H, int32_t C, int32_t fe_pad) {
+  return (int64_t)kWgradBlocks * H * C * fe_pad;
+}
+
+extern "C" int anemoi_gt_attention_fused_edge_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                                                  const float* edge_feat, int32_t fe_pad, const float* w_packed, const void* out,
+                                                  int64_t ldo, const float* lse, const void* d_out, int64_t lddo, const int32_t* row,
+                                                  const int32_t* colptr, const int32_t* rowptr, const int32_t* edge_ids,
+                                                  const int32_t* edge_dst, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv,
+                                                  int64_t lddv, float* d_w_packed, float* d_edge_feat, float* p_ws, float* ds_ws,
+                                                  float* sf_ws, float* qg_ws, float* part_ws, int32_t n_dst, int32_t n_src,
+                                                  int32_t n_edges, int32_t H, int32_t C, anemoi_dtype_t dtype, void* stream) {
+  ANEMOI_REQUIRE(n_dst > 0 && n_src > 0 && n_edges >= 0 && H > 0 && C > 0 && fe_pad > 0 && fe_pad % 4 == 0,
+                 "gt_attention_fused_edge_bwd: bad sizes n_dst=%d n_src=%d M=%d H=%d C=%d fe_pad=%d", n_dst, n_src, n_edges, H, C, fe_pad);
+  ANEMOI_REQUIRE(q && k && v && out && lse && d_out && colptr && rowptr && dq && dk && dv && w_packed && d_w_packed && sf_ws && part_ws,
+                 "gt_attention_fused_edge_bwd: null pointer");
+  ANEMOI_REQUIRE(n_edges == 0 || (edge_feat && row && edge_ids && edge_dst && p_ws && ds_ws), "gt_attention_fused_edge_bwd: null edge data");
+  ANEMOI_REQUIRE(d_edge_feat == nullptr || qg_ws != nullptr, "gt_attention_fused_edge_bwd: d_edge_feat needs the qg workspace");
+  const int64_t D = (int64_t)H * C;
+  ANEMOI_REQUIRE(ldq >= D && ldk >= D && ldv >= D && ldo >= D && lddo >= D && lddq >= D && lddk >= D && lddv >= D,
+                 "gt_attention_fused_edge_bwd: leading dimension smaller than H*C=%lld", (long long)D);
+  FusedBwdArgs f{{q, k, v, nullptr, out, d_out, ldq, ldk, ldv, 0, ldo, lddo, lse, row, colptr, rowptr, edge_ids, edge_dst,
+                  dq, dk, dv, nullptr, lddq, lddk, lddv, 0, p_ws, ds_ws, n_dst, n_src, H, C, as_stream(stream)},
+                 edge_feat, w_packed, fe_pad, d_w_packed, d_edge_feat, sf_ws, d_edge_feat ? qg_ws : nullptr, part_ws, n_edges};
+  switch (dtype) {
+    case ANEMOI_F32: return launch_fused<float>(f);
+    case ANEMOI_BF16: return launch_fused<bf16_t>(f);
+    case ANEMOI_F16: return launch_fused<f16_t>(f);
     default: set_error("unknown dtype %d", (int)dtype); return ANEMOI_E_INVALID;
   }
 }

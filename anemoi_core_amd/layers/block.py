@@ -31,6 +31,7 @@ ANEMOI_DEBUG_SHARDING = os.environ.get("ANEMOI_DEBUG_SHARDING", "") != ""
 # LayerNorm folded into the neighbouring GEMMs (anemoi_linear_stats_fwd / anemoi_linear_lnfold_fwd).  Opt-in: it removes 32 of
 # the 39 LayerNorm launches of the O96 forward but makes the consuming GEMMs' epilogues heavier (the 160-accumulator big-tile
 # kernel has no registers to spare): -1.4 % forward time in a same-box A/B, nothing on another box.
+_FUSED_EDGE_BWD = os.environ.get("ANEMOI_FUSED_EDGE_BWD", "1") == "1"  # 0: train through the materialised-E op (reference op boundary)
 _LN_FOLD = os.environ.get("ANEMOI_LN_FOLD", "0") == "1"
 
 
@@ -147,9 +148,23 @@ class GraphTransformerBaseBlock(BaseBlock):
         if ops._needs_grad(query, key, value, x_r, edge_attr, self.lin_edge.weight):
             # training (scope row f1): E = lin_edge(edge_pre_mlp(edge_attr)) is materialised, as in the reference
             # (block.py:623-635), and the attention runs through the op mirror, whose backward is registered
+            from .. import autograd as ag
             from ..autograd import attention, fused_attention
 
             wdt = self.lin_edge.weight.dtype
+            if (fused is not None and not self.qk_norm and isinstance(self.edge_pre_mlp, nn.Identity) and _FUSED_EDGE_BWD
+                    and ops.fused_edge_backward_supported(query.shape[1], H, edge_attr.shape[1])):
+                # lin_edge fused into the attention in forward AND backward: E / dE never exist; the packed features are shared
+                # by the layers of a processor
+                fkey = (id(edge_attr), id(csc.perm), "feat")
+                feat = None if edge_prep is None else edge_prep.get(fkey)
+                if feat is None:
+                    feat = ag.pack_edge_features(edge_attr if csc.perm is None else edge_attr.index_select(0, csc.perm))
+                    if edge_prep is not None:
+                        edge_prep[fkey] = feat
+                        edge_prep.setdefault("anchors", []).append((edge_attr, csc.perm))
+                spec = {"A": query.shape[1], **{kk: fused[kk] for kk in ("q", "k", "v", "s")}}
+                return ag.fused_edge_attention(spec, fused["bufs"], feat, self.lin_edge, csc, H, get_reverse_csr(csc))
             pkey = (id(edge_attr), id(csc.perm), wdt)
             ea = None if edge_prep is None else edge_prep.get(pkey)
             if ea is None:

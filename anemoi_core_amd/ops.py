@@ -193,6 +193,57 @@ def gt_attention_backward(d_out: Tensor, q: Tensor, k: Tensor, v: Tensor, e: Ten
     return dq, dk, dv, de
 
 
+def fused_edge_backward_supported(D: int, num_heads: int, fe: int) -> bool:
+    """Shapes the fused-edge backward kernels are instantiated for (csrc/gt_attention_bwd.hip: launch_fused)."""
+    if D % 64 or D % num_heads:
+        return False
+    vec, C = D // 64, D // num_heads
+    lph = C // vec if vec and C % vec == 0 else 0
+    return (vec, lph) in ((8, 4), (8, 8), (4, 8), (1, 16), (1, 8)) and edge_feature_pad(fe) <= 16
+
+
+def gt_attention_fused_edge_backward(d_out: Tensor, q: Tensor, k: Tensor, v: Tensor, edge_feat: Tensor, w_packed: Tensor, out: Tensor,
+                                     lse: Tensor, csc: CSC, reverse: tuple[Tensor, Tensor, Tensor], num_heads: int, grads_out=None,
+                                     need_feat_grad: bool = False):
+    """Gradients of ``gt_attention_fused_edge`` (no addend): (dq, dk, dv, d_w_packed fp32 [D, fe_pad], d_edge_feat fp32
+    [M, fe_pad] or None).  E and dE are never materialised.  ``out`` / ``lse``: the forward's results."""
+    rowptr, edge_ids, edge_dst = reverse
+    _dev(d_out, q, k, v, edge_feat, w_packed, out, lse, csc.row, rowptr, edge_ids, edge_dst)
+    D = q.shape[1]
+    M, fe_pad = csc.num_edges, w_packed.shape[1]
+    if edge_feat.dtype != torch.float32 or tuple(edge_feat.shape) != (M, fe_pad) or not edge_feat.is_contiguous():
+        raise ValueError(f"edge_feat must be contiguous fp32 [{M}, {fe_pad}]")
+    if w_packed.dtype != torch.float32 or tuple(w_packed.shape) != (D, fe_pad) or not w_packed.is_contiguous():
+        raise ValueError(f"w_packed must be contiguous fp32 [{D}, {fe_pad}]")
+    if d_out.shape != q.shape or out.shape != q.shape or tuple(lse.shape) != (csc.n_dst, num_heads) or lse.dtype != torch.float32:
+        raise ValueError("d_out/out must have q's shape and lse must be fp32 [n_dst, H]")
+    dev = q.device
+    if grads_out is None:
+        dq = torch.empty_like(q, memory_format=torch.contiguous_format)
+        dk, dv = torch.empty((csc.n_src, D), dtype=q.dtype, device=dev), torch.empty((csc.n_src, D), dtype=q.dtype, device=dev)
+    else:
+        dq, dk, dv = grads_out
+    f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)  # noqa: E731
+    lib = _lib.load()
+    d_wp = f32(D, fe_pad)
+    d_feat = f32(M, fe_pad) if need_feat_grad else None
+    ws, sf = f32(2, max(M, 1), num_heads), f32(csc.n_dst, num_heads, 2, fe_pad)
+    qg = f32(csc.n_dst, num_heads, 2, fe_pad) if need_feat_grad else None
+    part = f32(int(lib.anemoi_gt_attention_fused_edge_bwd_partial_floats(num_heads, D // num_heads, fe_pad)))
+    (qp, ldq), (kp, ldk), (vp, ldv) = _rows(q, "q"), _rows(k, "k", q.dtype), _rows(v, "v", q.dtype)
+    (op, ldo), (gp, ldg) = _rows(out, "out", q.dtype), _rows(d_out, "d_out", q.dtype)
+    (dqp, lddq), (dkp, lddk), (dvp, lddv) = _rows(dq, "dq", q.dtype), _rows(dk, "dk", q.dtype), _rows(dv, "dv", q.dtype)
+    i32 = lambda t: t if t.dtype == torch.int32 and t.is_contiguous() else t.to(torch.int32).contiguous()  # noqa: E731
+    rowptr, edge_ids, edge_dst = i32(rowptr), i32(edge_ids), i32(edge_dst)
+    rc = lib.anemoi_gt_attention_fused_edge_bwd(
+        qp, ldq, kp, ldk, vp, ldv, edge_feat.data_ptr(), fe_pad, w_packed.data_ptr(), op, ldo, lse.contiguous().data_ptr(), gp, ldg,
+        csc.row.data_ptr(), csc.colptr.data_ptr(), rowptr.data_ptr(), edge_ids.data_ptr(), edge_dst.data_ptr(), dqp, lddq, dkp, lddk,
+        dvp, lddv, d_wp.data_ptr(), 0 if d_feat is None else d_feat.data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(), sf.data_ptr(),
+        0 if qg is None else qg.data_ptr(), part.data_ptr(), csc.n_dst, csc.n_src, M, num_heads, D // num_heads, _dt(q), _stream())
+    _lib.check(rc, "gt_attention_fused_edge_bwd")
+    return dq, dk, dv, d_wp, d_feat
+
+
 def edge_feature_pad(fe: int) -> int:
     return 4 * ((fe + 1 + 3) // 4)
 

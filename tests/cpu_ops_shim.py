@@ -106,6 +106,20 @@ def fused_attention_train(spec, bufs, e, csc, num_heads, reverse):
     return gt_attention(slab("q"), slab("k"), slab("v"), e, csc, num_heads) + slab("s")
 
 
+def pack_edge_features_train(edge_attr):
+    """Stand-in for anemoi_core_amd.autograd.pack_edge_features: [attributes | 1 | 0] in plain torch."""
+    M, fe = edge_attr.shape
+    pad = 4 * ((fe + 1 + 3) // 4) - fe - 1
+    return torch.cat([edge_attr.float(), torch.ones(M, 1), torch.zeros(M, pad)], 1)
+
+
+def fused_edge_attention_train(spec, bufs, feat, lin_edge, csc, num_heads, reverse):
+    """Stand-in for anemoi_core_amd.autograd.fused_edge_attention."""
+    fe = lin_edge.weight.shape[1]
+    e = torch.nn.functional.linear(feat[:, :fe].to(lin_edge.weight.dtype), lin_edge.weight, lin_edge.bias)
+    return fused_attention_train(spec, bufs, e, csc, num_heads, reverse)
+
+
 def install(monkeypatch=None):
     """Patch anemoi_core_amd.ops in the current process (plain setattr when no pytest monkeypatch is given)."""
     names = ["gt_attention", "pack_edge_features", "pack_edge_weights", "gt_attention_fused_edge", "layer_norm", "linear",
@@ -115,7 +129,11 @@ def install(monkeypatch=None):
     if monkeypatch is not None:
         monkeypatch.setattr(_ag, "attention", attention_train)
         monkeypatch.setattr(_ag, "fused_attention", fused_attention_train)
+        monkeypatch.setattr(_ag, "pack_edge_features", pack_edge_features_train)
+        monkeypatch.setattr(_ag, "fused_edge_attention", fused_edge_attention_train)
     else:
+        _ag.pack_edge_features = pack_edge_features_train
+        _ag.fused_edge_attention = fused_edge_attention_train
         _ag.attention = attention_train
         _ag.fused_attention = fused_attention_train
     for n in names:

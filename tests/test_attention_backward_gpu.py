@@ -123,3 +123,43 @@ def test_backward_fullsize_properties(ops):
     lhs = (dk.float() + dv.float()).sum(0)
     rhs = de.float().sum(0)
     assert float((lhs - rhs).abs().max()) <= 2e-2 * float(rhs.abs().max()) + 0.5  # bf16 rounding of 8e4 / 1e4 summands
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("H,C,fe", [(16, 32, 11), (4, 16, 11), (8, 64, 3), (8, 32, 7), (8, 8, 15)])
+def test_fused_edge_backward_vs_oracle_autograd(ops, dtype, H, C, fe):
+    """anemoi_gt_attention_fused_edge_bwd (lin_edge fused, E / dE never materialised): dq, dk, dv, the gradients of lin_edge's
+    weight and bias and of the edge attributes == torch autograd of the fp32 oracle applied to E = edge_attr W^T + b."""
+    gen = torch.Generator().manual_seed(7 * H + C + fe)
+    n_src, n_dst, m = 70, 50, 400
+    D = H * C
+    assert ops.fused_edge_backward_supported(D, H, fe)
+    ei = rand_graph(gen, n_src, n_dst, m, empty=(3, 7, 20))
+    q, k, v, g = (torch.randn(n, H, C, generator=gen).to(dtype) for n in (n_dst, n_src, n_src, n_dst))
+    ea = torch.randn(m, fe, generator=gen)
+    w, b = (torch.randn(D, fe, generator=gen) / fe**0.5).to(dtype), (0.1 * torch.randn(D, generator=gen)).to(dtype)
+    # oracle: differentiable E in fp32
+    qs, ks, vs, eas, ws, bs = (t.detach().float().clone().requires_grad_(True) for t in (q, k, v, ea, w, b))
+    csc = ops.build_csc(ei.to(DEV), (n_src, n_dst))
+    perm = csc.perm.cpu() if csc.perm is not None else torch.arange(m)
+    e_ref = (eas @ ws.t() + bs).view(m, H, C)
+    O.gt_conv(qs, ks, vs, e_ref, ei, (n_src, n_dst)).backward(g.float())
+    flat = lambda t: t.reshape(t.shape[0], D).to(DEV)  # noqa: E731
+    feat = ops.pack_edge_features(ea[perm].to(DEV))
+    wp = ops.pack_edge_weights(w.to(DEV), b.to(DEV))
+    out, lse = ops.gt_attention_fused_edge(flat(q), flat(k), flat(v), feat, wp, csc, H, return_lse=True)
+    dq, dk, dv, d_wp, d_feat = ops.gt_attention_fused_edge_backward(flat(g), flat(q), flat(k), flat(v), feat, wp, out, lse, csc,
+                                                                    ops.build_reverse_csr(csc), H, need_feat_grad=True)
+    for name, a, r in (("dq", dq, qs.grad), ("dk", dk, ks.grad), ("dv", dv, vs.grad)):
+        assert_close(a.view(-1, H, C), r, dtype, f"{name} H={H} C={C}")
+    # parameter / attribute gradients are fp32 sums over all edges: compare relative to their scale
+    tol = 1e-4 if dtype == torch.float32 else 3e-2
+    for name, a, r in (("d_weight", d_wp[:, :fe].cpu(), ws.grad), ("d_bias", d_wp[:, fe].cpu(), bs.grad)):
+        assert float((a - r).abs().max()) <= tol * float(r.abs().max()) + 1e-5, name
+    d_ea = torch.empty(m, fe)
+    d_ea[perm] = d_feat[:, :fe].cpu()
+    assert float((d_ea - eas.grad).abs().max()) <= tol * float(eas.grad.abs().max()) + 1e-5
+    assert float(dq.view(n_dst, -1)[[3, 7, 20]].abs().max()) == 0.0  # rows without edges
+    again = ops.gt_attention_fused_edge_backward(flat(g), flat(q), flat(k), flat(v), feat, wp, out, lse, csc,
+                                                 ops.build_reverse_csr(csc), H, need_feat_grad=True)
+    assert all(torch.equal(x, y) for x, y in zip((dq, dk, dv, d_wp, d_feat), again))  # deterministic
