@@ -338,40 +338,62 @@ __global__ __launch_bounds__(64 * kBwdWaves) void gt_attn_bwd_dst_fused_kernel(
       sfP[f] = sfS[f] = 0.f;
     }
     const float m = lse[(int64_t)d * H + h];
-    for (int ei = beg; ei < end; ++ei) {
-      const int s = __builtin_amdgcn_readfirstlane(row[ei]);
-      float kv[VEC], vv[VEC];
-      load_vec<T, VEC>(k + (int64_t)s * ldk + c0, kv);
-      load_vec<T, VEC>(v + (int64_t)s * ldv + c0, vv);
-      const float* fe = feat + (int64_t)ei * FE_PAD;  // wave-uniform address: scalar loads
-      float ff[FE_PAD];
+    // Edge loop as in the forward kernel: the source ids of a chunk come from ONE coalesced load, PF edges are in flight
+    // (unconditional clamped refills keep the ring registers free of select code).
+    using Raw = Vec<T, VEC>;
+    constexpr int PF = 2;
+    for (int chunk = beg; chunk < end; chunk += 64) {
+      const int n = min(64, end - chunk);
+      const int my_src = (lane < n) ? row[chunk + lane] : 0;
+      Raw kb[PF], vb[PF];
+      float fb[PF][FE_PAD];
+      auto fetch = [&](int j, Raw& kr, Raw& vr, float (&fr)[FE_PAD]) {
+        j = min(j, n - 1);
+        const int s = __builtin_amdgcn_readlane(my_src, j);
+        kr = *reinterpret_cast<const Raw*>(k + (int64_t)s * ldk + c0);
+        vr = *reinterpret_cast<const Raw*>(v + (int64_t)s * ldv + c0);
+        const float* a = feat + (int64_t)(chunk + j) * FE_PAD;  // wave-uniform address -> scalar loads
 #pragma unroll
-      for (int f = 0; f < FE_PAD; ++f) ff[f] = fe[f];
-      float dot = 0.f, da = 0.f;
+        for (int f = 0; f < FE_PAD; ++f) fr[f] = a[f];
+      };
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        dot = fmaf(qv[i], kv[i], dot);
-        da = fmaf(gv[i], vv[i], da);
-      }
-      dot = group_sum<LPH>(dot);
-      da = group_sum<LPH>(da);
+      for (int st = 0; st < PF; ++st) fetch(st, kb[st], vb[st], fb[st]);
+      for (int j0 = 0; j0 < n; j0 += PF) {
 #pragma unroll
-      for (int f = 0; f < FE_PAD; ++f) {
-        dot = fmaf(ff[f], qw[f], dot);
-        da = fmaf(ff[f], gw[f], da);
-      }
-      const float p = __expf(dot * scale - m);
-      const float ds = p * (da - Dj) * scale;  // dS_e / sqrt(C)
+        for (int st = 0; st < PF; ++st) {
+          const int j = j0 + st;
+          if (j < n) {
+            float dot = 0.f, da = 0.f;
+            float kv[VEC];
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) acc[i] = fmaf(ds, kv[i], acc[i]);
+            for (int i = 0; i < VEC; ++i) {
+              kv[i] = to_float(kb[st].v[i]);
+              dot = fmaf(qv[i], kv[i], dot);
+              da = fmaf(gv[i], to_float(vb[st].v[i]), da);
+            }
+            dot = group_sum<LPH>(dot);
+            da = group_sum<LPH>(da);
 #pragma unroll
-      for (int f = 0; f < FE_PAD; ++f) {
-        sfP[f] = fmaf(p, ff[f], sfP[f]);
-        sfS[f] = fmaf(ds, ff[f], sfS[f]);
-      }
-      if ((lane % LPH) == 0) {
-        p_ws[(int64_t)ei * H + h] = p;
-        ds_ws[(int64_t)ei * H + h] = ds;
+            for (int f = 0; f < FE_PAD; ++f) {
+              dot = fmaf(fb[st][f], qw[f], dot);
+              da = fmaf(fb[st][f], gw[f], da);
+            }
+            const float p = __expf(dot * scale - m);
+            const float ds = p * (da - Dj) * scale;  // dS_e / sqrt(C)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] = fmaf(ds, kv[i], acc[i]);
+#pragma unroll
+            for (int f = 0; f < FE_PAD; ++f) {
+              sfP[f] = fmaf(p, fb[st][f], sfP[f]);
+              sfS[f] = fmaf(ds, fb[st][f], sfS[f]);
+            }
+            if ((lane % LPH) == 0) {
+              p_ws[(int64_t)(chunk + j) * H + h] = p;
+              ds_ws[(int64_t)(chunk + j) * H + h] = ds;
+            }
+            fetch(j + PF, kb[st], vb[st], fb[st]);
+          }
+        }
       }
     }
 #pragma unroll
@@ -379,19 +401,19 @@ __global__ __launch_bounds__(64 * kBwdWaves) void gt_attn_bwd_dst_fused_kernel(
 #pragma unroll
       for (int j = 0; j < VEC; ++j) acc[j] = fmaf(wl[f * VEC + j], sfS[f], acc[j]);
     store_vec<T, VEC>(dq + (int64_t)d * lddq + c0, acc);
-    if ((lane % LPH) == 0) {  // every (destination, head) slot is written, also with no in-edges (zeros)
-      float* sp = sf_ws + ((int64_t)d * H + h) * 2 * FE_PAD;
+    if ((lane % LPH) == 0) {  // every (destination, head) slot is written, also with no in-edges (zeros); 16-byte stores
+      float4* sp = reinterpret_cast<float4*>(sf_ws + ((int64_t)d * H + h) * 2 * FE_PAD);
 #pragma unroll
-      for (int f = 0; f < FE_PAD; ++f) {
-        sp[f] = sfP[f];
-        sp[FE_PAD + f] = sfS[f];
+      for (int t = 0; t < FE_PAD / 4; ++t) {
+        sp[t] = float4{sfP[4 * t], sfP[4 * t + 1], sfP[4 * t + 2], sfP[4 * t + 3]};
+        sp[FE_PAD / 4 + t] = float4{sfS[4 * t], sfS[4 * t + 1], sfS[4 * t + 2], sfS[4 * t + 3]};
       }
-      if (qg_ws != nullptr) {
-        float* gp = qg_ws + ((int64_t)d * H + h) * 2 * FE_PAD;
+      if (qg_ws != nullptr) {  // qw as it is: the 1/sqrt(C) is already inside dS
+        float4* gp = reinterpret_cast<float4*>(qg_ws + ((int64_t)d * H + h) * 2 * FE_PAD);
 #pragma unroll
-        for (int f = 0; f < FE_PAD; ++f) {
-          gp[f] = qw[f];  // the 1/sqrt(C) is already inside dS
-          gp[FE_PAD + f] = gw[f];
+        for (int t = 0; t < FE_PAD / 4; ++t) {
+          gp[t] = float4{qw[4 * t], qw[4 * t + 1], qw[4 * t + 2], qw[4 * t + 3]};
+          gp[FE_PAD / 4 + t] = float4{gw[4 * t], gw[4 * t + 1], gw[4 * t + 2], gw[4 * t + 3]};
         }
       }
     }
@@ -404,7 +426,7 @@ template <typename T, int VEC, int LPH, int FE_PAD>
 __global__ __launch_bounds__(64 * kBwdWaves) void edge_weight_grad_kernel(const T* __restrict__ q, int64_t ldq, const T* __restrict__ d_out,
                                                                           int64_t lddo, const float* __restrict__ sf_ws,
                                                                           float* __restrict__ part, int n_dst, int H) {
-  extern __shared__ float block_sum[];  // [64 * VEC][FE_PAD]
+  extern __shared__ float block_sum[];  // [FE_PAD][64 * VEC]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c0 = lane * VEC, h = lane / LPH;
   float dw[FE_PAD][VEC];
@@ -412,14 +434,39 @@ __global__ __launch_bounds__(64 * kBwdWaves) void edge_weight_grad_kernel(const 
   for (int f = 0; f < FE_PAD; ++f)
 #pragma unroll
     for (int j = 0; j < VEC; ++j) dw[f][j] = 0.f;
-  for (int d = blockIdx.x * kBwdWaves + wave; d < n_dst; d += gridDim.x * kBwdWaves) {
-    float qv[VEC], gv[VEC];
-    load_vec<T, VEC>(q + (int64_t)d * ldq + c0, qv);
-    load_vec<T, VEC>(d_out + (int64_t)d * lddo + c0, gv);
-    const float* sp = sf_ws + ((int64_t)d * H + h) * 2 * FE_PAD;
+  // rows d, d + stride, ...: the loads of the next row are issued before the current one is accumulated
+  using Raw = Vec<T, VEC>;
+  const int stride = gridDim.x * kBwdWaves;
+  int d = blockIdx.x * kBwdWaves + wave;
+  Raw q_n{}, g_n{};
+  float4 s_n[FE_PAD / 2];
+  auto fetch = [&](int dd) {
+    dd = min(dd, n_dst - 1);  // unconditional (clamped) refill
+    q_n = *reinterpret_cast<const Raw*>(q + (int64_t)dd * ldq + c0);
+    g_n = *reinterpret_cast<const Raw*>(d_out + (int64_t)dd * lddo + c0);
+    const float4* sp = reinterpret_cast<const float4*>(sf_ws + ((int64_t)dd * H + h) * 2 * FE_PAD);  // FE_PAD % 4 == 0
+#pragma unroll
+    for (int t = 0; t < FE_PAD / 2; ++t) s_n[t] = sp[t];
+  };
+  if (d < n_dst) fetch(d);
+  for (; d < n_dst; d += stride) {
+    float qv[VEC], gv[VEC], sv[2 * FE_PAD];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      qv[j] = to_float(q_n.v[j]);
+      gv[j] = to_float(g_n.v[j]);
+    }
+#pragma unroll
+    for (int t = 0; t < FE_PAD / 2; ++t) {
+      sv[4 * t] = s_n[t].x;
+      sv[4 * t + 1] = s_n[t].y;
+      sv[4 * t + 2] = s_n[t].z;
+      sv[4 * t + 3] = s_n[t].w;
+    }
+    fetch(d + stride);
 #pragma unroll
     for (int f = 0; f < FE_PAD; ++f) {
-      const float a = sp[f], b = sp[FE_PAD + f];
+      const float a = sv[f], b = sv[FE_PAD + f];
 #pragma unroll
       for (int j = 0; j < VEC; ++j) dw[f][j] = fmaf(gv[j], a, fmaf(qv[j], b, dw[f][j]));
     }
@@ -430,7 +477,7 @@ __global__ __launch_bounds__(64 * kBwdWaves) void edge_weight_grad_kernel(const 
       for (int f = 0; f < FE_PAD; ++f)
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-          float* dst = block_sum + (c0 + j) * FE_PAD + f;
+          float* dst = block_sum + f * (64 * VEC) + c0 + j;  // [feature][channel]: a lane's channels are contiguous, no bank conflicts
           *dst = kq == 0 ? dw[f][j] : *dst + dw[f][j];
         }
     }
@@ -440,19 +487,28 @@ __global__ __launch_bounds__(64 * kBwdWaves) void edge_weight_grad_kernel(const 
   for (int i = threadIdx.x; i < 64 * VEC * FE_PAD; i += 64 * kBwdWaves) prow[i] = block_sum[i];
 }
 
-__global__ void sum_partial_rows_kernel(const float* __restrict__ part, int n_part, int n, float* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int b = 0;
-  for (; b + 3 < n_part; b += 4) {
-    s0 += part[(int64_t)b * n + i];
-    s1 += part[(int64_t)(b + 1) * n + i];
-    s2 += part[(int64_t)(b + 2) * n + i];
-    s3 += part[(int64_t)(b + 3) * n + i];
+// out[c][f] = sum_b part[b][f][c] (the partial rows are [feature][channel], the result [channel][feature] like w_packed)
+__global__ __launch_bounds__(1024) void sum_partial_rows_kernel(const float* __restrict__ part, int n_part, int n, int D, float* __restrict__ out) {
+  __shared__ float red[16][64];
+  const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + cl;
+  float s0 = 0.f, s1 = 0.f;
+  if (i < n) {
+    int b = grp;
+    for (; b + 16 < n_part; b += 32) {  // two independent chains of loads
+      s0 += part[(int64_t)b * n + i];
+      s1 += part[(int64_t)(b + 16) * n + i];
+    }
+    if (b < n_part) s0 += part[(int64_t)b * n + i];
   }
-  for (; b < n_part; ++b) s0 += part[(int64_t)b * n + i];
-  out[i] = (s0 + s1) + (s2 + s3);
+  red[grp][cl] = s0 + s1;
+  __syncthreads();
+#pragma unroll
+  for (int step = 8; step >= 1; step >>= 1) {
+    if (grp < step) red[grp][cl] += red[grp + step][cl];
+    __syncthreads();
+  }
+  if (grp == 0 && i < n) out[(i % D) * (n / D) + i / D] = red[0][cl];
 }
 
 // df[e][f] = sum_h p[e,h] gw[d,h,f] + ds[e,h] qw[d,h,f]: 16 lanes per edge (lane = feature), edges sorted by destination.
@@ -504,7 +560,7 @@ int launch_fused_cfg(const FusedBwdArgs& f, float scale) {
     int rc = check_launch("edge_weight_grad_kernel");
     if (rc != ANEMOI_OK) return rc;
   }
-  hipLaunchKernelGGL(sum_partial_rows_kernel, dim3((nw + 255) / 256), dim3(256), 0, a.stream, f.part_ws, wb, nw, f.d_w_packed);
+  hipLaunchKernelGGL(sum_partial_rows_kernel, dim3((nw + 63) / 64), dim3(1024), 0, a.stream, f.part_ws, wb, nw, 64 * VEC, f.d_w_packed);
   int rc = check_launch("sum_partial_rows_kernel");
   if (rc != ANEMOI_OK) return rc;
   if (f.d_feat != nullptr && f.n_edges > 0) {
