@@ -39,8 +39,8 @@ SIGNATURES = {
     "anemoi_layernorm_fwd": ([_p, _i64, _p, _p, _p, _i64, _p, _i64, _i32, _i32, _f, C.c_int, _p], C.c_int),
     "anemoi_gt_attention_fused_edge_bwd_partial_floats": ([_i32, _i32, _i32], _i64),
     "anemoi_gt_attention_fused_edge_bwd": ([_p, _i64, _p, _i64, _p, _i64, _p, _i32, _p, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p,
-                                            _p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32,
-                                            C.c_int, _p], C.c_int),
+                                            _p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _i64,
+                                            _i32, _i32, _i32, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_linear_wgrad_workspace_bytes": ([_i32, _i32, _i32], _i64),
     "anemoi_linear_wgrad": ([_p, _i64, _p, _i64, _p, _i64, _p, _p, _i32, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_linear_splitk_f32": ([_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, _i32, C.c_int, _p], C.c_int),

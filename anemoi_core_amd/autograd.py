@@ -134,8 +134,11 @@ class LayerNormFunction(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         need_p = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
         dx, dg, db = ops.layer_norm_backward(d_y.contiguous(), x, weight, ctx.eps, need_param_grads=need_p)
-        return (dx if ctx.needs_input_grad[0] else None, dg.to(weight.dtype) if ctx.needs_input_grad[1] else None,
-                db.to(weight.dtype) if ctx.has_bias and ctx.needs_input_grad[2] else None, None)
+        if need_p:  # dgamma and dbeta are the two rows of one fp32 buffer: one cast for both
+            gb = dg._base.to(weight.dtype)
+            dg, db = gb[0], gb[1]
+        return (dx if ctx.needs_input_grad[0] else None, dg if ctx.needs_input_grad[1] else None,
+                db if ctx.has_bias and ctx.needs_input_grad[2] else None, None)
 
 
 class CondLayerNormFunction(torch.autograd.Function):
@@ -257,11 +260,11 @@ class FusedEdgeAttentionFunction(torch.autograd.Function):
         A = spec["A"]
         slab = lambda key: bufs[spec[key][0]][:, spec[key][1]: spec[key][1] + A]  # noqa: E731
         wp = ops.pack_edge_weights(weight.contiguous(), bias)
-        out, lse = ops.gt_attention_fused_edge(slab("q"), slab("k"), slab("v"), feat, wp, csc, num_heads, return_lse=True)
+        y, lse = ops.gt_attention_fused_edge(slab("q"), slab("k"), slab("v"), feat, wp, csc, num_heads, addend=slab("s"), return_lse=True)
         ctx.spec, ctx.csc, ctx.H, ctx.reverse = spec, csc, num_heads, reverse
         ctx.fe, ctx.wdt, ctx.bdt = weight.shape[1], weight.dtype, None if bias is None else bias.dtype
-        ctx.save_for_backward(feat, wp, out, lse, *bufs)
-        return out + slab("s")
+        ctx.save_for_backward(feat, wp, y, lse, *bufs)  # y includes the self term; the backward kernel subtracts it again
+        return y
 
     @staticmethod
     def backward(ctx, d_y):
@@ -276,10 +279,13 @@ class FusedEdgeAttentionFunction(torch.autograd.Function):
         slab = lambda ts, key: ts[spec[key][0]][:, spec[key][1]: spec[key][1] + A]  # noqa: E731
         _, _, _, d_wp, d_feat = ops.gt_attention_fused_edge_backward(
             d_y, slab(bufs, "q"), slab(bufs, "k"), slab(bufs, "v"), feat, wp, out, lse, ctx.csc, ctx.reverse, ctx.H,
-            grads_out=(slab(grads, "q"), slab(grads, "k"), slab(grads, "v")), need_feat_grad=ctx.needs_input_grad[4])
-        slab(grads, "s").copy_(d_y)
-        d_w = d_wp[:, :ctx.fe].to(ctx.wdt) if ctx.needs_input_grad[5] else None
-        d_b = d_wp[:, ctx.fe].to(ctx.bdt) if ctx.bdt is not None and ctx.needs_input_grad[6] else None
+            grads_out=(slab(grads, "q"), slab(grads, "k"), slab(grads, "v")), need_feat_grad=ctx.needs_input_grad[4],
+            addend=slab(bufs, "s"), d_addend=slab(grads, "s"))
+        d_w = d_b = None
+        if ctx.needs_input_grad[5] or ctx.needs_input_grad[6]:
+            d_wb = d_wp[:, :ctx.fe + 1].to(ctx.wdt)  # one cast for weight and bias
+            d_w = d_wb[:, :ctx.fe] if ctx.needs_input_grad[5] else None
+            d_b = d_wb[:, ctx.fe].to(ctx.bdt) if ctx.bdt is not None and ctx.needs_input_grad[6] else None
         return (None, None, None, None, d_feat, d_w, d_b, *grads)
 
 

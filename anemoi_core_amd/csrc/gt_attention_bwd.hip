@@ -295,7 +295,10 @@ __global__ __launch_bounds__(64 * kBwdWaves) void gt_attn_bwd_dst_fused_kernel(
     const float* __restrict__ feat, const float* __restrict__ w_packed, const T* __restrict__ out, int64_t ldo,
     const float* __restrict__ lse, const T* __restrict__ d_out, int64_t lddo, const int32_t* __restrict__ row,
     const int32_t* __restrict__ colptr, T* __restrict__ dq, int64_t lddq, float* __restrict__ p_ws, float* __restrict__ ds_ws,
-    float* __restrict__ sf_ws, float* __restrict__ qg_ws, int n_dst, int H, float scale) {
+    float* __restrict__ sf_ws, float* __restrict__ qg_ws, const T* __restrict__ addend, int64_t ldadd, T* __restrict__ d_addend,
+    int64_t lddadd, int n_dst, int H, float scale) {
+  // addend != NULL: `out` is the forward's result INCLUDING the addend (o = out - addend); d_addend != NULL: receives dO (the
+  // gradient of the addend) - both save an elementwise kernel around the op.
   using L = WLayoutB<VEC, FE_PAD>;
   extern __shared__ __attribute__((aligned(16))) float w_lds[];  // [64][kChunk], chunk layout [feature][channel]
   const int lane = threadIdx.x & 63;
@@ -317,6 +320,13 @@ __global__ __launch_bounds__(64 * kBwdWaves) void gt_attn_bwd_dst_fused_kernel(
     load_vec<T, VEC>(q + (int64_t)d * ldq + c0, qv);
     load_vec<T, VEC>(d_out + (int64_t)d * lddo + c0, gv);
     load_vec<T, VEC>(out + (int64_t)d * ldo + c0, ov);
+    if (addend != nullptr) {
+      float av[VEC];
+      load_vec<T, VEC>(addend + (int64_t)d * ldadd + c0, av);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) ov[i] -= av[i];
+    }
+    if (d_addend != nullptr) store_vec<T, VEC>(d_addend + (int64_t)d * lddadd + c0, gv);
     float dd = 0.f;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
@@ -533,6 +543,10 @@ struct FusedBwdArgs {
   int fe_pad;
   float *d_w_packed, *d_feat, *sf_ws, *qg_ws, *part_ws;
   int n_edges;
+  const void* addend;
+  int64_t ldadd;
+  void* d_addend;
+  int64_t lddadd;
 };
 
 template <typename T, int VEC, int LPH, int FE_PAD>
@@ -546,8 +560,8 @@ int launch_fused_cfg(const FusedBwdArgs& f, float scale) {
     blocks = blocks < 256 * 6 ? blocks : 256 * 6;
     hipLaunchKernelGGL((gt_attn_bwd_dst_fused_kernel<T, VEC, LPH, FE_PAD>), dim3(blocks), block, L::kFloats * sizeof(float), a.stream,
                        (const T*)a.q, a.ldq, (const T*)a.k, a.ldk, (const T*)a.v, a.ldv, f.feat, f.w_packed, (const T*)a.out, a.ldo,
-                       a.lse, (const T*)a.d_out, a.lddo, a.row, a.colptr, (T*)a.dq, a.lddq, a.p_ws, a.ds_ws, f.sf_ws, f.qg_ws, a.n_dst,
-                       a.H, scale);
+                       a.lse, (const T*)a.d_out, a.lddo, a.row, a.colptr, (T*)a.dq, a.lddq, a.p_ws, a.ds_ws, f.sf_ws, f.qg_ws,
+                       (const T*)f.addend, f.ldadd, (T*)f.d_addend, f.lddadd, a.n_dst, a.H, scale);
     int rc = check_launch("gt_attn_bwd_dst_fused_kernel");
     if (rc != ANEMOI_OK) return rc;
   }
@@ -602,7 +616,7 @@ int launch_fused(const FusedBwdArgs& f) {
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   const bool aligned = a.ldq % vb == 0 && a.ldk % vb == 0 && a.ldv % vb == 0 && a.ldo % vb == 0 && a.lddo % vb == 0 && a.lddq % vb == 0 &&
                        a.lddk % vb == 0 && a.lddv % vb == 0 && al16(a.q) && al16(a.k) && al16(a.v) && al16(a.out) && al16(a.d_out) &&
-                       al16(a.dq) && al16(a.dk) && al16(a.dv);
+                       al16(a.dq) && al16(a.dk) && al16(a.dv) && al16(f.addend) && al16(f.d_addend) && f.ldadd % vb == 0 && f.lddadd % vb == 0;
   int rc = 1;
   if (D % 64 == 0 && aligned) {
     const int vec = D / 64, lph = a.C % vec == 0 ? a.C / vec : 0;
@@ -661,8 +675,9 @@ extern "C" int anemoi_gt_attention_fused_edge_bwd(const void* q, int64_t ldq, co
                                                   const int32_t* colptr, const int32_t* rowptr, const int32_t* edge_ids,
                                                   const int32_t* edge_dst, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv,
                                                   int64_t lddv, float* d_w_packed, float* d_edge_feat, float* p_ws, float* ds_ws,
-                                                  float* sf_ws, float* qg_ws, float* part_ws, int32_t n_dst, int32_t n_src,
-                                                  int32_t n_edges, int32_t H, int32_t C, anemoi_dtype_t dtype, void* stream) {
+                                                  float* sf_ws, float* qg_ws, float* part_ws, const void* addend, int64_t ldadd,
+                                                  void* d_addend, int64_t lddadd, int32_t n_dst, int32_t n_src, int32_t n_edges,
+                                                  int32_t H, int32_t C, anemoi_dtype_t dtype, void* stream) {
   ANEMOI_REQUIRE(n_dst > 0 && n_src > 0 && n_edges >= 0 && H > 0 && C > 0 && fe_pad > 0 && fe_pad % 4 == 0,
                  "gt_attention_fused_edge_bwd: bad sizes n_dst=%d n_src=%d M=%d H=%d C=%d fe_pad=%d", n_dst, n_src, n_edges, H, C, fe_pad);
   ANEMOI_REQUIRE(q && k && v && out && lse && d_out && colptr && rowptr && dq && dk && dv && w_packed && d_w_packed && sf_ws && part_ws,
@@ -674,7 +689,9 @@ extern "C" int anemoi_gt_attention_fused_edge_bwd(const void* q, int64_t ldq, co
                  "gt_attention_fused_edge_bwd: leading dimension smaller than H*C=%lld", (long long)D);
   FusedBwdArgs f{{q, k, v, nullptr, out, d_out, ldq, ldk, ldv, 0, ldo, lddo, lse, row, colptr, rowptr, edge_ids, edge_dst,
                   dq, dk, dv, nullptr, lddq, lddk, lddv, 0, p_ws, ds_ws, n_dst, n_src, H, C, as_stream(stream)},
-                 edge_feat, w_packed, fe_pad, d_w_packed, d_edge_feat, sf_ws, d_edge_feat ? qg_ws : nullptr, part_ws, n_edges};
+                 edge_feat, w_packed, fe_pad, d_w_packed, d_edge_feat, sf_ws, d_edge_feat ? qg_ws : nullptr, part_ws, n_edges,
+                 addend, ldadd, d_addend, lddadd};
+  ANEMOI_REQUIRE((addend == nullptr || ldadd >= D) && (d_addend == nullptr || lddadd >= D), "gt_attention_fused_edge_bwd: addend stride");
   switch (dtype) {
     case ANEMOI_F32: return launch_fused<float>(f);
     case ANEMOI_BF16: return launch_fused<bf16_t>(f);

@@ -204,9 +204,10 @@ def fused_edge_backward_supported(D: int, num_heads: int, fe: int) -> bool:
 
 def gt_attention_fused_edge_backward(d_out: Tensor, q: Tensor, k: Tensor, v: Tensor, edge_feat: Tensor, w_packed: Tensor, out: Tensor,
                                      lse: Tensor, csc: CSC, reverse: tuple[Tensor, Tensor, Tensor], num_heads: int, grads_out=None,
-                                     need_feat_grad: bool = False):
-    """Gradients of ``gt_attention_fused_edge`` (no addend): (dq, dk, dv, d_w_packed fp32 [D, fe_pad], d_edge_feat fp32
-    [M, fe_pad] or None).  E and dE are never materialised.  ``out`` / ``lse``: the forward's results."""
+                                     need_feat_grad: bool = False, addend: Optional[Tensor] = None, d_addend: Optional[Tensor] = None):
+    """Gradients of ``gt_attention_fused_edge``: (dq, dk, dv, d_w_packed fp32 [D, fe_pad], d_edge_feat fp32 [M, fe_pad] or
+    None).  E and dE are never materialised.  ``out`` / ``lse``: the forward's results; ``addend``: the forward's addend if it
+    had one (``out`` includes it); ``d_addend``: a [n_dst, D] view that receives the addend's gradient (= d_out)."""
     rowptr, edge_ids, edge_dst = reverse
     _dev(d_out, q, k, v, edge_feat, w_packed, out, lse, csc.row, rowptr, edge_ids, edge_dst)
     D = q.shape[1]
@@ -239,7 +240,8 @@ def gt_attention_fused_edge_backward(d_out: Tensor, q: Tensor, k: Tensor, v: Ten
         qp, ldq, kp, ldk, vp, ldv, edge_feat.data_ptr(), fe_pad, w_packed.data_ptr(), op, ldo, lse.contiguous().data_ptr(), gp, ldg,
         csc.row.data_ptr(), csc.colptr.data_ptr(), rowptr.data_ptr(), edge_ids.data_ptr(), edge_dst.data_ptr(), dqp, lddq, dkp, lddk,
         dvp, lddv, d_wp.data_ptr(), 0 if d_feat is None else d_feat.data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(), sf.data_ptr(),
-        0 if qg is None else qg.data_ptr(), part.data_ptr(), csc.n_dst, csc.n_src, M, num_heads, D // num_heads, _dt(q), _stream())
+        0 if qg is None else qg.data_ptr(), part.data_ptr(), *_rows(addend, "addend", q.dtype), *_rows(d_addend, "d_addend", q.dtype),
+        csc.n_dst, csc.n_src, M, num_heads, D // num_heads, _dt(q), _stream())
     _lib.check(rc, "gt_attention_fused_edge_bwd")
     return dq, dk, dv, d_wp, d_feat
 
@@ -443,8 +445,8 @@ def layer_norm_backward(d_y: Tensor, x: Tensor, weight: Tensor, eps: float = 1e-
     D = x.shape[-1]
     x2, g2 = x.reshape(-1, D), d_y.reshape(-1, D)
     dx = torch.empty((x2.shape[0], D), dtype=x.dtype, device=x.device)
-    dg = torch.empty(D, dtype=torch.float32, device=x.device) if need_param_grads else None
-    db = torch.empty(D, dtype=torch.float32, device=x.device) if need_param_grads else None
+    gb = torch.empty((2, D), dtype=torch.float32, device=x.device) if need_param_grads else None  # one buffer: one cast later
+    dg, db = (gb[0], gb[1]) if need_param_grads else (None, None)
     (xp, ldx), (gp, ldg) = _rows(x2, "x"), _rows(g2, "d_y", x.dtype)
     rc = _lib.load().anemoi_layernorm_bwd(xp, ldx, _vec(weight, "weight", D, x.dtype), gp, ldg, dx.data_ptr(), D,
                                           dg.data_ptr() if need_param_grads else 0, db.data_ptr() if need_param_grads else 0,

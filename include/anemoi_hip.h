@@ -84,7 +84,9 @@ int anemoi_gt_attention_fused_edge_fwd(const void* q, int64_t ldq, const void* k
 
 /* Backward of the fused-edge op (scope row f1): dq / dk / dv as anemoi_gt_attention_bwd, plus d_w_packed fp32 [H*C, fe_pad]
  * (= [d w_edge | d b_edge | .]) and, when d_edge_feat != NULL, d_edge_feat fp32 [M, fe_pad] (gradient of the edge attributes,
- * CSC order); E and dE are never materialised.  `out` / `lse`: the forward's results WITHOUT addend.  Workspaces (fp32):
+ * CSC order); E and dE are never materialised.  `out` / `lse`: the forward's results; when the forward ran with an addend pass the
+ * same rows as `addend` (o = out - addend is formed in the kernel); `d_addend` (nullable) receives the addend's gradient (= d_out)
+ * from the same pass.  Workspaces (fp32):
  * p_ws, ds_ws [M, H]; sf_ws, qg_ws [n_dst, H, 2, fe_pad] (qg_ws only with d_edge_feat); part_ws
  * [anemoi_gt_attention_fused_edge_bwd_partial_floats].  Shapes outside the fused fast path return ANEMOI_E_UNSUPPORTED (train
  * through anemoi_gt_attention_bwd with a materialised E then).  Replaces the autograd of lin_edge + the op
@@ -96,8 +98,8 @@ int anemoi_gt_attention_fused_edge_bwd(const void* q, int64_t ldq, const void* k
                                        const int32_t* rowptr, const int32_t* edge_ids, const int32_t* edge_dst, void* dq,
                                        int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, float* d_w_packed,
                                        float* d_edge_feat, float* p_ws, float* ds_ws, float* sf_ws, float* qg_ws, float* part_ws,
-                                       int32_t n_dst, int32_t n_src, int32_t n_edges, int32_t H, int32_t C, anemoi_dtype_t dtype,
-                                       void* stream);
+                                       const void* addend, int64_t ldadd, void* d_addend, int64_t lddadd, int32_t n_dst,
+                                       int32_t n_src, int32_t n_edges, int32_t H, int32_t C, anemoi_dtype_t dtype, void* stream);
 
 /* Pack lin_edge's parameters for the fused op: out fp32 [D, fe_pad] = [w_edge [D,Fe] | b_edge [D] (or 0) | 0...]. */
 int anemoi_pack_edge_weights(const void* w_edge, const void* b_edge, float* out, int32_t D, int32_t fe, int32_t fe_pad,

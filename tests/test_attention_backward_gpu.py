@@ -163,3 +163,12 @@ def test_fused_edge_backward_vs_oracle_autograd(ops, dtype, H, C, fe):
     again = ops.gt_attention_fused_edge_backward(flat(g), flat(q), flat(k), flat(v), feat, wp, out, lse, csc,
                                                  ops.build_reverse_csr(csc), H, need_feat_grad=True)
     assert all(torch.equal(x, y) for x, y in zip((dq, dk, dv, d_wp, d_feat), again))  # deterministic
+    # forward with an addend (the blocks' self term): the backward takes out + addend and hands back the addend's gradient
+    add = torch.randn(n_dst, D, generator=gen).to(dtype).to(DEV)
+    y = ops.gt_attention_fused_edge(flat(q), flat(k), flat(v), feat, wp, csc, H, addend=add)
+    d_add = torch.empty_like(add)
+    withadd = ops.gt_attention_fused_edge_backward(flat(g), flat(q), flat(k), flat(v), feat, wp, y, lse, csc, ops.build_reverse_csr(csc), H,
+                                                   need_feat_grad=True, addend=add, d_addend=d_add)
+    assert torch.equal(d_add, flat(g))
+    for name, a, r2 in zip(("dq", "dk", "dv", "d_wp", "d_feat"), withadd, (dq, dk, dv, d_wp, d_feat)):
+        assert float((a.float() - r2.float()).abs().max()) <= (1e-4 if dtype == torch.float32 else 3e-2) * float(r2.float().abs().max()) + 1e-5, name
