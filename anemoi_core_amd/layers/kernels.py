@@ -102,8 +102,10 @@ class PaddedLinear:
         pad = (-K) % 8
         if pad == 0 or x.dtype == torch.float32:
             return ops.linear(x, lin.weight, lin.bias, **kw)
-        if x.shape[-1] == K:  # else: the caller already zero-padded the rows (one padded copy shared by several layers)
+        if x.shape[-1] == K:
             x = torch.nn.functional.pad(x, (0, pad))
+        elif x.shape[-1] != K + pad:  # else: the caller already zero-padded the rows (one padded copy shared by several consumers)
+            raise ValueError(f"input width {x.shape[-1]} matches neither in_features {K} nor its padded width {K + pad}")
         if torch.is_grad_enabled() and lin.weight.requires_grad:  # training: gradients flow through the padding
             return ops.linear(x, torch.nn.functional.pad(lin.weight, (0, pad)), lin.bias, **kw)
         sig = (lin.weight.data_ptr(), version(lin.weight), lin.weight.dtype, str(lin.weight.device))

@@ -89,7 +89,7 @@ class MLP(nn.Module):
                 kw["x2"] = x2
             if last and ln is None and residual is not None:
                 kw["residual"] = residual.reshape(-1, residual.shape[-1])
-            if n == 0 and h.shape[1] % 8 and h.dtype != torch.float32 and kw.get("x2") is None:
+            if n == 0 and lin.weight.shape[1] % 8 and h.dtype != torch.float32 and kw.get("x2") is None:
                 # e.g. the 11 raw edge attributes entering a GNN's edge embedding: zero-pad K onto the MFMA path
                 h = self._pad_first(h, lin, act=act, **{k: v for k, v in kw.items() if k != "x2"})
             else:

@@ -19,6 +19,8 @@ from ..distributed.primitives import shard_tensor
 from ..distributed.shapes import BipartiteGraphShardInfo, GraphShardInfo, comm_size, get_shard_sizes
 from ..layers.graph import NamedNodesAttributes
 from ..layers.graph_provider import create_graph_provider
+from ..layers.mapper import GraphTransformerBaseMapper
+from ..utils.tensors import version
 from ..utils.config import DotDict, instantiate
 
 _REF_PREFIX = "anemoi.models.layers."
@@ -80,6 +82,7 @@ class AnemoiModelEncProcDec(nn.Module):
         res = mc.get("residual", {}) or {}
         self._skip_step = int(res.get("step", -1))
         self.boundings = self._build_boundings(mc.get("bounding", []) or [])
+        self._pad_zeros = self._hidden_padded = None
         self._bound_tables: dict = {}
 
     # -- shapes (models/base.py:96-150) -------------------------------------------------------------------
@@ -151,7 +154,33 @@ class AnemoiModelEncProcDec(nn.Module):
             node_attr = shard_tensor(node_attr, 0, shard_sizes, group)
         B, T, E, N, V = x.shape
         flat = x.permute(0, 2, 3, 1, 4).reshape(B * E * N, T * V)  # "(batch ensemble grid) (time vars)"
-        return torch.cat((flat, node_attr.to(flat.dtype)), dim=-1), x_skip
+        cols = [flat, node_attr.to(flat.dtype)]
+        pad = (-(flat.shape[1] + node_attr.shape[1])) % 8
+        if pad and flat.dtype != torch.float32 and self._prepad(ds):
+            # 16-bit GEMM operand rows must be 16-byte aligned: the zero columns the embeddings of encoder (source) and decoder
+            # (destination) would each append with a pad kernel are written by this cat instead (PaddedLinear takes such rows)
+            key = (flat.shape[0], pad, flat.dtype, str(flat.device))
+            if self._pad_zeros is None or self._pad_zeros[0] != key:
+                self._pad_zeros = (key, torch.zeros((flat.shape[0], pad), dtype=flat.dtype, device=flat.device))
+            cols.append(self._pad_zeros[1])
+        return torch.cat(cols, dim=-1), x_skip
+
+    def _prepad(self, ds: str) -> bool:
+        """The GraphTransformer mappers embed their inputs through PaddedLinear, which accepts rows that already carry the
+        alignment zeros; the GNN mappers (MLP embeddings) take the exact width."""
+        return isinstance(self.encoder[ds], GraphTransformerBaseMapper) and isinstance(self.decoder[ds], GraphTransformerBaseMapper)
+
+    def _hidden_attributes(self, batch_size: int) -> Tensor:
+        """Node attributes of the hidden mesh; outside training (a static tensor) with the zero columns of the 16-byte row
+        alignment already appended, once."""
+        x = self.node_attributes(self._graph_name_hidden, batch_size=batch_size)
+        pad = (-x.shape[1]) % 8
+        if not pad or x.dtype == torch.float32 or (torch.is_grad_enabled() and x.requires_grad) or not all(self._prepad(ds) for ds in self.dataset_names):
+            return x
+        key = (x.data_ptr(), version(x), tuple(x.shape), x.dtype)
+        if self._hidden_padded is None or self._hidden_padded[0] != key:
+            self._hidden_padded = (key, torch.nn.functional.pad(x, (0, pad)), x)
+        return self._hidden_padded[1]
 
     def _assemble_output(self, x_out: Tensor, x_skip: Tensor, batch_size: int, ensemble_size: int, dtype, ds: str) -> Tensor:
         N = x_out.shape[0] // (batch_size * ensemble_size)
@@ -186,7 +215,7 @@ class AnemoiModelEncProcDec(nn.Module):
             assert batch_size == 1, "Only batch size of 1 is supported when model is sharded across GPUs"
             assert ensemble_size == 1, "Ensemble size per device must be 1 when model is sharded across GPUs"
         hid = self._graph_name_hidden
-        x_hidden_latent = self.node_attributes(hid, batch_size=batch_size)
+        x_hidden_latent = self._hidden_attributes(batch_size)
         shard_sizes_hidden = get_shard_sizes(x_hidden_latent, 0, model_comm_group)
         x_hidden_latent = shard_tensor(x_hidden_latent, 0, shard_sizes_hidden, model_comm_group)
         latents, skips, data_latents, data_shards = {}, {}, {}, {}
