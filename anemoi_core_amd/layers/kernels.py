@@ -91,26 +91,28 @@ class GELU(nn.GELU):
 class PaddedLinear:
     """Apply an ``nn.Linear`` whose in_features is not a multiple of 8 on the MFMA path: 16-bit operand rows must be
     16-byte aligned, so the K dimension of both the input and a cached copy of the weight is zero-padded to a multiple
-    of 8 (exact: the extra products are 0).  fp32 inputs take the generic kernel and need no padding."""
+    of 8 (exact: the extra products are 0).  An input that already carries zero columns (any multiple of 8 >= in_features)
+    is taken as it is and only the weight is padded to its width.  fp32 inputs take the generic kernel and need no padding."""
 
     def __init__(self):
         self._sig = None
         self._w = None
 
     def __call__(self, x: Tensor, lin: nn.Linear, **kw) -> Tensor:
-        K = lin.weight.shape[1]
-        pad = (-K) % 8
-        if pad == 0 or x.dtype == torch.float32:
+        K, W = lin.weight.shape[1], x.shape[-1]
+        if x.dtype == torch.float32 or (W == K and K % 8 == 0):
             return ops.linear(x, lin.weight, lin.bias, **kw)
-        if x.shape[-1] == K:
-            x = torch.nn.functional.pad(x, (0, pad))
-        elif x.shape[-1] != K + pad:  # else: the caller already zero-padded the rows (one padded copy shared by several consumers)
-            raise ValueError(f"input width {x.shape[-1]} matches neither in_features {K} nor its padded width {K + pad}")
+        if W == K:
+            x = torch.nn.functional.pad(x, (0, (-K) % 8))
+            W = x.shape[-1]
+        elif W < K or W % 8:  # else: the caller already appended zero columns (one padded copy shared by several consumers,
+            # possibly up to a multiple of 64 so that the GEMM takes the DMA-ring kernels)
+            raise ValueError(f"input width {W} is neither in_features {K} nor a zero-padded width (multiple of 8 >= {K})")
         if torch.is_grad_enabled() and lin.weight.requires_grad:  # training: gradients flow through the padding
-            return ops.linear(x, torch.nn.functional.pad(lin.weight, (0, pad)), lin.bias, **kw)
-        sig = (lin.weight.data_ptr(), version(lin.weight), lin.weight.dtype, str(lin.weight.device))
+            return ops.linear(x, torch.nn.functional.pad(lin.weight, (0, W - K)), lin.bias, **kw)
+        sig = (lin.weight.data_ptr(), version(lin.weight), lin.weight.dtype, str(lin.weight.device), W)
         if self._sig != sig:
             with torch.no_grad():
-                self._w = torch.nn.functional.pad(lin.weight, (0, pad)).contiguous()
+                self._w = torch.nn.functional.pad(lin.weight, (0, W - K)).contiguous()
             self._sig = sig
         return ops.linear(x, self._w, lin.bias, **kw)

@@ -9,6 +9,7 @@ existing config selects the HIP path without edits.  Residual = SkipConnection (
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -21,6 +22,8 @@ from ..layers.graph import NamedNodesAttributes
 from ..layers.graph_provider import create_graph_provider
 from ..layers.mapper import GraphTransformerBaseMapper
 from ..utils.tensors import version
+
+_PAD64 = os.environ.get("ANEMOI_PAD64", "1") == "1"  # developer switch: 0 = pad the input width to a multiple of 8 only
 from ..utils.config import DotDict, instantiate
 
 _REF_PREFIX = "anemoi.models.layers."
@@ -155,7 +158,8 @@ class AnemoiModelEncProcDec(nn.Module):
         B, T, E, N, V = x.shape
         flat = x.permute(0, 2, 3, 1, 4).reshape(B * E * N, T * V)  # "(batch ensemble grid) (time vars)"
         cols = [flat, node_attr.to(flat.dtype)]
-        pad = (-(flat.shape[1] + node_attr.shape[1])) % 8
+        width = flat.shape[1] + node_attr.shape[1]
+        pad = (-width) % 64 if (-width) % 64 <= 16 and _PAD64 else (-width) % 8  # a K multiple of 64 takes the DMA-ring GEMM kernels
         if pad and flat.dtype != torch.float32 and self._prepad(ds):
             # 16-bit GEMM operand rows must be 16-byte aligned: the zero columns the embeddings of encoder (source) and decoder
             # (destination) would each append with a pad kernel are written by this cat instead (PaddedLinear takes such rows)
