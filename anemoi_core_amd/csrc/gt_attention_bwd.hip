@@ -108,17 +108,39 @@ __global__ __launch_bounds__(64 * kBwdWaves) void gt_attn_bwd_src_kernel(
 #pragma unroll
   for (int i = 0; i < VEC; ++i) ak[i] = av[i] = 0.f;
   const int beg = rowptr[s], end = rowptr[s + 1];
-  for (int i = beg; i < end; ++i) {
-    const int ei = edge_ids[i];
-    const int d = edge_dst[ei];
-    float qv[VEC], gv[VEC];
-    load_vec<T, VEC>(q + (int64_t)d * ldq + c0, qv);
-    load_vec<T, VEC>(d_out + (int64_t)d * lddo + c0, gv);
-    const float p = p_ws[(int64_t)ei * H + h], ds = ds_ws[(int64_t)ei * H + h];
+  // Out-edges in chunks of 64: edge ids and their destinations come from two coalesced loads (lane j holds edge j of the
+  // chunk) and are broadcast with v_readlane; the q / dO rows of PF edges are in flight (clamped unconditional refills).
+  using Raw = Vec<T, VEC>;
+  constexpr int PF = 2;
+  for (int chunk = beg; chunk < end; chunk += 64) {
+    const int n = min(64, end - chunk);
+    const int my_e = (lane < n) ? edge_ids[chunk + lane] : 0;
+    const int my_d = (lane < n) ? edge_dst[my_e] : 0;
+    Raw qb[PF], gb[PF];
+    float pb[PF], sb[PF];
+    auto fetch = [&](int j, Raw& qr, Raw& gr, float& pr, float& sr) {
+      j = min(j, n - 1);
+      const int ei = __builtin_amdgcn_readlane(my_e, j);
+      const int d = __builtin_amdgcn_readlane(my_d, j);
+      qr = *reinterpret_cast<const Raw*>(q + (int64_t)d * ldq + c0);
+      gr = *reinterpret_cast<const Raw*>(d_out + (int64_t)d * lddo + c0);
+      pr = p_ws[(int64_t)ei * H + h];
+      sr = ds_ws[(int64_t)ei * H + h];
+    };
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      ak[j] = fmaf(ds, qv[j], ak[j]);
-      av[j] = fmaf(p, gv[j], av[j]);
+    for (int st = 0; st < PF; ++st) fetch(st, qb[st], gb[st], pb[st], sb[st]);
+    for (int j0 = 0; j0 < n; j0 += PF) {
+#pragma unroll
+      for (int st = 0; st < PF; ++st) {
+        if (j0 + st < n) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            ak[j] = fmaf(sb[st], to_float(qb[st].v[j]), ak[j]);
+            av[j] = fmaf(pb[st], to_float(gb[st].v[j]), av[j]);
+          }
+          fetch(j0 + st + PF, qb[st], gb[st], pb[st], sb[st]);
+        }
+      }
     }
   }
   store_vec<T, VEC>(dk + (int64_t)s * lddk + c0, ak);
@@ -529,12 +551,20 @@ __global__ void edge_feat_grad_kernel(const float* __restrict__ p_ws, const floa
   const int f = (int)(t & 15);
   if (e >= n_edges || f >= fe_pad) return;
   const int d = edge_dst[e];
-  float s = 0.f;
-  for (int hh = 0; hh < H; ++hh) {
-    const float* gp = qg_ws + ((int64_t)d * H + hh) * 2 * fe_pad;
-    s = fmaf(p_ws[e * H + hh], gp[fe_pad + f], fmaf(ds_ws[e * H + hh], gp[f], s));
+  float s0 = 0.f, s1 = 0.f;  // two independent chains; the loads of several heads are in flight together
+  int hh = 0;
+#pragma unroll 4
+  for (; hh + 1 < H; hh += 2) {
+    const float* g0 = qg_ws + ((int64_t)d * H + hh) * 2 * fe_pad;
+    const float* g1 = g0 + 2 * fe_pad;
+    s0 = fmaf(p_ws[e * H + hh], g0[fe_pad + f], fmaf(ds_ws[e * H + hh], g0[f], s0));
+    s1 = fmaf(p_ws[e * H + hh + 1], g1[fe_pad + f], fmaf(ds_ws[e * H + hh + 1], g1[f], s1));
   }
-  d_feat[e * fe_pad + f] = s;
+  if (hh < H) {
+    const float* g0 = qg_ws + ((int64_t)d * H + hh) * 2 * fe_pad;
+    s0 = fmaf(p_ws[e * H + hh], g0[fe_pad + f], fmaf(ds_ws[e * H + hh], g0[f], s0));
+  }
+  d_feat[e * fe_pad + f] = s0 + s1;
 }
 
 struct FusedBwdArgs {
