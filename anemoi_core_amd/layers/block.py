@@ -414,12 +414,21 @@ class GraphTransformerProcessorBlock(GraphTransformerBaseBlock):
             plan = self._halo_plan(x, edge_index, shard_info, batch_size, model_comm_group, halo_cache)
             x_plus_halo = comm.halo_exchange(xn, plan.send_index, plan.send_counts, plan.recv_counts, model_comm_group,
                                              gather_fn=ops.gather_rows)
-            w_qs, b_qs = self._fused.get("qs", [self.lin_query, self.lin_self])
-            w_kv, b_kv = self._fused.get("kv", [self.lin_key, self.lin_value])
-            qs = ops.linear(xn, w_qs, b_qs)
-            kv = ops.linear(x_plus_halo, w_kv, b_kv)
-            q, k, v, x_r = qs[:, :A], kv[:, :A], kv[:, A:], qs[:, A:]
-            fused = dict(bufs=(qs, kv), q=(0, 0), s=(0, A), k=(1, 0), v=(1, A))
+            nl = xn.shape[0]
+            if not ops._needs_grad(xn, self.lin_query.weight) and x_plus_halo.shape[0] <= 2 * nl:
+                # inference on a shard: ONE fused [q|k|v|self] GEMM over local + halo rows (q / self of the halo rows are
+                # wasted work, but at a rank's row counts a GEMM launch costs more than those flops)
+                w, b = self._fused.get("qkvs", [self.lin_query, self.lin_key, self.lin_value, self.lin_self])
+                qkvs = ops.linear(x_plus_halo, w, b)
+                q, k, v, x_r = qkvs[:nl, :A], qkvs[:, A:2 * A], qkvs[:, 2 * A:3 * A], qkvs[:nl, 3 * A:]
+                fused = None
+            else:
+                w_qs, b_qs = self._fused.get("qs", [self.lin_query, self.lin_self])
+                w_kv, b_kv = self._fused.get("kv", [self.lin_key, self.lin_value])
+                qs = ops.linear(xn, w_qs, b_qs)
+                kv = ops.linear(x_plus_halo, w_kv, b_kv)
+                q, k, v, x_r = qs[:, :A], kv[:, :A], kv[:, A:], qs[:, A:]
+                fused = dict(bufs=(qs, kv), q=(0, 0), s=(0, A), k=(1, 0), v=(1, A))
             csc = get_csc(plan.edge_index_local, (plan.info.total_nodes, plan.info.num_local_nodes), True)
         else:
             n = x.shape[0]
