@@ -171,6 +171,15 @@ def halo_exchange(x: Tensor, send_index: Tensor, send_counts: Sequence[int], rec
     return torch.cat([x, recv], dim=0)
 
 
+def halo_exchange_into(buf: Tensor, n_local: int, send_index: Tensor, send_counts: Sequence[int], recv_counts: Sequence[int], group,
+                       gather_fn) -> Tensor:
+    """Inference variant of ``halo_exchange`` without the concatenation: ``buf`` [n_local + n_halo, D] already holds the local
+    rows in its head; the halo rows are received straight into its tail."""
+    packed = gather_fn(buf[:n_local], send_index)
+    _all_to_all_single(buf[n_local:], packed.contiguous(), list(recv_counts), list(send_counts), group)
+    return buf
+
+
 def exchange_rows(x_local: Tensor, want_global_ids: Tensor, shard_sizes: Sequence[int], group, gather_fn=None,
                   plan: Optional[dict] = None):
     """Needed-rows exchange: every rank holds a contiguous shard of a [N, D] table and obtains the rows

@@ -22,7 +22,7 @@ from ..distributed.partition import build_graph_partition_from_shard_info
 from ..distributed.shapes import BipartiteGraphShardInfo, GraphShardInfo, comm_rank, comm_size, model_is_distributed
 from .conv import GraphConv
 from .graphcache import get_csc, get_edge_features, get_reverse_csr
-from .kernels import PaddedLinear, apply_layer_norm
+from .kernels import ConditionalLayerNorm, PaddedLinear, apply_layer_norm
 from .mlp import MLP
 from .utils import compute_mlp_hidden_dim
 from ..utils.tensors import version
@@ -407,13 +407,24 @@ class GraphTransformerProcessorBlock(GraphTransformerBaseBlock):
             csc = get_csc(edge_index, (x.shape[0], x.shape[0]), edges_are_dst_sorted)
             out = self._attention(q, k, v, x_r, edge_attr, csc)
             return self._post_attention(out, x, cond, chain), edge_attr
-        xn = apply_layer_norm(ln, x, cond)
+        sharded = model_is_distributed(model_comm_group) and self.shard_strategy != "heads"
+        x_plus_halo = None
+        if (sharded and cond is None and not isinstance(ln, ConditionalLayerNorm) and not ops._needs_grad(x, ln.weight)):
+            # inference on a shard: LayerNorm writes the head of the [local + halo] buffer, the all-to-all receives into its tail
+            plan = self._halo_plan(x, edge_index, shard_info, batch_size, model_comm_group, halo_cache)
+            nl = x.shape[0]
+            x_plus_halo = torch.empty((nl + sum(plan.recv_counts), x.shape[1]), dtype=x.dtype, device=x.device)
+            xn = ops.layer_norm(x, ln.weight, ln.bias, ln.eps, out=x_plus_halo[:nl])
+            comm.halo_exchange_into(x_plus_halo, nl, plan.send_index, plan.send_counts, plan.recv_counts, model_comm_group, ops.gather_rows)
+        else:
+            xn = apply_layer_norm(ln, x, cond)
         if model_is_distributed(model_comm_group) and self.shard_strategy == "heads":
             return self._forward_heads(x, xn, edge_attr, edge_index, shard_info, batch_size, model_comm_group, cond, halo_cache), edge_attr
         if model_is_distributed(model_comm_group):
             plan = self._halo_plan(x, edge_index, shard_info, batch_size, model_comm_group, halo_cache)
-            x_plus_halo = comm.halo_exchange(xn, plan.send_index, plan.send_counts, plan.recv_counts, model_comm_group,
-                                             gather_fn=ops.gather_rows)
+            if x_plus_halo is None:
+                x_plus_halo = comm.halo_exchange(xn, plan.send_index, plan.send_counts, plan.recv_counts, model_comm_group,
+                                                 gather_fn=ops.gather_rows)
             nl = xn.shape[0]
             if not ops._needs_grad(xn, self.lin_query.weight) and x_plus_halo.shape[0] <= 2 * nl:
                 # inference on a shard: ONE fused [q|k|v|self] GEMM over local + halo rows (q / self of the halo rows are

@@ -341,9 +341,15 @@ def _needs_grad(*tensors) -> bool:
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
-def layer_norm(x: Tensor, weight: Tensor, bias: Optional[Tensor], eps: float = 1e-5, residual: Optional[Tensor] = None) -> Tensor:
+def layer_norm(x: Tensor, weight: Tensor, bias: Optional[Tensor], eps: float = 1e-5, residual: Optional[Tensor] = None,
+               out: Optional[Tensor] = None) -> Tensor:
     """LayerNorm over the last dim of a [..., D] tensor (fp32 statistics), optionally + residual (same shape).
-    Differentiable: with autograd recording it runs as ``autograd.LayerNormFunction`` (HIP backward kernel)."""
+    Differentiable: with autograd recording it runs as ``autograd.LayerNormFunction`` (HIP backward kernel).
+    ``out`` (inference only): a contiguous [rows, D] tensor that receives the result."""
+    if out is not None:
+        if _needs_grad(x, weight, bias, residual):
+            raise ValueError("layer_norm: out= is an inference-only argument")
+        return _layer_norm_fwd(x, weight, bias, eps, residual, out)
     if _needs_grad(x, weight, bias, residual):
         from .autograd import LayerNormFunction
 
@@ -352,13 +358,17 @@ def layer_norm(x: Tensor, weight: Tensor, bias: Optional[Tensor], eps: float = 1
     return _layer_norm_fwd(x, weight, bias, eps, residual)
 
 
-def _layer_norm_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], eps: float = 1e-5, residual: Optional[Tensor] = None) -> Tensor:
-    _dev(x, weight, bias, residual)
+def _layer_norm_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], eps: float = 1e-5, residual: Optional[Tensor] = None,
+                    out: Optional[Tensor] = None) -> Tensor:
+    """``out``: a contiguous [rows, D] tensor (e.g. the leading rows of a larger buffer) that receives the result."""
+    _dev(x, weight, bias, residual, out)
     D = x.shape[-1]
     x2 = x.reshape(-1, D)
     if x2.shape[1] > 1 and x2.stride(1) != 1:
         x2 = x2.contiguous()
-    y = torch.empty((x2.shape[0], D), dtype=x.dtype, device=x.device)
+    if out is not None and (tuple(out.shape) != (x2.shape[0], D) or out.dtype != x.dtype or not out.is_contiguous()):
+        raise ValueError("layer_norm: out must be a contiguous [rows, D] tensor of x's dtype")
+    y = torch.empty((x2.shape[0], D), dtype=x.dtype, device=x.device) if out is None else out
     p, ld = _rows(x2, "x")
     if residual is not None and residual.shape != x.shape:
         raise ValueError("residual shape does not match x")

@@ -54,10 +54,13 @@ def gt_attention_fused_edge(q, k, v, edge_feat, w_packed, csc, num_heads, addend
     return gt_attention(q, k, v, e, csc, num_heads, addend, return_lse)
 
 
-def layer_norm(x, weight, bias, eps=1e-5, residual=None):
+def layer_norm(x, weight, bias, eps=1e-5, residual=None, out=None):
     y = F.layer_norm(x.float(), (x.shape[-1],), weight.float(), None if bias is None else bias.float(), eps)
     if residual is not None:
         y = y + residual.float()
+    if out is not None:
+        out.copy_(y.to(x.dtype))
+        return out
     return y.to(x.dtype)
 
 
