@@ -338,6 +338,38 @@ def gen_model():
     save("model_tiny.pt", out)
 
 
+def gen_model_grads():
+    """Gradients of the REFERENCE's tiny models (same parameters / input as model_tiny.pt): loss = sum(out * w) with the seeded w the
+    gradient tests use; pins the backward (scope row f1) to the reference's own autograd instead of the oracle's."""
+    from anemoi.models.models import AnemoiModelEncProcDec
+
+    base = torch.load(os.path.join(HERE, "model_tiny.pt"), weights_only=False)
+    g = build_synthetic_graph("o8", 3)
+    out = {}
+    for kind in ("gt", "gnn"):
+        c = base[kind]
+        cfg = c["cfg"]
+        torch.manual_seed(33)
+        model = AnemoiModelEncProcDec(
+            model_config=model_config(kind, cfg["num_channels"], cfg["num_layers"], cfg["num_heads"], cfg["trainable"]),
+            data_indices=make_data_indices(cfg["n_vars"], cfg["n_vars"]),
+            statistics={"data": None},
+            n_step_input=cfg["n_step_input"],
+            n_step_output=1,
+            graph_data=make_hetero(g),
+        ).train()
+        model.load_state_dict(c["params"], strict=True)
+        x = c["x"].clone().requires_grad_(True)
+        w = torch.randn(c["out"].shape, generator=torch.Generator().manual_seed(2))
+        y = model({"data": x})["data"]
+        assert float((y.detach() - c["out"]).abs().max()) < 1e-5
+        (y * w).sum().backward()
+        grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+        out[kind] = dict(grads=grads, dx=x.grad.clone(), loss_weight_seed=2)
+        print(kind, "model grads", len(grads), "parameters, |dx| mean", float(x.grad.abs().mean()))
+    save("model_tiny_grads.pt", out)
+
+
 # ----------------------------------------------------------------------------------- sharding (gloo, multi-process)
 def _shard_worker(rank, world, init_file, g_proc, params, cfg, x, ea, result_dir):
     import torch.distributed as dist
@@ -476,7 +508,7 @@ def gen_variants():
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ["conv", "blocks", "proc", "model", "sharding", "variants"]
+    which = sys.argv[1:] or ["conv", "blocks", "proc", "model", "grads", "sharding", "variants"]
     if "conv" in which:
         gen_conv()
     if "blocks" in which:
@@ -485,6 +517,8 @@ if __name__ == "__main__":
         gen_proc_mappers()
     if "model" in which:
         gen_model()
+    if "grads" in which:
+        gen_model_grads()
     if "sharding" in which:
         gen_sharding()
     if "variants" in which:

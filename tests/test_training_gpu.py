@@ -185,3 +185,23 @@ def test_conditional_layernorm_block_gradients_match_oracle():
     for name, prm in blk.named_parameters():
         # lin_key.bias has a ZERO true gradient (softmax is shift-invariant per destination): both sides are round-off there
         _close(prm.grad, p["b." + name].grad, f"d{name}", atol=2e-5)
+
+
+@pytest.mark.parametrize("kind", ["gt", "gnn"])
+def test_full_model_gradients_match_reference_autograd(kind):
+    """The HIP backward against the REFERENCE's own autograd (fixture model_tiny_grads.pt generated by importing the reference:
+    input gradient and every parameter gradient, loss = sum(out * w) with the seeded w)."""
+    c, r = load_golden("model_tiny.pt")[kind], load_golden("model_tiny_grads.pt")[kind]
+    model, _ = build_model_from_fixture(c)
+    model.load_state_dict(c["params"], strict=True)
+    model = model.to(DEV).train()
+    x = c["x"].to(DEV).requires_grad_(True)
+    w = torch.randn(c["out"].shape, generator=torch.Generator().manual_seed(r["loss_weight_seed"]))
+    (model({"data": x})["data"] * w.to(DEV)).sum().backward()
+    _close(x.grad, r["dx"], "d input")
+    got = dict(model.named_parameters())
+    assert set(r["grads"]) <= set(got)
+    for name, ref in r["grads"].items():
+        assert got[name].grad is not None, f"no gradient for {name}"
+        _close(got[name].grad, ref, f"d {name}")
+    assert len(r["grads"]) >= 60
