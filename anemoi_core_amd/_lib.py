@@ -9,7 +9,7 @@ import ctypes as C
 import os
 import threading
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libanemoi_hip.so")
 
 F32, BF16, F16 = 0, 1, 2
@@ -47,6 +47,8 @@ SIGNATURES = {
     "anemoi_linear_stats_fwd": ([_p, _i64, _i32, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_linear_lnfold_fwd": ([_p, _i64, _i32, _p, _i64, _p, _p, _p, _i32, _f, C.c_int, _p, _i64, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_linear_fwd": ([_p, _i64, _i32, _p, _i64, _i32, _p, _i64, _p, _p, _i64, _p, _p, _i64, _p, _p, _i64, _p, _i64, _i32, _i32, C.c_int, C.c_int, _p], C.c_int),
+    "anemoi_linear_fwd_pre": ([_p, _i64, _i32, _p, _i64, _i32, _p, _i64, _p, _p, _i64, _p, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _i32, _i32,
+                               C.c_int, C.c_int, _p], C.c_int),
     "anemoi_edge_ln_residual_segment_sum_fwd": ([_p, _i64, _p, _i64, _p, _p, _f, _p, _p, _i64, _p, _i64, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_segment_sum_rows": ([_p, _i64, _p, _p, _p, _i64, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_gather_add_rows": ([_p, _i64, _p, _i64, _p, _p, _i64, _i32, _i32, C.c_int, _p], C.c_int),

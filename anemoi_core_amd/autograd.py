@@ -26,6 +26,9 @@ def _t_padded(a: Tensor, mult: int = 64) -> Tensor:
     return ops.transpose_pad(a, mult)
 
 
+_SAVE_PRE = os.environ.get("ANEMOI_SAVE_PREACT", "1") == "1"  # 0: recompute GELU's argument in backward (saves [N, O] per layer)
+
+
 def _granule_rows(t: Tensor) -> Tensor:
     """Rows that start on 16-byte boundaries (what the LDS-DMA granules of the wgrad kernel need), copying only if necessary."""
     ok = t.stride(1) == 1 and (t.shape[0] == 1 or t.stride(0) % 8 == 0) and t.data_ptr() % 16 == 0
@@ -62,16 +65,22 @@ class LinearFunction(torch.autograd.Function):
         ctx.act = act
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
         ctx.seg1, ctx.seg2 = seg1, seg2
-        ctx.save_for_backward(x, weight, bias, g1, idx1, g2, idx2)
-        return ops._linear_fwd(x, weight, bias, act=act, residual=residual, g1=g1, idx1=idx1, g2=g2, idx2=idx2)
+        pre = None
+        if act == "gelu" and _SAVE_PRE:  # the GEMM stores the pre-activation next to the output: no recomputing GEMM in backward
+            y, pre = ops._linear_fwd(x, weight, bias, act=act, residual=residual, g1=g1, idx1=idx1, g2=g2, idx2=idx2, want_pre=True)
+        else:
+            y = ops._linear_fwd(x, weight, bias, act=act, residual=residual, g1=g1, idx1=idx1, g2=g2, idx2=idx2)
+        ctx.save_for_backward(x, weight, bias, g1, idx1, g2, idx2, pre)
+        return y
 
     @staticmethod
     def backward(ctx, d_y: Tensor):
-        x, weight, bias, g1, idx1, g2, idx2 = ctx.saved_tensors
+        x, weight, bias, g1, idx1, g2, idx2, pre = ctx.saved_tensors
         d_y = d_y.contiguous()
         dz = d_y
         if ctx.act == "gelu":
-            pre = ops._linear_fwd(x, weight, bias, g1=g1, idx1=idx1, g2=g2, idx2=idx2)
+            if pre is None:  # shapes outside the DMA-ring kernels: recompute
+                pre = ops._linear_fwd(x, weight, bias, g1=g1, idx1=idx1, g2=g2, idx2=idx2)
             dz = ops.gelu_backward(pre, d_y)
         dx = dw = db = dg1 = dg2 = None
         if ctx.needs_input_grad[0]:

@@ -54,6 +54,8 @@ struct LinArgs {
   int ln_strips = 0, ln_D = 0;
   float ln_eps = 0.f;
   int f32_atomic = 0; // persistent kernel only: y is fp32 and accumulated with atomics (caller zeroes it)
+  void* y_pre = nullptr;  // training, with act = GELU on the DMA-ring kernels: the pre-activation is stored here as well (saves
+  int64_t ldy_pre = 0;    // the backward a recomputing GEMM)
   int tail_rows = 0;  // big-tile kernel only: rows [n_rows, n_rows + tail_rows) are computed on the VALU, a column per wave
 };
 
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(LinArgs a, int tile
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
-enum : int { EPI_RES = 1, EPI_GATHER = 2, EPI_GELU = 4, EPI_STATS = 8, EPI_LNFOLD = 16 };
+enum : int { EPI_RES = 1, EPI_GATHER = 2, EPI_GELU = 4, EPI_STATS = 8, EPI_LNFOLD = 16, EPI_PRE = 32 };  // PRE: also store GELU's argument (training)
 
 // acc[mi][ni][r] = out[m0 + wr*64 + mi*16 + (lane & 15)][n0 + wc*64 + ni*16 + (lane>>4)*4 + r]
 // epi: this wave's 4 KiB LDS slice (16 rows x 256 B); one 16-row band (mi) at a time.  The band is written in the MFMA
@@ -453,6 +455,20 @@ __device__ __forceinline__ void mfma_epilogue_band(const LinArgs& a, f32x4 (&acc
         for (int r = 0; r < 8; ++r) vv[r] += to_float(t1[it].v[r]) + to_float(t2[it].v[r]);
       }
       if constexpr ((EPI & EPI_GELU) != 0) {
+        if constexpr ((EPI & EPI_PRE) != 0) if (ok) {  // training variants only: the inference kernels are untouched
+          V8 p8;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) p8.v[r] = from_float<T>(vv[r]);
+          T* dp = (T*)a.y_pre + (int64_t)m * a.ldy_pre + nc;
+          if (ncols == 8) {
+            *reinterpret_cast<V8*>(dp) = p8;
+          } else {
+            V4 p4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p4.v[r] = p8.v[r];
+            *reinterpret_cast<V4*>(dp) = p4;
+          }
+        }
 #pragma unroll
         for (int r = 0; r < 8; ++r) vv[r] = gelu_fast(vv[r]);
       }
@@ -695,7 +711,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void linear_mfma_persistent_kernel
       mfma_epilogue_band<T, EPI>(a, acc, m0, n0, wr, wc, lane, smem + ((g - 1) % STAGES) * kStageBytes + wave * 4096, interior);
       // An interior tile issues exactly kEpiStores stores per wave, and every load of its epilogue has been consumed
       // (waited for, with everything older) before the last store was issued.  Edge tiles predicate their stores.
-      if (interior && nk >= STAGES && !a.f32_atomic && (EPI & EPI_STATS) == 0)  // the statistics add stores: drain instead of counting
+      if (interior && nk >= STAGES && !a.f32_atomic && (EPI & (EPI_STATS | EPI_PRE)) == 0)  // statistics / pre-activation add stores: drain instead of counting
         counted_stores = true;
       else
         drain_all = true;
@@ -819,7 +835,7 @@ __global__ __launch_bounds__(512, 1) void linear_mfma_splitwave_kernel(LinArgs a
 // per output column, lanes split K in 16-byte chunks, fp32 dot product + butterfly, lane 0 applies the epilogue.
 // Called at the end of the big-tile kernel by every wave of the grid (column = global wave index, stride = waves in the
 // grid): 2 rows x 2048 columns are one column per wave, a few hundred cycles hidden behind the draining stores.
-template <typename T>
+template <typename T, bool PRE = false>
 __device__ __forceinline__ void tail_rows_valu(const LinArgs& a, int m_begin, int m_end, int n_first, int n_stride, int lane) {
   for (int n = n_first; n < a.O; n += n_stride) {
     const T* __restrict__ w = (const T*)a.w + (int64_t)n * a.ldw;
@@ -863,6 +879,7 @@ __device__ __forceinline__ void tail_rows_valu(const LinArgs& a, int m_begin, in
         if (a.bias) vv += to_float(((const T*)a.bias)[n]);
         if (a.g1) vv += to_float(((const T*)a.g1)[(int64_t)a.idx1[m] * a.ldg1 + n]);
         if (a.g2) vv += to_float(((const T*)a.g2)[(int64_t)a.idx2[m] * a.ldg2 + n]);
+        if constexpr (PRE) ((T*)a.y_pre)[(int64_t)m * a.ldy_pre + n] = from_float<T>(vv);  // pre-activation for the backward
         if (a.act == ANEMOI_ACT_GELU) vv = gelu_fast(vv);  // same formula as the rows of the MFMA epilogue
         if (a.residual) vv += to_float(((const T*)a.residual)[(int64_t)m * a.ldr + n]);
         ((T*)a.y)[(int64_t)m * a.ldy + n] = from_float<T>(vv);
@@ -984,7 +1001,7 @@ __global__ __launch_bounds__(512, 1) void linear_mfma_bigtile_kernel(LinArgs a, 
   for (int i = 0; i < kPPW; ++i) issue_piece(i);
   end_issue();
   // the tail rows ride in the shadow of the first (cold) K-tile's flight time
-  if (a.tail_rows > 0) tail_rows_valu<T>(a, a.n_rows, a.n_rows + a.tail_rows, (int)blockIdx.x * NW + wave, G * NW, lane);
+  if (a.tail_rows > 0) tail_rows_valu<T, (EPI & EPI_PRE) != 0>(a, a.n_rows, a.n_rows + a.tail_rows, (int)blockIdx.x * NW + wave, G * NW, lane);
 
   const int frow = lane & 15, fslot = lane >> 4;
   int a_rd[2], w_rd[2];
@@ -1066,7 +1083,7 @@ __global__ __launch_bounds__(512, 1) void linear_mfma_bigtile_kernel(LinArgs a, 
     asm volatile("" ::: "memory");
     const bool interior = (m0 + TBM <= a.n_rows) && (n0 + TBN <= a.O);
     mfma_epilogue_band<T, EPI, MI>(a, acc, m0, n0, wr, wc, lane, smem + ((g - 1) % STAGES) * kStageBytes + wave * 4096, interior, ln_rows);
-    counted_stores = interior;  // exactly kStores stores per wave, issued after the DMAs of the next K-tile
+    counted_stores = interior && (EPI & EPI_PRE) == 0;  // exactly kStores stores per wave, issued after the DMAs of the next K-tile
   }
 }
 
@@ -1190,10 +1207,6 @@ static int launch_persistent(const LinArgs& a, hipStream_t st) {
       const int64_t t1 = (int64_t)((a.n_rows + SM - 1) / SM) * ((a.O + SN - 1) / SN);
       if (sw && t1 <= 256 && a.K2 == 0 && a.K1 % SK == 0 && a.splits == 1 && !a.f32_atomic) return launch_splitwave<T, EPI>(a, st);
     }
-    // a lone small tile walks its K-loop at DMA latency / stages in flight: long K -> deeper ring (24.5 KiB per stage)
-    static const int deep = [] { const char* e = getenv("ANEMOI_GEMM_SMALL_STAGES"); return e ? atoi(e) : 3; }();
-    if (nk >= 16 && deep == 5) return launch_persistent_wm<T, EPI, 1, false, 2, 5>(a, st);
-    if (nk >= 16 && deep == 4) return launch_persistent_wm<T, EPI, 1, false, 2, 4>(a, st);
     return launch_persistent_wm<T, EPI, 1, false, 2>(a, st);
   }
   static const bool pp = [] { const char* e = getenv("ANEMOI_GEMM_PP"); return !(e && e[0] == '0'); }();
@@ -1209,6 +1222,14 @@ template <typename T>
 static int launch_mfma(const LinArgs& a, hipStream_t st) {
   if (ring_eligible<T>(a)) {
     const int epi = (a.residual ? EPI_RES : 0) | (a.g1 ? EPI_GATHER : 0) | (a.act == ANEMOI_ACT_GELU ? EPI_GELU : 0);
+    if (a.y_pre != nullptr) {  // act == GELU checked by the caller
+      switch (epi) {
+        case 4: return launch_persistent<T, 4 | EPI_PRE>(a, st);
+        case 5: return launch_persistent<T, 5 | EPI_PRE>(a, st);
+        case 6: return launch_persistent<T, 6 | EPI_PRE>(a, st);
+        default: return launch_persistent<T, 7 | EPI_PRE>(a, st);
+      }
+    }
     switch (epi) {
       case 0: return launch_persistent<T, 0>(a, st);
       case 1: return launch_persistent<T, 1>(a, st);
@@ -1319,11 +1340,11 @@ extern "C" int anemoi_linear_lnfold_fwd(const void* x, int64_t ldx, int32_t K, c
   return rc;
 }
 
-extern "C" int anemoi_linear_fwd(const void* x, int64_t ldx, int32_t K1, const void* x2, int64_t ldx2, int32_t K2,
-                                 const void* w, int64_t ldw, const void* bias, const void* g1, int64_t ldg1,
-                                 const int32_t* idx1, const void* g2, int64_t ldg2, const int32_t* idx2,
-                                 const void* residual, int64_t ldr, void* y, int64_t ldy, int32_t n_rows, int32_t O,
-                                 anemoi_act_t act, anemoi_dtype_t dtype, void* stream) {
+static int linear_fwd_impl(const void* x, int64_t ldx, int32_t K1, const void* x2, int64_t ldx2, int32_t K2,
+                           const void* w, int64_t ldw, const void* bias, const void* g1, int64_t ldg1,
+                           const int32_t* idx1, const void* g2, int64_t ldg2, const int32_t* idx2,
+                           const void* residual, int64_t ldr, void* y, int64_t ldy, void* y_pre, int64_t ldy_pre, int32_t n_rows,
+                           int32_t O, anemoi_act_t act, anemoi_dtype_t dtype, void* stream) {
   ANEMOI_REQUIRE(n_rows >= 0 && O > 0 && K1 > 0 && K2 >= 0, "linear_fwd: bad sizes n_rows=%d O=%d K1=%d K2=%d", n_rows, O, K1, K2);
   if (n_rows == 0) return ANEMOI_OK;
   ANEMOI_REQUIRE(x && w && y, "linear_fwd: null x/w/y");
@@ -1333,10 +1354,40 @@ extern "C" int anemoi_linear_fwd(const void* x, int64_t ldx, int32_t K1, const v
   ANEMOI_REQUIRE(act == ANEMOI_ACT_NONE || act == ANEMOI_ACT_GELU, "linear_fwd: unknown activation %d", (int)act);
   LinArgs a{x, ldx, K1, x2, ldx2, K2, w, ldw, bias, g1, ldg1, idx1, g2, ldg2, idx2, residual, ldr, y, ldy, n_rows, O, (int)act};
   hipStream_t st = as_stream(stream);
+  if (y_pre != nullptr) {  // only the DMA-ring kernels (shared epilogue) store the pre-activation
+    a.y_pre = y_pre;
+    a.ldy_pre = ldy_pre;
+    const bool ok = act == ANEMOI_ACT_GELU && ldy_pre >= O && ldy_pre % 8 == 0 && al(y_pre, 16) &&
+                    ((dtype == ANEMOI_BF16 && mfma_eligible<bf16_t>(a) && ring_eligible<bf16_t>(a)) ||
+                     (dtype == ANEMOI_F16 && mfma_eligible<f16_t>(a) && ring_eligible<f16_t>(a)));
+    if (!ok) {
+      set_error("linear_fwd_pre: the pre-activation output needs act = GELU on a DMA-ring GEMM shape (16-bit, K %% 64 == 0)");
+      return ANEMOI_E_UNSUPPORTED;
+    }
+  }
   switch (dtype) {
     case ANEMOI_F32: return launch_generic<float>(a, st);
     case ANEMOI_BF16: return mfma_eligible<bf16_t>(a) ? launch_mfma<bf16_t>(a, st) : launch_generic<bf16_t>(a, st);
     case ANEMOI_F16: return mfma_eligible<f16_t>(a) ? launch_mfma<f16_t>(a, st) : launch_generic<f16_t>(a, st);
     default: set_error("unknown dtype %d", (int)dtype); return ANEMOI_E_INVALID;
   }
+}
+
+extern "C" int anemoi_linear_fwd(const void* x, int64_t ldx, int32_t K1, const void* x2, int64_t ldx2, int32_t K2,
+                                 const void* w, int64_t ldw, const void* bias, const void* g1, int64_t ldg1,
+                                 const int32_t* idx1, const void* g2, int64_t ldg2, const int32_t* idx2,
+                                 const void* residual, int64_t ldr, void* y, int64_t ldy, int32_t n_rows, int32_t O,
+                                 anemoi_act_t act, anemoi_dtype_t dtype, void* stream) {
+  return linear_fwd_impl(x, ldx, K1, x2, ldx2, K2, w, ldw, bias, g1, ldg1, idx1, g2, ldg2, idx2, residual, ldr, y, ldy, nullptr, 0, n_rows, O,
+                         act, dtype, stream);
+}
+
+extern "C" int anemoi_linear_fwd_pre(const void* x, int64_t ldx, int32_t K1, const void* x2, int64_t ldx2, int32_t K2,
+                                     const void* w, int64_t ldw, const void* bias, const void* g1, int64_t ldg1,
+                                     const int32_t* idx1, const void* g2, int64_t ldg2, const int32_t* idx2,
+                                     const void* residual, int64_t ldr, void* y, int64_t ldy, void* y_pre, int64_t ldy_pre,
+                                     int32_t n_rows, int32_t O, anemoi_act_t act, anemoi_dtype_t dtype, void* stream) {
+  ANEMOI_REQUIRE(y_pre != nullptr, "linear_fwd_pre: null y_pre");
+  return linear_fwd_impl(x, ldx, K1, x2, ldx2, K2, w, ldw, bias, g1, ldg1, idx1, g2, ldg2, idx2, residual, ldr, y, ldy, y_pre, ldy_pre,
+                         n_rows, O, act, dtype, stream);
 }

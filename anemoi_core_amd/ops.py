@@ -405,7 +405,9 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, *, act: Opt
 def _linear_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, *, act: Optional[str] = None,
                 residual: Optional[Tensor] = None, x2: Optional[Tensor] = None, g1: Optional[Tensor] = None,
                 idx1: Optional[Tensor] = None, g2: Optional[Tensor] = None, idx2: Optional[Tensor] = None,
-                out: Optional[Tensor] = None) -> Tensor:
+                out: Optional[Tensor] = None, want_pre: bool = False):
+    """``want_pre`` (training, act = "gelu"): returns (y, pre) with pre = the pre-activation stored by the same kernel, or
+    (y, None) when the shape does not run on the DMA-ring kernels (the backward then recomputes it)."""
     _dev(x, weight, bias, residual, x2, g1, idx1, g2, idx2, out)
     N, K1 = x.shape
     K2 = 0 if x2 is None else x2.shape[1]
@@ -428,12 +430,21 @@ def _linear_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, *, act
     dt = x.dtype
     (xp, ldx), (x2p, ldx2), (wp, ldw) = _rows(x, "x"), _rows(x2, "x2", dt), _rows(weight, "weight", dt)
     (g1p, ldg1), (g2p, ldg2), (rp, ldr), (yp, ldy) = _rows(g1, "g1", dt), _rows(g2, "g2", dt), _rows(residual, "residual", dt), _rows(y, "out", dt)
-    rc = _lib.load().anemoi_linear_fwd(xp, ldx, K1, x2p, ldx2, K2, wp, ldw, _vec(bias, "bias", O, dt), g1p, ldg1,
-                                       idx1.data_ptr() if idx1 is not None else 0, g2p, ldg2,
-                                       idx2.data_ptr() if idx2 is not None else 0, rp, ldr, yp, ldy, N, O,
-                                       _lib.ACT_GELU if act == "gelu" else _lib.ACT_NONE, _dt(x), _stream())
+    lib = _lib.load()
+    i1p, i2p = idx1.data_ptr() if idx1 is not None else 0, idx2.data_ptr() if idx2 is not None else 0
+    actc = _lib.ACT_GELU if act == "gelu" else _lib.ACT_NONE
+    if want_pre and act == "gelu" and dt != torch.float32 and N > 0:
+        pre = torch.empty((N, O), dtype=dt, device=x.device)
+        rc = lib.anemoi_linear_fwd_pre(xp, ldx, K1, x2p, ldx2, K2, wp, ldw, _vec(bias, "bias", O, dt), g1p, ldg1, i1p, g2p, ldg2, i2p, rp, ldr,
+                                       yp, ldy, pre.data_ptr(), O, N, O, actc, _dt(x), _stream())
+        if rc == 0:
+            return y, pre
+        if rc != _lib.E_UNSUPPORTED:
+            _lib.check(rc, "linear_fwd_pre")
+    rc = lib.anemoi_linear_fwd(xp, ldx, K1, x2p, ldx2, K2, wp, ldw, _vec(bias, "bias", O, dt), g1p, ldg1, i1p, g2p, ldg2, i2p, rp, ldr, yp, ldy,
+                               N, O, actc, _dt(x), _stream())
     _lib.check(rc, "linear_fwd")
-    return y
+    return (y, None) if want_pre else y
 
 
 _REDUCE_WS: dict = {}

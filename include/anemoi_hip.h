@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ANEMOI_HIP_ABI_VERSION 4
+#define ANEMOI_HIP_ABI_VERSION 5
 
 typedef enum { ANEMOI_F32 = 0, ANEMOI_BF16 = 1, ANEMOI_F16 = 2 } anemoi_dtype_t;
 typedef enum { ANEMOI_ACT_NONE = 0, ANEMOI_ACT_GELU = 1 } anemoi_act_t;
@@ -204,6 +204,14 @@ int anemoi_linear_fwd(const void* x, int64_t ldx, int32_t K1, const void* x2, in
                       int64_t ldw, const void* bias, const void* g1, int64_t ldg1, const int32_t* idx1, const void* g2,
                       int64_t ldg2, const int32_t* idx2, const void* residual, int64_t ldr, void* y, int64_t ldy,
                       int32_t n_rows, int32_t O, anemoi_act_t act, anemoi_dtype_t dtype, void* stream);
+
+/* Same, and the pre-activation z (the argument of GELU) is stored to y_pre as well: training keeps it for GELU's backward
+ * instead of recomputing it with a second GEMM (scope row f1).  act must be GELU and the shape one of the DMA-ring GEMM shapes
+ * (16-bit, K multiple of 64); otherwise ANEMOI_E_UNSUPPORTED and nothing is launched. */
+int anemoi_linear_fwd_pre(const void* x, int64_t ldx, int32_t K1, const void* x2, int64_t ldx2, int32_t K2, const void* w,
+                          int64_t ldw, const void* bias, const void* g1, int64_t ldg1, const int32_t* idx1, const void* g2,
+                          int64_t ldg2, const int32_t* idx2, const void* residual, int64_t ldr, void* y, int64_t ldy, void* y_pre,
+                          int64_t ldy_pre, int32_t n_rows, int32_t O, anemoi_act_t act, anemoi_dtype_t dtype, void* stream);
 
 /* GraphConv edge epilogue + aggregation, one pass over the dst-sorted edges (no atomics).
  * Replaces: MLP.layer_norm + "+ edge_attr" + scatter(sum) (layers/conv.py:73-81, layers/mlp.py:176-178).
