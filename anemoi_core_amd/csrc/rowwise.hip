@@ -5,6 +5,8 @@
 // Reference semantics: torch.nn.LayerNorm (eps inside sqrt, biased variance, affine) as instantiated by
 // layer_kernels.LayerNorm (models/src/anemoi/models/layers/utils.py:107-121); GraphConv's
 // "edge_mlp(...) + edge_attr" followed by scatter-sum (models/src/anemoi/models/layers/conv.py:73-81).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace anemoi {
@@ -99,6 +101,59 @@ __global__ __launch_bounds__(64 * kRowWaves) void layernorm_fwd_kernel(const T* 
       for (int j = 0; j < VEC; ++j) r[t][j] += rs[t][j];
   }
   store_row<T, VEC, CH>(y + (int64_t)rowi * ldy, D, lane, r);
+}
+
+// Quarter-wave variant for D = 16 * 8 * CHQ 16-bit elements (D = 512: CHQ = 4): FOUR rows per wave, 16 lanes per row, every lane
+// owns CHQ 16-byte chunks of its row (chunk c covers columns (c * 16 + l16) * 8 ..): 4x fewer waves than one row per wave, CHQ
+// independent loads in flight per lane, and the two reductions stay inside a DPP row (4 butterfly steps instead of 6).
+template <typename T, int CHQ>
+__global__ __launch_bounds__(64 * kRowWaves) void layernorm_fwd_q_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ gamma,
+                                                                         const T* __restrict__ beta, const T* __restrict__ residual,
+                                                                         int64_t ldr, T* __restrict__ y, int64_t ldy, int n_rows, float eps) {
+  constexpr int D = 16 * 8 * CHQ;
+  const int lane = threadIdx.x & 63, l16 = lane & 15;
+  const int rowi = (blockIdx.x * kRowWaves + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+  const bool live = rowi < n_rows;
+  const int64_t r = live ? rowi : n_rows - 1;  // lanes past the end recompute the last row and do not store
+  float v[CHQ][8];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < CHQ; ++c) {
+    load_vec<T, 8>(x + r * ldx + (c * 16 + l16) * 8, v[c]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[c][j];
+  }
+  const float mean = group_sum<16>(s) * (1.0f / D);
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < CHQ; ++c)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      v[c][j] -= mean;
+      ss = fmaf(v[c][j], v[c][j], ss);
+    }
+  const float rstd = rsqrtf(group_sum<16>(ss) * (1.0f / D) + eps);
+#pragma unroll
+  for (int c = 0; c < CHQ; ++c) {
+    const int col = (c * 16 + l16) * 8;
+    float g[8], b[8], o[8];
+    load_vec<T, 8>(gamma + col, g);
+    if (beta != nullptr) {
+      load_vec<T, 8>(beta + col, b);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) b[j] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = fmaf(v[c][j] * rstd, g[j], b[j]);
+    if (residual != nullptr) {
+      float rs[8];
+      load_vec<T, 8>(residual + r * ldr + col, rs);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] += rs[j];
+    }
+    if (live) store_vec<T, 8>(y + r * ldy + col, o);
+  }
 }
 
 // ConditionalLayerNorm (reference layers/normalization.py:34-94): y = LN(x) * (scale[row] + 1) + shift[row] with per-row
@@ -245,6 +300,13 @@ static int layernorm_launch(const void* x, int64_t ldx, const void* gamma, const
   const int vec = pick_vec<T>(D, {ldx, ldy, residual ? ldr : (int64_t)0}, {x, y, gamma, beta, residual});
   const int ch = pick_chunks(D, vec);
   ANEMOI_REQUIRE(ch > 0, "layernorm_fwd: D=%d too large for the register-resident row (max %d at vector width %d)", D, 64 * vec * kMaxChunksLimit, vec);
+  static const bool quarter = [] { const char* e = getenv("ANEMOI_LN_QUARTER"); return !(e && e[0] == '0'); }();
+  if (quarter && sizeof(T) == 2 && vec == 8 && D == 512 && n_rows > 0) {  // the 512-channel rows of the hot path
+    const int rows_per_block = 4 * kRowWaves;
+    hipLaunchKernelGGL((layernorm_fwd_q_kernel<T, 4>), dim3((n_rows + rows_per_block - 1) / rows_per_block), dim3(64 * kRowWaves), 0, st,
+                       (const T*)x, ldx, (const T*)gamma, (const T*)beta, (const T*)residual, ldr, (T*)y, ldy, n_rows, eps);
+    return check_launch("layernorm_fwd_q_kernel");
+  }
   const dim3 grid((n_rows + kRowWaves - 1) / kRowWaves), block(64 * kRowWaves);
 #define LN_CASE(V, C)                                                                                                   \
   case V * 16 + C:                                                                                                      \

@@ -199,6 +199,17 @@ def test_layernorm(ops, dtype, D):
     assert_close(y, F.layer_norm(x.float(), (D,), g.float(), b.float()), dtype, "layernorm")
     y_nb = ops.layer_norm(x.to(DEV), g.to(DEV), None)
     assert_close(y_nb, F.layer_norm(x.float(), (D,), g.float(), None), dtype, "layernorm, no bias")
+    # residual fused, row-strided input (a column slab of a wider buffer) and out= into the head of a larger buffer
+    res = torch.randn(257, D, generator=gen).to(dtype)
+    assert_close(ops.layer_norm(x.to(DEV), g.to(DEV), b.to(DEV), 1e-5, res.to(DEV)),
+                 F.layer_norm(x.float(), (D,), g.float(), b.float()) + res.float(), dtype, "layernorm + residual")
+    if D % 8 == 0:
+        wide = torch.randn(257, D + 16, generator=gen).to(dtype).to(DEV)
+        assert_close(ops.layer_norm(wide[:, 8:8 + D], g.to(DEV), b.to(DEV)),
+                     F.layer_norm(wide[:, 8:8 + D].float().cpu(), (D,), g.float(), b.float()), dtype, "layernorm, strided rows")
+    buf = torch.zeros(300, D, dtype=dtype, device=DEV)
+    got = ops.layer_norm(x.to(DEV), g.to(DEV), b.to(DEV), out=buf[:257])
+    assert got.data_ptr() == buf.data_ptr() and torch.equal(got, y) and float(buf[257:].abs().max()) == 0.0
     # per-head norm over C (qk_norm): 3-D input
     if D <= 64:
         x3 = x.view(257, 1, D).expand(257, 4, D).contiguous()
