@@ -106,24 +106,24 @@ __global__ __launch_bounds__(64 * kRowWaves) void layernorm_fwd_kernel(const T* 
 // Quarter-wave variant for D = 16 * 8 * CHQ 16-bit elements (D = 512: CHQ = 4): FOUR rows per wave, 16 lanes per row, every lane
 // owns CHQ 16-byte chunks of its row (chunk c covers columns (c * 16 + l16) * 8 ..): 4x fewer waves than one row per wave, CHQ
 // independent loads in flight per lane, and the two reductions stay inside a DPP row (4 butterfly steps instead of 6).
-template <typename T, int CHQ>
+template <typename T, int CHQ, int LPR = 16>
 __global__ __launch_bounds__(64 * kRowWaves) void layernorm_fwd_q_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ gamma,
                                                                          const T* __restrict__ beta, const T* __restrict__ residual,
                                                                          int64_t ldr, T* __restrict__ y, int64_t ldy, int n_rows, float eps) {
-  constexpr int D = 16 * 8 * CHQ;
-  const int lane = threadIdx.x & 63, l16 = lane & 15;
-  const int rowi = (blockIdx.x * kRowWaves + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+  constexpr int D = LPR * 8 * CHQ, RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, l16 = lane % LPR;
+  const int rowi = (blockIdx.x * kRowWaves + (threadIdx.x >> 6)) * RPW + lane / LPR;
   const bool live = rowi < n_rows;
   const int64_t r = live ? rowi : n_rows - 1;  // lanes past the end recompute the last row and do not store
   float v[CHQ][8];
   float s = 0.f;
 #pragma unroll
   for (int c = 0; c < CHQ; ++c) {
-    load_vec<T, 8>(x + r * ldx + (c * 16 + l16) * 8, v[c]);
+    load_vec<T, 8>(x + r * ldx + (c * LPR + l16) * 8, v[c]);
 #pragma unroll
     for (int j = 0; j < 8; ++j) s += v[c][j];
   }
-  const float mean = group_sum<16>(s) * (1.0f / D);
+  const float mean = group_sum<LPR>(s) * (1.0f / D);
   float ss = 0.f;
 #pragma unroll
   for (int c = 0; c < CHQ; ++c)
@@ -132,10 +132,10 @@ __global__ __launch_bounds__(64 * kRowWaves) void layernorm_fwd_q_kernel(const T
       v[c][j] -= mean;
       ss = fmaf(v[c][j], v[c][j], ss);
     }
-  const float rstd = rsqrtf(group_sum<16>(ss) * (1.0f / D) + eps);
+  const float rstd = rsqrtf(group_sum<LPR>(ss) * (1.0f / D) + eps);
 #pragma unroll
   for (int c = 0; c < CHQ; ++c) {
-    const int col = (c * 16 + l16) * 8;
+    const int col = (c * LPR + l16) * 8;
     float g[8], b[8], o[8];
     load_vec<T, 8>(gamma + col, g);
     if (beta != nullptr) {
@@ -300,8 +300,9 @@ static int layernorm_launch(const void* x, int64_t ldx, const void* gamma, const
   const int vec = pick_vec<T>(D, {ldx, ldy, residual ? ldr : (int64_t)0}, {x, y, gamma, beta, residual});
   const int ch = pick_chunks(D, vec);
   ANEMOI_REQUIRE(ch > 0, "layernorm_fwd: D=%d too large for the register-resident row (max %d at vector width %d)", D, 64 * vec * kMaxChunksLimit, vec);
-  static const bool quarter = [] { const char* e = getenv("ANEMOI_LN_QUARTER"); return !(e && e[0] == '0'); }();
-  if (quarter && sizeof(T) == 2 && vec == 8 && D == 512 && n_rows > 0) {  // the 512-channel rows of the hot path
+  static const int quarter = [] { const char* e = getenv("ANEMOI_LN_QUARTER"); return e ? atoi(e) : 1; }();
+  if (quarter && sizeof(T) == 2 && vec == 8 && D == 512 && n_rows > 0) {  // the 512-channel rows of the hot path (8 rows per wave,
+    // 8 lanes per row, measured slower: +55 us per forward)
     const int rows_per_block = 4 * kRowWaves;
     hipLaunchKernelGGL((layernorm_fwd_q_kernel<T, 4>), dim3((n_rows + rows_per_block - 1) / rows_per_block), dim3(64 * kRowWaves), 0, st,
                        (const T*)x, ldx, (const T*)gamma, (const T*)beta, (const T*)residual, ldr, (T*)y, ldy, n_rows, eps);
