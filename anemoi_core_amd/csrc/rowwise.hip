@@ -268,6 +268,27 @@ __global__ void assemble_output_kernel(const T* __restrict__ x_out, int64_t ldx,
   out[(int64_t)n * ldo + v] = from_float<T>(val);
 }
 
+// Input assembly at the model edge for batch = ensemble = 1 (reference models/encoder_processor_decoder.py:98-143,
+// "batch time ensemble grid vars -> (batch ensemble grid) (time vars)" + cat with the node attributes):
+//   out[n, :] = [ x[0, n, :] | ... | x[T-1, n, :] | attrs[n, :] | 0 ... ]   (width W >= T*V + A: the alignment zeros of the embedding GEMMs)
+// in one pass instead of a permute-copy and a cat.  Q elements per thread (Q = 4 when V, A, W and the row strides allow 8-byte moves).
+template <typename T, int Q>
+__global__ void assemble_input_kernel(const T* __restrict__ x, int64_t ld_t, int64_t ldx, int T_steps, int V, const T* __restrict__ attrs,
+                                      int64_t lda, int A, T* __restrict__ out, int64_t ldo, int W, int n_rows) {
+  const int per_row = W / Q;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)n_rows * per_row) return;
+  const int n = (int)(i / per_row), c = (int)(i % per_row) * Q;
+  Vec<T, Q> v{};
+  if (c < T_steps * V) {
+    const int t = c / V, cv = c % V;  // V % Q == 0: a group never straddles two time steps
+    v = *reinterpret_cast<const Vec<T, Q>*>(x + t * ld_t + (int64_t)n * ldx + cv);
+  } else if (c < T_steps * V + A) {
+    v = *reinterpret_cast<const Vec<T, Q>*>(attrs + (int64_t)n * lda + (c - T_steps * V));
+  }
+  *reinterpret_cast<Vec<T, Q>*>(out + (int64_t)n * ldo + c) = v;
+}
+
 // Pick the widest vector width (in elements) such that rows stay 16-byte-or-narrower aligned and D % VEC == 0.
 template <typename T>
 static int pick_vec(int D, std::initializer_list<int64_t> lds, std::initializer_list<const void*> ptrs) {
@@ -472,4 +493,31 @@ extern "C" int anemoi_assemble_output(const void* x_out, int64_t ldx, const void
     default: set_error("unknown dtype"); return ANEMOI_E_INVALID;
   }
   return check_launch("assemble_output_kernel");
+}
+
+extern "C" int anemoi_assemble_input(const void* x, int64_t ld_t, int64_t ldx, int32_t T_steps, int32_t V, const void* attrs, int64_t lda,
+                                     int32_t A, void* out, int64_t ldo, int32_t W, int32_t n_rows, anemoi_dtype_t dtype, void* stream) {
+  ANEMOI_REQUIRE(n_rows >= 0 && T_steps > 0 && V > 0 && A >= 0 && W >= T_steps * V + A && ldo >= W && ldx >= V && (A == 0 || lda >= A),
+                 "assemble_input: bad sizes");
+  if (n_rows == 0) return ANEMOI_OK;
+  ANEMOI_REQUIRE(x && out && (A == 0 || attrs), "assemble_input: null pointer");
+  const size_t es = dtype == ANEMOI_F32 ? 4 : 2;
+  auto al = [&](const void* p, int q) { return p == nullptr || reinterpret_cast<uintptr_t>(p) % (q * es) == 0; };
+  const bool q4 = V % 4 == 0 && A % 4 == 0 && W % 4 == 0 && ld_t % 4 == 0 && ldx % 4 == 0 && lda % 4 == 0 && ldo % 4 == 0 && al(x, 4) &&
+                  al(attrs, 4) && al(out, 4);
+  const int q = q4 ? 4 : 1;
+  const int64_t n = (int64_t)n_rows * (W / q);
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  hipStream_t st = as_stream(stream);
+#define AI_LAUNCH(TT, QQ)                                                                                                        \
+  hipLaunchKernelGGL((assemble_input_kernel<TT, QQ>), grid, block, 0, st, (const TT*)x, ld_t, ldx, T_steps, V, (const TT*)attrs, lda, A, \
+                     (TT*)out, ldo, W, n_rows)
+  switch (dtype) {
+    case ANEMOI_F32: if (q4) AI_LAUNCH(float, 4); else AI_LAUNCH(float, 1); break;
+    case ANEMOI_BF16: if (q4) AI_LAUNCH(bf16_t, 4); else AI_LAUNCH(bf16_t, 1); break;
+    case ANEMOI_F16: if (q4) AI_LAUNCH(f16_t, 4); else AI_LAUNCH(f16_t, 1); break;
+    default: set_error("unknown dtype"); return ANEMOI_E_INVALID;
+  }
+#undef AI_LAUNCH
+  return check_launch("assemble_input_kernel");
 }

@@ -23,6 +23,7 @@ from ..layers.graph_provider import create_graph_provider
 from ..layers.mapper import GraphTransformerBaseMapper
 from ..utils.tensors import version
 
+_FUSED_INPUT = os.environ.get("ANEMOI_FUSED_INPUT", "1") == "1"  # developer switch: 0 = permute-copy + cat in torch
 _PAD64 = os.environ.get("ANEMOI_PAD64", "1") == "1"  # developer switch: 0 = pad the input width to a multiple of 8 only
 from ..utils.config import DotDict, instantiate
 
@@ -156,6 +157,13 @@ class AnemoiModelEncProcDec(nn.Module):
         if shard_sizes is not None:
             node_attr = shard_tensor(node_attr, 0, shard_sizes, group)
         B, T, E, N, V = x.shape
+        if (_FUSED_INPUT and B == 1 and E == 1 and x.is_cuda and node_attr.dtype == x.dtype and x.stride(4) == 1
+                and not (torch.is_grad_enabled() and (x.requires_grad or node_attr.requires_grad))):
+            # inference, one member: permute + cat + alignment zeros in ONE kernel
+            width = T * V + node_attr.shape[1]
+            if x.dtype != torch.float32 and self._prepad(ds):
+                width += (-width) % 64 if (-width) % 64 <= 16 and _PAD64 else (-width) % 8
+            return ops.assemble_input(x[0, :, 0], node_attr, width), x_skip
         flat = x.permute(0, 2, 3, 1, 4).reshape(B * E * N, T * V)  # "(batch ensemble grid) (time vars)"
         cols = [flat, node_attr.to(flat.dtype)]
         width = flat.shape[1] + node_attr.shape[1]

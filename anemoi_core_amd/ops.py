@@ -658,6 +658,20 @@ def glu_backward(gate_value: Tensor, d_out: Tensor, kind: str) -> Tensor:
     return out
 
 
+def assemble_input(x: Tensor, attrs: Optional[Tensor], width: int) -> Tensor:
+    """x [T, N, V] (time slices of one batch / ensemble member), attrs [N, A] -> [N, width] = [x[0] | ... | x[T-1] | attrs | 0...]."""
+    _dev(x, attrs)
+    T, N, V = x.shape
+    A = 0 if attrs is None else attrs.shape[1]
+    if x.stride(2) != 1 or width < T * V + A or (attrs is not None and (attrs.shape[0] != N or attrs.dtype != x.dtype)):
+        raise ValueError("assemble_input: x must be [T, N, V] with contiguous variables, attrs [N, A] of the same dtype")
+    out = torch.empty((N, width), dtype=x.dtype, device=x.device)
+    ap, lda = _rows(attrs, "attrs", x.dtype)
+    _lib.check(_lib.load().anemoi_assemble_input(x.data_ptr(), x.stride(0), x.stride(1), T, V, ap, lda, A, out.data_ptr(), width, width, N,
+                                                 _dt(x), _stream()), "assemble_input")
+    return out
+
+
 def assemble_output(x_out: Tensor, x_skip: Tensor, col_map: Tensor) -> Tensor:
     """out[n, v] = x_out[n, v] + x_skip[n, col_map[v]] (where col_map[v] >= 0); x_out [N, V_out], x_skip [N, V_in] (row
     stride allowed), col_map int32 [V_out]."""

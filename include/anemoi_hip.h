@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ANEMOI_HIP_ABI_VERSION 5
+#define ANEMOI_HIP_ABI_VERSION 6
 
 typedef enum { ANEMOI_F32 = 0, ANEMOI_BF16 = 1, ANEMOI_F16 = 2 } anemoi_dtype_t;
 typedef enum { ANEMOI_ACT_NONE = 0, ANEMOI_ACT_GELU = 1 } anemoi_act_t;
@@ -136,6 +136,12 @@ int anemoi_cond_layernorm_bwd(const void* x, int64_t ldx, const void* scale, int
  * minimum), 5 / 6 (Leaky)HardtanhBounding (min, max), 7 / 8 (Leaky)FractionBounding (min, max; times column ``total``). */
 int anemoi_bound_columns(void* x, int64_t ldx, int32_t n_rows, int32_t n_cols, const int32_t* ops, const float* params,
                          int32_t n_ops, anemoi_dtype_t dtype, void* stream);
+
+/* Input assembly at the model edge for batch = ensemble = 1 (models/encoder_processor_decoder.py:98-143): out[n] = [x[0, n, :] | ... |
+ * x[T-1, n, :] | attrs[n, :] | zeros up to W], x time slices ld_t elements apart, rows ldx apart.  Replaces the permute-copy, the cat
+ * with the node attributes and the zero padding of the embedding GEMMs' K dimension. */
+int anemoi_assemble_input(const void* x, int64_t ld_t, int64_t ldx, int32_t T_steps, int32_t V, const void* attrs, int64_t lda, int32_t A,
+                          void* out, int64_t ldo, int32_t W, int32_t n_rows, anemoi_dtype_t dtype, void* stream);
 
 /* Output assembly at the model edge for batch = ensemble = output steps = 1 (models/encoder_processor_decoder.py:145-163):
  * out[n, v] = x_out[n, v] + x_skip[n, col_map[v]] where col_map[v] >= 0 (the SkipConnection residual on the prognostic

@@ -409,3 +409,17 @@ def test_assemble_output_residual_columns(ops, dtype):
     ref = x_out.clone()  # the reference adds in the output dtype: cast(x_out) + skip, rounded once more
     ref[:, picks] = (x_out[:, picks].float() + x_skip[:, col_map[picks].long()].float()).to(dtype)
     assert got.dtype == dtype and torch.equal(got.cpu(), ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("T,N,V,A,W", [(2, 1000, 84, 12, 192), (2, 333, 84, 12, 180), (3, 257, 7, 5, 32), (1, 64, 4, 0, 8)])
+def test_assemble_input_matches_permute_and_cat(ops, dtype, T, N, V, A, W):
+    """[x[0] | ... | x[T-1] | attrs | zeros] per node == the reference's "(batch ensemble grid) (time vars)" rearrangement + cat
+    (encoder_processor_decoder.py:98-143), bit-exact (pure data movement), with 8-byte and scalar paths."""
+    g = torch.Generator().manual_seed(T * N + V)
+    x5 = torch.randn(1, T, 1, N, V, generator=g).to(dtype)
+    attrs = torch.randn(N, A, generator=g).to(dtype) if A else None
+    flat = x5.permute(0, 2, 3, 1, 4).reshape(N, T * V)
+    ref = torch.cat([flat] + ([attrs] if A else []) + [torch.zeros(N, W - T * V - A, dtype=dtype)], 1)
+    got = ops.assemble_input(x5.to(DEV)[0, :, 0], None if attrs is None else attrs.to(DEV), W)
+    assert got.shape == (N, W) and torch.equal(got.cpu(), ref)
