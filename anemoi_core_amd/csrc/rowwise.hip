@@ -256,16 +256,22 @@ __global__ void bound_columns_kernel(T* __restrict__ x, int64_t ldx, int n_rows,
 // Output assembly at the model edge (reference models/encoder_processor_decoder.py:145-163 for batch = ensemble = time = 1):
 // out[n, v] = x_out[n, v] + (col_map[v] >= 0 ? x_skip[n, col_map[v]] : 0) - the residual (SkipConnection) added onto the
 // prognostic columns - in one pass instead of clone + index_select + index_add_.
-template <typename T>
+template <typename T, int Q>
 __global__ void assemble_output_kernel(const T* __restrict__ x_out, int64_t ldx, const T* __restrict__ skip, int64_t lds,
                                        const int32_t* __restrict__ col_map, T* __restrict__ out, int64_t ldo, int n_rows, int n_cols) {
+  const int per_row = n_cols / Q;  // Q columns per thread (8-byte moves for 16-bit types when the widths / strides allow)
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (int64_t)n_rows * n_cols) return;
-  const int n = (int)(i / n_cols), v = (int)(i % n_cols);
-  float val = to_float(x_out[(int64_t)n * ldx + v]);
-  const int m = col_map[v];
-  if (m >= 0) val = to_float(from_float<T>(val)) + to_float(skip[(int64_t)n * lds + m]);
-  out[(int64_t)n * ldo + v] = from_float<T>(val);
+  if (i >= (int64_t)n_rows * per_row) return;
+  const int n = (int)(i / per_row), v0 = (int)(i % per_row) * Q;
+  Vec<T, Q> a = *reinterpret_cast<const Vec<T, Q>*>(x_out + (int64_t)n * ldx + v0), o;
+#pragma unroll
+  for (int j = 0; j < Q; ++j) {
+    float val = to_float(a.v[j]);
+    const int m = col_map[v0 + j];
+    if (m >= 0) val = to_float(from_float<T>(val)) + to_float(skip[(int64_t)n * lds + m]);
+    o.v[j] = from_float<T>(val);
+  }
+  *reinterpret_cast<Vec<T, Q>*>(out + (int64_t)n * ldo + v0) = o;
 }
 
 // Input assembly at the model edge for batch = ensemble = 1 (reference models/encoder_processor_decoder.py:98-143,
@@ -483,15 +489,22 @@ extern "C" int anemoi_assemble_output(const void* x_out, int64_t ldx, const void
   ANEMOI_REQUIRE(n_rows >= 0 && n_cols > 0 && ldx >= n_cols && ldo >= n_cols, "assemble_output: bad sizes");
   if (n_rows == 0) return ANEMOI_OK;
   ANEMOI_REQUIRE(x_out && x_skip && col_map && out, "assemble_output: null pointer");
-  const int64_t n = (int64_t)n_rows * n_cols;
+  const size_t es = dtype == ANEMOI_F32 ? 4 : 2;
+  const bool q4 = n_cols % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && reinterpret_cast<uintptr_t>(x_out) % (4 * es) == 0 &&
+                  reinterpret_cast<uintptr_t>(out) % (4 * es) == 0;
+  const int64_t n = (int64_t)n_rows * (n_cols / (q4 ? 4 : 1));
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);
   hipStream_t st = as_stream(stream);
+#define AO_LAUNCH(TT, QQ)                                                                                                              \
+  hipLaunchKernelGGL((assemble_output_kernel<TT, QQ>), grid, block, 0, st, (const TT*)x_out, ldx, (const TT*)x_skip, lds, col_map, (TT*)out, \
+                     ldo, n_rows, n_cols)
   switch (dtype) {
-    case ANEMOI_F32: hipLaunchKernelGGL((assemble_output_kernel<float>), grid, block, 0, st, (const float*)x_out, ldx, (const float*)x_skip, lds, col_map, (float*)out, ldo, n_rows, n_cols); break;
-    case ANEMOI_BF16: hipLaunchKernelGGL((assemble_output_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)x_out, ldx, (const bf16_t*)x_skip, lds, col_map, (bf16_t*)out, ldo, n_rows, n_cols); break;
-    case ANEMOI_F16: hipLaunchKernelGGL((assemble_output_kernel<f16_t>), grid, block, 0, st, (const f16_t*)x_out, ldx, (const f16_t*)x_skip, lds, col_map, (f16_t*)out, ldo, n_rows, n_cols); break;
+    case ANEMOI_F32: if (q4) AO_LAUNCH(float, 4); else AO_LAUNCH(float, 1); break;
+    case ANEMOI_BF16: if (q4) AO_LAUNCH(bf16_t, 4); else AO_LAUNCH(bf16_t, 1); break;
+    case ANEMOI_F16: if (q4) AO_LAUNCH(f16_t, 4); else AO_LAUNCH(f16_t, 1); break;
     default: set_error("unknown dtype"); return ANEMOI_E_INVALID;
   }
+#undef AO_LAUNCH
   return check_launch("assemble_output_kernel");
 }
 

@@ -394,11 +394,12 @@ def test_wgrad_transpose_read_kernel(n, o, i, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
-def test_assemble_output_residual_columns(ops, dtype):
+@pytest.mark.parametrize("V_out", [37, 84])  # scalar path / four columns per thread
+def test_assemble_output_residual_columns(ops, dtype, V_out):
     """out[n, v] = x_out[n, v] + x_skip[n, col_map[v]] where col_map[v] >= 0 (reference _assemble_output: index_add_ of the
     skip connection onto the prognostic columns, encoder_processor_decoder.py:145-163); x_skip may be a row-strided view."""
     g = torch.Generator().manual_seed(3)
-    N, V_out, V_in = 1000, 37, 53
+    N, V_in = 1000, 53
     x_out = torch.randn(N, V_out, generator=g).to(dtype)
     wide = torch.randn(N, V_in + 5, generator=g).to(dtype)
     x_skip = wide[:, 2:2 + V_in]
