@@ -9,7 +9,7 @@ import ctypes as C
 import os
 import threading
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libanemoi_hip.so")
 
 F32, BF16, F16 = 0, 1, 2
@@ -31,6 +31,7 @@ SIGNATURES = {
     "anemoi_reduce_workspace_bytes": ([_i32], _i64),
     "anemoi_layernorm_bwd": ([_p, _i64, _p, _p, _i64, _p, _i64, _p, _p, _p, _i32, _i32, _f, C.c_int, _p], C.c_int),
     "anemoi_colsum": ([_p, _i64, _p, _p, _i32, _i32, C.c_int, _p], C.c_int),
+    "anemoi_gelu_fwd": ([_p, _i64, _p, _i64, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_gelu_bwd": ([_p, _i64, _p, _i64, _p, _i64, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_cond_layernorm_bwd": ([_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i32, _i32, _f, C.c_int, _p], C.c_int),
     "anemoi_cond_layernorm_fwd": ([_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i32, _i32, _f, C.c_int, _p], C.c_int),

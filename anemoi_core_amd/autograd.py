@@ -180,6 +180,21 @@ class GluFunction(torch.autograd.Function):
         return ops.glu_backward(gv, d_out.contiguous(), ctx.kind), None
 
 
+class GeluFunction(torch.autograd.Function):
+    """Stand-alone exact GELU (layer_kernels ``Activation``): forward ``anemoi_gelu_fwd``, backward ``anemoi_gelu_bwd``."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor):
+        ctx.save_for_backward(x)
+        return ops._gelu_fwd(x)
+
+    @staticmethod
+    def backward(ctx, d_y: Tensor):
+        (x,) = ctx.saved_tensors
+        D = x.shape[-1]
+        return ops.gelu_backward(x.reshape(-1, D), d_y.reshape(-1, D).contiguous()).view(x.shape)
+
+
 class GatherRowsFunction(torch.autograd.Function):
     """out[i] = x[idx[i]]; backward: d_x[r] = sum of d_out rows with idx == r (fp32 accumulation)."""
 

@@ -127,4 +127,18 @@ __device__ __forceinline__ float gelu_fast(float x) {
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// hipFuncSetAttribute (raised dynamic-LDS limit) is a per-DEVICE setting: one flag per device id, so that a second GPU
+// used from the same process gets the limit as well.
+struct PerDeviceOnce {
+  bool done[64] = {};
+  bool first() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    d &= 63;
+    if (done[d]) return false;
+    done[d] = true;
+    return true;
+  }
+};
+
 }  // namespace anemoi

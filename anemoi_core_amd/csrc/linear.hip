@@ -1123,11 +1123,10 @@ template <typename T, int EPI, int WM, bool PP, int WN = 2, int ST = 3>
 static int launch_persistent_wm(const LinArgs& a, hipStream_t st) {
   // (64*WM) x (64*WN) tile, WM*WN waves, ST-stage ring (3 stages = 144 KiB at 4 x 2: one workgroup per CU)
   constexpr int smem_bytes = ST * (64 * WM + 64 * WN) * BK * 2 + 1024;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_mfma_persistent_kernel<T, WM, WN, ST, EPI, PP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
-    attr_set = true;
   }
   const int tm = (a.n_rows + 64 * WM - 1) / (64 * WM), tn = (a.O + 64 * WN - 1) / (64 * WN);
   const int nt = tm * tn * a.splits;
@@ -1141,11 +1140,10 @@ static int launch_persistent_wm(const LinArgs& a, hipStream_t st) {
 template <typename T, int EPI>
 static int launch_splitwave(const LinArgs& a, hipStream_t st) {
   constexpr int smem_bytes = kSStages * kSStage;  // 144 KiB (the reduction / epilogue staging reuses it)
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_mfma_splitwave_kernel<T, EPI>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
-    attr_set = true;
   }
   const int tm = (a.n_rows + SM - 1) / SM, tn = (a.O + SN - 1) / SN;
   hipLaunchKernelGGL((linear_mfma_splitwave_kernel<T, EPI>), dim3(tm * tn), dim3(512), smem_bytes, st, a, tn);
@@ -1156,11 +1154,10 @@ template <typename T, int EPI, int MI>
 static int launch_bigtile(const LinArgs& a, hipStream_t st) {
   constexpr int TBM = 32 * MI, TBN = 256;
   constexpr int smem_bytes = 2 * (TBM + TBN) * BK * 2 + 1024 + ((EPI & EPI_LNFOLD) ? 2 * TBM * 2 * 4 : 0);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_mfma_bigtile_kernel<T, MI, EPI>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
-    attr_set = true;
   }
   const int tm = (a.n_rows + TBM - 1) / TBM, tn = (a.O + TBN - 1) / TBN;
   const int nt = tm * tn;
@@ -1243,10 +1240,9 @@ static int launch_mfma(const LinArgs& a, hipStream_t st) {
   }
   const int tiles_m = (a.n_rows + BM - 1) / BM, tiles_n = (a.O + BN - 1) / BN;
   const int num_tiles = tiles_m * tiles_n;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_mfma_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kTileBytes);
-    attr_set = true;
   }
   hipLaunchKernelGGL((linear_mfma_kernel<T>), dim3(num_tiles), dim3(256), 4 * kTileBytes, st, a, tiles_n, num_tiles);
   return check_launch("linear_mfma_kernel");

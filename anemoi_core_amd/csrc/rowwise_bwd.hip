@@ -245,6 +245,21 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ pre
   store_vec<T, VEC>(dpre + (int64_t)r * lddp + c, o);
 }
 
+// y = gelu(x), exact erf form (torch.nn.GELU default): the stand-alone activation of the layer_kernels plug-in point
+// (kernels.GELU inside an unmodified reference MLP: layers/mlp.py:158-169).  The fused blocks never launch it.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy, int n_rows, int D) {
+  const int per_row = D / VEC;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)n_rows * per_row) return;
+  const int r = (int)(i / per_row), c = (int)(i % per_row) * VEC;
+  float v[VEC];
+  load_vec<T, VEC>(x + (int64_t)r * ldx + c, v);
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) v[j] = gelu_erf(v[j]);
+  store_vec<T, VEC>(y + (int64_t)r * ldy + c, v);
+}
+
 // out[r] = sum_{i in [ptr[r], ptr[r+1])} x[ids ? ids[i] : i]   (fp32 accumulation, one wave per output row).
 // ids == NULL: contiguous segments (edges sorted by destination); ids = the reverse-CSR edge list: rows grouped by source.
 // Adjoint of the row gathers in the GraphConv GEMM epilogue and of gather_rows (deterministic, no atomics).
@@ -440,6 +455,23 @@ int launch_gelu_bwd(const void* pre, int64_t ldp, const void* dy, int64_t lddy, 
 }
 
 template <typename T>
+int launch_gelu_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, int n_rows, int D, hipStream_t st) {
+  const int vec = pick_vec<T>(D, {ldx, ldy}, {x, y});
+  const int64_t n = (int64_t)n_rows * (D / vec);
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+#define GF_CASE(V)                                                                                            \
+  case V:                                                                                                     \
+    hipLaunchKernelGGL((gelu_fwd_kernel<T, V>), grid, block, 0, st, (const T*)x, ldx, (T*)y, ldy, n_rows, D); \
+    break;
+  switch (vec) {
+    GF_CASE(1) GF_CASE(2) GF_CASE(4) GF_CASE(8)
+    default: set_error("gelu_fwd: bad vector width"); return ANEMOI_E_INVALID;
+  }
+#undef GF_CASE
+  return check_launch("gelu_fwd_kernel");
+}
+
+template <typename T>
 int launch_segment_sum(const void* x, int64_t ldx, const int32_t* ptr, const int32_t* ids, void* out, int64_t ldo, int n_out, int D, hipStream_t st) {
   const int vec = pick_vec<T>(D, {ldx, ldo}, {x, out});
   const dim3 grid((n_out + kWaves - 1) / kWaves), block(64 * kWaves);
@@ -554,6 +586,19 @@ extern "C" int anemoi_gelu_bwd(const void* pre, int64_t ldp, const void* d_y, in
     case ANEMOI_F32: return launch_gelu_bwd<float>(pre, ldp, d_y, lddy, d_pre, lddp, n_rows, D, st);
     case ANEMOI_BF16: return launch_gelu_bwd<bf16_t>(pre, ldp, d_y, lddy, d_pre, lddp, n_rows, D, st);
     case ANEMOI_F16: return launch_gelu_bwd<f16_t>(pre, ldp, d_y, lddy, d_pre, lddp, n_rows, D, st);
+    default: set_error("unknown dtype"); return ANEMOI_E_INVALID;
+  }
+}
+
+extern "C" int anemoi_gelu_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, int32_t n_rows, int32_t D, anemoi_dtype_t dtype, void* stream) {
+  ANEMOI_REQUIRE(n_rows >= 0 && D > 0 && ldx >= D && ldy >= D, "gelu_fwd: bad sizes");
+  if (n_rows == 0) return ANEMOI_OK;
+  ANEMOI_REQUIRE(x && y, "gelu_fwd: null pointer");
+  hipStream_t st = as_stream(stream);
+  switch (dtype) {
+    case ANEMOI_F32: return launch_gelu_fwd<float>(x, ldx, y, ldy, n_rows, D, st);
+    case ANEMOI_BF16: return launch_gelu_fwd<bf16_t>(x, ldx, y, ldy, n_rows, D, st);
+    case ANEMOI_F16: return launch_gelu_fwd<f16_t>(x, ldx, y, ldy, n_rows, D, st);
     default: set_error("unknown dtype"); return ANEMOI_E_INVALID;
   }
 }

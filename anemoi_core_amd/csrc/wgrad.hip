@@ -265,10 +265,9 @@ hipStream_t as_hip_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 template <typename T, bool BIAS, int TKS, int STAGES>
 int launch_wgrad_cfg(const WgradArgs& a, hipStream_t st) {
   constexpr int lds = STAGES * 2 * TKS * TM * 2;
-  static const int once = [] {
-    return (int)hipFuncSetAttribute((const void*)wgrad_tn_kernel<T, BIAS, TKS, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  }();
-  (void)once;
+  static PerDeviceOnce attr_once;
+  if (attr_once.first())
+    (void)hipFuncSetAttribute((const void*)wgrad_tn_kernel<T, BIAS, TKS, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL((wgrad_tn_kernel<T, BIAS, TKS, STAGES>), dim3(a.tiles_m * a.tiles_n * a.splits), dim3(256), lds, st, a);
   return check_launch("wgrad_tn_kernel");
 }

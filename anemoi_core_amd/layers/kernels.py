@@ -81,11 +81,17 @@ def apply_layer_norm(ln: nn.Module, x: Tensor, cond: Tensor | None = None, resid
 
 
 class GELU(nn.GELU):
-    """Exact (erf) GELU marker module.  MLP / blocks fuse it into the preceding Linear's epilogue; there is no
-    stand-alone GELU launch in the product path."""
+    """Exact (erf) GELU.  This package's MLP / blocks fuse it into the preceding Linear's epilogue (no launch of its own);
+    called as a module - e.g. as ``layer_kernels.Activation`` inside the reference's own MLP (layers/mlp.py:158-169) or a
+    plain ``nn.Sequential`` - it is one row-wise HIP kernel (``anemoi_gelu_fwd`` / ``anemoi_gelu_bwd``)."""
+
+    def __init__(self, approximate: str = "none") -> None:
+        if approximate != "none":
+            raise NotImplementedError("only the exact (erf) GELU is implemented (torch.nn.GELU default, layers/utils.py:111)")
+        super().__init__(approximate="none")
 
     def forward(self, x: Tensor) -> Tensor:  # noqa: D102
-        raise NotImplementedError("GELU is fused into the preceding Linear (anemoi_core_amd.layers.mlp.MLP)")
+        return ops.gelu(x)
 
 
 class PaddedLinear:

@@ -61,7 +61,6 @@ class BaseMapper(nn.Module):
         if cpu_offload:
             raise NotImplementedError("cpu_offload is a training memory feature; not needed with 288 GB of HBM")
         self._local = _LocalGraphCache()
-        self._plan = None
         self._heads_cache = None
 
     def _local_graph(self, x, shard_info, edge_attr, edge_index, group):
@@ -90,7 +89,10 @@ class BaseMapper(nn.Module):
             n_src_total = partition.num_nodes[0]
             all_connected = src_ids.shape[0] == n_src_total
             return dict(partition=partition, dst_range=(dr.start, dr.stop), src_ids=src_ids, src_ids32=src_ids.to(torch.int32).contiguous(),
-                        edge_index=ei_local.contiguous(), edge_rows=edge_rows, all_connected=all_connected, anchors=(edge_index,))
+                        edge_index=ei_local.contiguous(), edge_rows=edge_rows, all_connected=all_connected, anchors=(edge_index,),
+                        # needed-rows exchange plans live WITH the graph they were built for (same key: edge_index, shard sizes,
+                        # world, rank): a new graph / partition / group rebuilds them instead of reusing stale send indices
+                        plans={})
 
         g = dict(self._local.get(key, build))
         g["edge_attr"] = edge_attr if g["edge_rows"] is None else edge_attr[g["edge_rows"]]
@@ -135,8 +137,8 @@ class GraphTransformerBaseMapper(BaseMapper):
             x_dst = x_dst[d0:d1]
         # source rows this rank needs
         if sharded and shard_info.src_is_sharded():
-            x_src_c, self._plan = comm.exchange_rows(x_src, g["src_ids"], shard_info.src_nodes, model_comm_group,
-                                                     gather_fn=ops.gather_rows, plan=self._plan)
+            x_src_c, g["plans"]["src"] = comm.exchange_rows(x_src, g["src_ids"], shard_info.src_nodes, model_comm_group,
+                                                            gather_fn=ops.gather_rows, plan=g["plans"].get("src"))
         elif g["all_connected"]:
             x_src_c = x_src
         else:
@@ -146,7 +148,8 @@ class GraphTransformerBaseMapper(BaseMapper):
             if sharded and not shard_info.dst_is_sharded():
                 c_dst = c_dst[d0:d1]
             if sharded and shard_info.src_is_sharded():
-                c_src, _ = comm.exchange_rows(c_src, g["src_ids"], shard_info.src_nodes, model_comm_group, gather_fn=ops.gather_rows, plan=self._plan)
+                c_src, _ = comm.exchange_rows(c_src, g["src_ids"], shard_info.src_nodes, model_comm_group, gather_fn=ops.gather_rows,
+                                              plan=g["plans"].get("src"))
             elif not g["all_connected"]:
                 c_src = ops.gather_rows(c_src, g["src_ids32"])
             kwargs["cond"] = (c_src, c_dst)
@@ -286,7 +289,8 @@ class GNNBaseMapper(BaseMapper):
         x_src_loc = x_src if src_was_sharded else comm.shard_tensor(x_src, 0, src_sizes, group)
         e_loc = self.emb_edges(g["edge_attr"])
         xs_loc, xd_loc = self.pre_process((x_src_loc, x_dst_loc))
-        xs_need, self._plan = comm.exchange_rows(xs_loc, g["src_ids"], src_sizes, group, gather_fn=ops.gather_rows, plan=self._plan)
+        pkey = ("src", tuple(src_sizes))
+        xs_need, g["plans"][pkey] = comm.exchange_rows(xs_loc, g["src_ids"], src_sizes, group, gather_fn=ops.gather_rows, plan=g["plans"].get(pkey))
         (xs_new, xd_new), _ = self.proc.forward_local(xs_need, xd_loc, xs_loc, e_loc, g["edge_index"])
         out_dst = self.post_process(xd_new)
         if not keep_x_dst_sharded:

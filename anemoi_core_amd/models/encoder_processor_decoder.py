@@ -5,7 +5,8 @@
 
 ``model_config`` is the reference's nested config (attribute dict).  ``_target_`` strings may name either this
 package's classes or the reference's ``anemoi.models.layers.*`` classes (rewritten to the MI355X implementations), so an
-existing config selects the HIP path without edits.  Residual = SkipConnection (step), boundings: ReluBounding only.
+existing config selects the HIP path without edits.  Residual = SkipConnection (step); boundings: all eight classes of
+layers/bounding.py, run as one in-place column program.
 """
 from __future__ import annotations
 
@@ -204,17 +205,20 @@ class AnemoiModelEncProcDec(nn.Module):
             x_out = ops.assemble_output(x_out, x_skip.reshape(N, -1), col_map).view(1, 1, 1, N, -1)
         else:
             x_out = x_out.view(batch_size, ensemble_size, N, self.n_step_output, -1).permute(0, 3, 1, 2, 4).to(dtype=dtype).clone()
-            x_out.index_add_(-1, out_idx, x_skip.unsqueeze(1).index_select(-1, in_idx).to(dtype))
+            # SkipConnection._expand_time (layers/residual.py:53-57): the skip is repeated over the output steps
+            skip = x_skip.unsqueeze(1).expand(-1, self.n_step_output, -1, -1, -1)
+            x_out.index_add_(-1, out_idx, skip.index_select(-1, in_idx).to(dtype))
         if len(self.boundings[ds]):  # all configured boundings as ONE in-place column program (configuration order)
             from ..layers.bounding import apply_program_torch, program_tables
 
-            prog = [op for b in self.boundings[ds] for op in b.program()]
             if torch.is_grad_enabled() and x_out.requires_grad:
-                x_out = apply_program_torch(x_out, prog)
+                x_out = apply_program_torch(x_out, [op for b in self.boundings[ds] for op in b.program()])
             else:
+                # the column program and its device tables are built ONCE per (dataset, device): program() of the normalised
+                # boundings reads a registered buffer (.tolist() = a device->host sync, illegal under hipGraph capture)
                 key = (ds, str(x_out.device))
                 if key not in self._bound_tables:
-                    self._bound_tables[key] = program_tables(prog, x_out.device)
+                    self._bound_tables[key] = program_tables([op for b in self.boundings[ds] for op in b.program()], x_out.device)
                 ops.bound_columns_(x_out, *self._bound_tables[key])
         return x_out
 

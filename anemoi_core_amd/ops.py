@@ -55,6 +55,11 @@ def _dev(*ts: Optional[Tensor]) -> None:
             dev = t.device
         elif t.device != dev:
             raise RuntimeError(f"tensors on different devices: {dev} vs {t.device}")
+    # kernels are enqueued on the CURRENT device's current stream (_stream): tensors of another GPU would be launched on the
+    # wrong device / stream.  Fail loudly instead (multi-GPU processes: torch.cuda.set_device / `with torch.cuda.device(d)`).
+    if dev is not None and dev.index is not None and dev.index != torch.cuda.current_device():
+        raise RuntimeError(f"tensors live on {dev} but the current device is cuda:{torch.cuda.current_device()}; make {dev} current "
+                           "(torch.cuda.set_device or `with torch.cuda.device(...)`) before calling anemoi_core_amd ops")
 
 
 def _rows(t: Optional[Tensor], name: str, dtype=None) -> tuple[int, int]:
@@ -485,6 +490,28 @@ def colsum(x: Tensor) -> Tensor:
     p, ld = _rows(x, "x")
     _lib.check(_lib.load().anemoi_colsum(p, ld, out.data_ptr(), _reduce_workspace(D, x.device).data_ptr(), N, D, _dt(x), _stream()), "colsum")
     return out
+
+
+def gelu(x: Tensor) -> Tensor:
+    """Exact (erf) GELU of a [..., D] tensor as ONE stand-alone kernel (the layer_kernels ``Activation`` plug-in; the fused
+    blocks apply GELU in a GEMM epilogue instead).  Differentiable (backward: ``gelu_backward``)."""
+    if _needs_grad(x):
+        from .autograd import GeluFunction
+
+        return GeluFunction.apply(x)
+    return _gelu_fwd(x)
+
+
+def _gelu_fwd(x: Tensor) -> Tensor:
+    _dev(x)
+    D = x.shape[-1]
+    x2 = x.reshape(-1, D)
+    if x2.shape[1] > 1 and x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    y = torch.empty((x2.shape[0], D), dtype=x.dtype, device=x.device)
+    p, ld = _rows(x2, "x")
+    _lib.check(_lib.load().anemoi_gelu_fwd(p, ld, y.data_ptr(), D, x2.shape[0], D, _dt(x), _stream()), "gelu_fwd")
+    return y.view(x.shape)
 
 
 def gelu_backward(pre: Tensor, d_y: Tensor) -> Tensor:

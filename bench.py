@@ -1,22 +1,31 @@
 #!/usr/bin/env python
-"""Benchmark of the hot path: AnemoiModelEncProcDec forward on the O96 GraphTransformer configuration.
+"""Benchmark of the hot path: AnemoiModelEncProcDec forward (BASELINE.json configurations).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config o96|o96-res6|n320|gnn]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One "step" = one full forward (encoder -> 16 processor layers -> decoder) over one synthetic ERA5-shaped input that
-is already resident in HBM.  metric = forward nodes*channels / s = N_data * num_channels / t_forward (BASELINE.json,
-SURVEY.md §8d).  At N > 1 the hidden mesh is sharded across the ranks (halo all-to-all per processor layer, needed-rows
-exchange in the decoder): the total work is fixed -> "scaling": "strong".
+One "step" = one full forward (encoder -> processor layers -> decoder) over one synthetic ERA5-shaped input that is already
+resident in HBM.  metric = forward nodes*channels / s = N_data * num_channels / t_forward (BASELINE.json).
+``--gpus N`` with N > 1 and no torchrun environment launches the N ranks itself (one process per GPU, RCCL).  At N > 1 the
+hidden mesh is sharded across the ranks (halo all-to-all per processor layer, needed-rows exchange in the decoder): the
+total work is fixed -> "scaling": "strong".
 
-Rank 0 prints ONE JSON line.  Extra objects: "roofline" (dominant kernel, measured live with HIP events on the launch
-stream) and, at N = 1, "cpu_baseline" (the oracle timed on the host cores on a bounded sample) and "kernels".
+Rank 0 prints ONE JSON line.  Extra objects: "roofline" (dominant kernel family, measured live with HIP events on the launch
+stream), "kernel_families" (algorithmic flops AND bytes per family), at N = 1 "cpu_baseline" (the oracle timed on the host
+cores on a bounded sample) and "kernels"; at N > 1 "rccl" (what the exchange carries).
+
+Configurations (BASELINE.json `configs`): o96 = config 2 (the headline; default), o96-res6 = its stated res-6 variant,
+n320 = config 4 (mapper stress), gnn = config 5 (GraphConv processor on O96).
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -28,25 +37,52 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 peak
 
+CONFIGS = {
+    "o96": dict(data_grid="o96", hidden_res=5, kind="gt"),
+    "o96-res6": dict(data_grid="o96", hidden_res=6, kind="gt"),
+    "n320": dict(data_grid="n320", hidden_res=6, kind="gt"),
+    "gnn": dict(data_grid="o96", hidden_res=5, kind="gnn"),
+}
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--data-grid", default="o96")
-    ap.add_argument("--hidden-res", type=int, default=5)
+    ap.add_argument("--config", default="o96", choices=sorted(CONFIGS), help="BASELINE.json configuration (default: the headline)")
+    ap.add_argument("--data-grid", default=None)
+    ap.add_argument("--hidden-res", type=int, default=None)
+    ap.add_argument("--kind", default=None, choices=["gt", "gnn"])
     ap.add_argument("--layers", type=int, default=16)
     ap.add_argument("--channels", type=int, default=512)
     ap.add_argument("--heads", type=int, default=16)
     ap.add_argument("--vars", type=int, default=84, help="variables per data node (ERA5-like)")
-    ap.add_argument("--kind", default="gt", choices=["gt", "gnn"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-graph", action="store_true", help="do not capture the forward in a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--kernels-only", action="store_true", help="developer aid: only the per-kernel table of one processor layer")
-    return ap.parse_args()
+    args = ap.parse_args()
+    for k, v in CONFIGS[args.config].items():
+        if getattr(args, k) is None:
+            setattr(args, k, v)
+    return args
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` outside torchrun: start the N ranks (one process per GPU) under torch.distributed.run on this
+    node and hand their output through (rank 0 prints the JSON line).  Mirrors what the reference's strategy does when it
+    hands every rank its process group (training/src/anemoi/training/distributed/strategy.py:172-230)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (the host driver supports nothing else)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
 
 
 def build(args, device):
@@ -77,13 +113,12 @@ def kernel_cases(model, g, args, dtype, device):
     ea, ei, _ = model.processor_graph_provider.get_edges(batch_size=1)
     csc = get_csc(ei, (N, N), True)
     feat = get_edge_features(ea, None)
-    fe = ea.shape[1]
     x = torch.randn(N, D, device=device).to(dtype)
     w4, b4 = blk._fused.get("qkvs", [blk.lin_query, blk.lin_key, blk.lin_value, blk.lin_self])
     qkvs = ops.linear(x, w4, b4)
     hid = blk.node_dst_mlp.mlp[0].out_features
     h = torch.randn(N, hid, device=device).to(dtype)
-    es = dtype.itemsize if hasattr(dtype, "itemsize") else torch.tensor([], dtype=dtype).element_size()
+    es = torch.tensor([], dtype=dtype).element_size()
     ln = blk.layer_norm_attention
     cases = {
         "layernorm": (lambda: ops.layer_norm(x, ln.weight, ln.bias, ln.eps), "hbm", 2 * N * D * es),
@@ -135,11 +170,25 @@ def time_kernels(model, g, args, dtype, device):
     return out
 
 
-def profile_forward(step, dtype):
+def _backed_up_queue(ms: float = 12.0):
+    """Back the queue up with a SLEEP kernel (no power draw, unlike a GEMM burst, which lowers the clocks for ms afterwards -
+    tools/event_probe.py) so that the host is done enqueueing before the first kernel starts: every event pair then brackets
+    exactly one kernel (+ ~2.5 us of marker cost), never a wait for the host."""
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    torch.cuda._sleep(1_000_000)
+    e1.record()
+    torch.cuda.synchronize()
+    per_ms = 1_000_000 / max(e0.elapsed_time(e1), 1e-3)
+    torch.cuda._sleep(int(per_ms * ms))
+
+
+def profile_forward(step, dtype, host_ms: float = 12.0):
     """One extra EAGER forward with a HIP-event pair (on the launch stream) around every kernel entry point: per kernel
-    family the call count, summed device time and summed ALGORITHMIC work (flops for the GEMMs, bytes for the rest).
-    These are the figures the `roofline` object is built from; profiles/ holds the rocprofv3 --kernel-trace --stats
-    summary of the same command for cross-checking."""
+    family the call count, summed device time and summed ALGORITHMIC work - flops (GEMMs) and compulsory bytes (every
+    family: operands + outputs once).  These are the figures the `roofline` object is built from; profiles/ holds the
+    rocprofv3 --kernel-trace --stats summary of the same command for cross-checking."""
     from anemoi_core_amd import ops
 
     es = torch.tensor([], dtype=dtype).element_size()
@@ -151,59 +200,64 @@ def profile_forward(step, dtype):
             e0.record()
             out = fn(*a, **kw)
             e1.record()
-            rec.append((name, work(out, *a, **kw), e0, e1))
+            rec.append((work(out, *a, **kw), e0, e1))
             return out
         return inner
 
     def lin_work(out, x, w, bias=None, **kw):
-        K = w.shape[1]
-        fam = "linear_mfma_*" if (x.dtype != torch.float32 and x.shape[1] % 8 == 0 and (kw.get("x2") is None or kw["x2"].shape[1] % 8 == 0) and w.shape[0] % 4 == 0) else "linear_generic_kernel"
-        return fam, 2.0 * x.shape[0] * K * w.shape[0], "flop"
+        N, K, O = x.shape[0], w.shape[1], w.shape[0]
+        mfma = x.dtype != torch.float32 and x.shape[1] % 8 == 0 and (kw.get("x2") is None or kw["x2"].shape[1] % 8 == 0) and O % 4 == 0
+        extra = sum(1 for k in ("residual", "g1", "g2") if kw.get(k) is not None)
+        byts = es * (N * K + O * K + N * O * (1 + extra)) + 4 * N * sum(1 for k in ("idx1", "idx2") if kw.get(k) is not None)
+        return ("linear_mfma_*" if mfma else "linear_generic_kernel"), 2.0 * N * K * O, byts
 
     def attn_work(out, q, k, v, feat, wp, csc, H, **kw):
         D = q.shape[1]
         # compulsory traffic: q, out, self-term (3 N_dst D) + k, v (2 N_src D) + edge features + indices (lin_edge fused)
-        return "gt_attn_fused_edge_fwd_kernel", es * (3 * csc.n_dst * D + 2 * csc.n_src * D) + 4 * csc.num_edges * feat.shape[1] + 4 * (csc.num_edges + csc.n_dst + 1), "byte"
+        return "gt_attn_fused_edge_fwd_kernel", 0.0, es * (3 * csc.n_dst * D + 2 * csc.n_src * D) + 4 * csc.num_edges * feat.shape[1] + 4 * (csc.num_edges + csc.n_dst + 1)
 
     def ln_work(out, x, *a, **kw):
-        return "layernorm_fwd_kernel", 2 * x.numel() * es, "byte"
+        return "layernorm_fwd_kernel", 0.0, 2 * x.numel() * es + (x.numel() * es if kw.get("residual") is not None else 0)
 
     def gemm_work(out, x, w, *a, **kw):  # the LayerNorm-fold GEMMs (statistics producer / folding consumer)
-        return "linear_mfma_*", 2.0 * x.shape[0] * w.shape[1] * w.shape[0], "flop"
+        N, K, O = x.shape[0], w.shape[1], w.shape[0]
+        return "linear_mfma_*", 2.0 * N * K * O, es * (N * K + O * K + N * O)
 
-    saved = {n: getattr(ops, n) for n in ("linear", "gt_attention_fused_edge", "layer_norm", "linear_with_row_stats", "linear_ln_folded")}
-    ops.linear_with_row_stats = wrap("linear_stats", saved["linear_with_row_stats"], gemm_work)
-    ops.linear_ln_folded = wrap("linear_lnfold", saved["linear_ln_folded"], gemm_work)
-    ops.linear = wrap("linear", saved["linear"], lin_work)
-    ops.gt_attention_fused_edge = wrap("attn", saved["gt_attention_fused_edge"], attn_work)
-    ops.layer_norm = wrap("ln", saved["layer_norm"], ln_work)
+    def segsum_work(out, z, e_old, gamma, beta, eps, csc):  # read z, e_old; write e_new, agg (2(3 M D + N D))
+        M, D = z.shape
+        return "edge_ln_res_segsum_kernel", 0.0, es * (3 * M * D + csc.n_dst * D) + 4 * (csc.n_dst + 1)
+
+    def rows_work(name):
+        def f(out, a, *rest, **kw):
+            o = out if isinstance(out, torch.Tensor) else out[0]
+            return name, 0.0, 2 * o.numel() * es
+        return f
+
+    table = {"linear": ("linear", lin_work), "gt_attention_fused_edge": ("attn", attn_work), "layer_norm": ("ln", ln_work),
+             "linear_with_row_stats": ("linear_stats", gemm_work), "linear_ln_folded": ("linear_lnfold", gemm_work),
+             "edge_ln_residual_segment_sum": ("segsum", segsum_work), "gather_rows": ("gather", rows_work("gather_rows_kernel")),
+             "gather_add_rows": ("gather_add", rows_work("gather_add_rows_kernel"))}
+    saved = {n: getattr(ops, n) for n in table}
+    for n, (tag, work) in table.items():
+        setattr(ops, n, wrap(tag, saved[n], work))
     try:
-        torch.cuda.synchronize()
-        # Back the queue up with a SLEEP kernel (no power draw, unlike a GEMM burst, which lowers the clocks for ms
-        # afterwards - tools/event_probe.py) so that the host is done enqueueing before the first kernel starts: every
-        # event pair then brackets exactly one kernel (+ ~2.5 us of marker cost), never a wait for the host.
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        torch.cuda._sleep(1_000_000)
-        e1.record()
-        torch.cuda.synchronize()
-        per_ms = 1_000_000 / max(e0.elapsed_time(e1), 1e-3)
-        torch.cuda._sleep(int(per_ms * 12.0))  # ~12 ms: the eager forward with its ~330 event records enqueues in ~5 ms
+        _backed_up_queue(host_ms)
         step()
         torch.cuda.synchronize()
     finally:
         for n, f in saved.items():
             setattr(ops, n, f)
     fam = {}
-    for _, (name, work, unit), e0, e1 in rec:
-        d = fam.setdefault(name, {"calls": 0, "us": 0.0, "work": 0.0, "unit": unit})
+    for (name, flops, byts), e0, e1 in rec:
+        d = fam.setdefault(name, {"calls": 0, "us": 0.0, "flops": 0.0, "bytes": 0.0})
         d["calls"] += 1
         d["us"] += e0.elapsed_time(e1) * 1e3
-        d["work"] += work
+        d["flops"] += flops
+        d["bytes"] += byts
     return fam
 
 
-def component_times(model, step, n_data, n_hidden, channels, layers):
+def component_times(model, step, n_data, n_hidden, channels, layers, host_ms: float = 12.0):
     """Device time of encoder / processor / decoder in one more eager forward (events on forward hooks, queue backed up by a
     sleep kernel as in profile_forward) and the per-component N*D/t of SURVEY.md 8(d)."""
     marks, handles = {}, []
@@ -227,13 +281,7 @@ def component_times(model, step, n_data, n_hidden, channels, layers):
         handles.append(m.register_forward_pre_hook(pre(n), with_kwargs=True))
         handles.append(m.register_forward_hook(post(n), with_kwargs=True))
     try:
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        torch.cuda._sleep(1_000_000)
-        e1.record()
-        torch.cuda.synchronize()
-        torch.cuda._sleep(int(1_000_000 / max(e0.elapsed_time(e1), 1e-3) * 12.0))
+        _backed_up_queue(host_ms)
         step()
         torch.cuda.synchronize()
     finally:
@@ -244,6 +292,13 @@ def component_times(model, step, n_data, n_hidden, channels, layers):
             "processor_nodes_channels_layers_per_s": n_hidden * channels * layers / (ms["processor"] * 1e-3),
             "encoder_nodes_channels_per_s": n_data * channels / (ms["encoder"] * 1e-3),
             "decoder_nodes_channels_per_s": n_data * channels / (ms["decoder"] * 1e-3)}
+
+
+def _oracle_inputs(O, p, g, x, conv=torch.from_numpy):
+    B, T, E, N, V = x.shape
+    x_data = torch.cat([x[0, :, 0].permute(1, 0, 2).reshape(N, T * V), O.node_attributes(p, "data")], -1)
+    x_hid = O.node_attributes(p, "hidden")
+    return x_data, x_hid
 
 
 def gpu_eager_baseline(model_fp32_params, cfg, g, x, device, steps=5):
@@ -263,15 +318,17 @@ def gpu_eager_baseline(model_fp32_params, cfg, g, x, device, steps=5):
     enc_ei, proc_ei, dec_ei = t(g.enc_edge_index), t(g.proc_edge_index), t(g.dec_edge_index)
 
     def fwd():
-        B, T, E, N, V = xd.shape
-        x_data = torch.cat([xd[0, :, 0].permute(1, 0, 2).reshape(N, T * V), O.node_attributes(p, "data")], -1)
-        x_hid = O.node_attributes(p, "hidden")
+        x_data, x_hid = _oracle_inputs(O, p, g, xd)
         enc_ea = O.provider_edge_attr(p, "encoder_graph_provider.data", tf(g.enc_edge_attr))
         proc_ea = O.provider_edge_attr(p, "processor_graph_provider", tf(g.proc_edge_attr))
         dec_ea = O.provider_edge_attr(p, "decoder_graph_provider.data", tf(g.dec_edge_attr))
-        lat = O.gt_forward_mapper(p, "encoder.data", x_data, x_hid, enc_ea, enc_ei, H)
-        h = O.gt_processor(p, "processor", lat, proc_ea, proc_ei, L, H) + lat
-        return O.gt_backward_mapper(p, "decoder.data", h, x_data, dec_ea, dec_ei, H)
+        if cfg["kind"] == "gt":
+            lat = O.gt_forward_mapper(p, "encoder.data", x_data, x_hid, enc_ea, enc_ei, H)
+            h = O.gt_processor(p, "processor", lat, proc_ea, proc_ei, L, H) + lat
+            return O.gt_backward_mapper(p, "decoder.data", h, x_data, dec_ea, dec_ei, H)
+        xs, lat = O.gnn_forward_mapper(p, "encoder.data", x_data, x_hid, enc_ea, enc_ei)
+        h = O.gnn_processor(p, "processor", lat, proc_ea, proc_ei, L) + lat
+        return O.gnn_backward_mapper(p, "decoder.data", h, xs, dec_ea, dec_ei)
 
     with torch.inference_mode():
         for _ in range(2):
@@ -286,29 +343,38 @@ def gpu_eager_baseline(model_fp32_params, cfg, g, x, device, steps=5):
             "kind": "eager PyTorch-ROCm restatement of the reference's pyg op sequence (bf16, torch/rocBLAS kernels, no hipGraph)"}
 
 
-def cpu_baseline(model_fp32_params, cfg, g, x, layers_sample):
-    """The oracle (CPU restatement of the reference, parity-pinned) on the host cores: encoder + ``layers_sample``
-    processor layers + decoder are timed once each, the full forward is t_enc + L * t_layer + t_dec."""
+def cpu_baseline(model_fp32_params, cfg, g, x, budget_s: float = 30.0):
+    """The oracle (CPU restatement of the reference, parity-pinned) on the host cores, fp32, same graph / inputs / weights.
+    A *unit* = encoder + 2 processor layers + decoder; one un-timed warm-up unit, then as many timed units as fit the budget
+    (>= 3 whenever one unit takes < budget/4; the median is used), the full forward is enc + L * layer + dec."""
     from oracle import gt_oracle as O
 
     ncpu = os.cpu_count() or 1
     p = model_fp32_params
-    H, L = cfg["num_heads"], cfg["num_layers"]
+    H, L, gt = cfg["num_heads"], cfg["num_layers"], cfg["kind"] == "gt"
     t = torch.from_numpy
+    ls = min(2, L)
     with torch.no_grad():
-        B, T, E, N, V = x.shape
-        x_data = torch.cat([x[0, :, 0].permute(1, 0, 2).reshape(N, T * V), O.node_attributes(p, "data")], -1)
-        x_hid = O.node_attributes(p, "hidden")
+        x_data, x_hid = _oracle_inputs(O, p, g, x)
         enc_ea = O.provider_edge_attr(p, "encoder_graph_provider.data", t(g.enc_edge_attr))
         proc_ea = O.provider_edge_attr(p, "processor_graph_provider", t(g.proc_edge_attr))
         dec_ea = O.provider_edge_attr(p, "decoder_graph_provider.data", t(g.dec_edge_attr))
+        enc_ei, proc_ei, dec_ei = t(g.enc_edge_index), t(g.proc_edge_index), t(g.dec_edge_index)
+
+        def layer(i, h, e):
+            if gt:
+                return O.gt_processor_block(p, f"processor.proc.{i}", h, e, proc_ei, H), e
+            return O.gconv_processor_block(p, f"processor.proc.{i}", h, e, proc_ei)
+
         # pick the thread count that serves the CPU path best (eager torch ops on [M, H, C] temporaries do not scale
         # to hundreds of threads): one processor layer is timed at each candidate, the fastest is used throughout
+        h0 = x_hid.new_zeros(x_hid.shape[0], cfg["num_channels"]).normal_()
+        e1 = layer(0, h0, proc_ea)[1] if not gt else proc_ea  # GNN layers >= 1 take the embedded edges
         best = None
         for th in sorted({c for c in (8, 16, 32, 64, ncpu) if c <= ncpu}):
             torch.set_num_threads(th)
             t0 = time.perf_counter()
-            O.gt_processor_block(p, "processor.proc.0", x_hid.new_zeros(x_hid.shape[0], cfg["num_channels"]).normal_(), proc_ea, t(g.proc_edge_index), H)
+            layer(1 if L > 1 else 0, h0, e1 if L > 1 else proc_ea)
             dt = time.perf_counter() - t0
             if best is None or dt < best[1]:
                 best = (th, dt)
@@ -316,33 +382,85 @@ def cpu_baseline(model_fp32_params, cfg, g, x, layers_sample):
                 break
         cores = best[0]
         torch.set_num_threads(cores)
+
+        def unit():
+            t0 = time.perf_counter()
+            if gt:
+                lat = O.gt_forward_mapper(p, "encoder.data", x_data, x_hid, enc_ea, enc_ei, H)
+                xs = x_data
+            else:
+                xs, lat = O.gnn_forward_mapper(p, "encoder.data", x_data, x_hid, enc_ea, enc_ei)
+            t1 = time.perf_counter()
+            h, e = lat, proc_ea
+            for i in range(ls):
+                h, e = layer(i, h, e)
+            t2 = time.perf_counter()
+            if gt:
+                O.gt_backward_mapper(p, "decoder.data", h, xs, dec_ea, dec_ei, H)
+            else:
+                O.gnn_backward_mapper(p, "decoder.data", h, xs, dec_ea, dec_ei)
+            t3 = time.perf_counter()
+            return t1 - t0, (t2 - t1) / ls, t3 - t2
+
         t0 = time.perf_counter()
-        lat = O.gt_forward_mapper(p, "encoder.data", x_data, x_hid, enc_ea, t(g.enc_edge_index), H)
-        t_enc = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        h = lat
-        for i in range(layers_sample):
-            h = O.gt_processor_block(p, f"processor.proc.{i}", h, proc_ea, t(g.proc_edge_index), H)
-        t_layer = (time.perf_counter() - t0) / layers_sample
-        t0 = time.perf_counter()
-        O.gt_backward_mapper(p, "decoder.data", h, x_data, dec_ea, t(g.dec_edge_index), H)
-        t_dec = time.perf_counter() - t0
+        unit()  # warm-up (page faults, thread pool, allocator)
+        warm = time.perf_counter() - t0
+        reps = max(1, min(5, int((budget_s - warm) / max(warm, 1e-3))))
+        runs = [unit() for _ in range(reps)]
+    t_enc, t_layer, t_dec = (statistics.median(r[i] for r in runs) for i in range(3))
     t_full = t_enc + L * t_layer + t_dec
+    B, T, E, N, V = x.shape
     return {"value": N * cfg["num_channels"] / t_full, "unit": "nodes*channels/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fp32 on {cores} of {ncpu} host threads (fastest of a thread sweep): encoder ({t_enc:.2f}s) + {layers_sample} of {L} processor layers "
-                      f"({t_layer:.3f}s each) + decoder ({t_dec:.2f}s), same O96 graph/inputs; full forward = enc + {L}*layer + dec = {t_full:.2f}s",
-            "seconds_forward": round(t_full, 3)}
+            "sample": f"oracle fp32 on {cores} of {ncpu} host threads (fastest of a thread sweep); unit = encoder + {ls} of {L} processor layers + decoder, "
+                      f"1 warm-up unit ({warm:.1f}s) + median of {reps} timed units: encoder {t_enc:.2f}s, layer {t_layer:.3f}s, decoder {t_dec:.2f}s; "
+                      f"full forward = enc + {L}*layer + dec = {t_full:.2f}s",
+            "seconds_forward": round(t_full, 3), "timed_units": reps}
+
+
+def rccl_block(model, group, world, graph):
+    """What the model-parallel exchange carries per forward (from the halo / needed-rows plans of this rank = rank 0)."""
+    out = {"backend": torch.distributed.get_backend(group), "world_size": torch.distributed.get_world_size(group)}
+    try:
+        plan = getattr(model.processor, "_halo_cache", {}).get("plan")
+        if plan is not None:
+            es = next(model.parameters()).element_size()
+            D = model.num_channels
+            out.update({"halo_rows_recv": int(sum(plan.recv_counts)), "halo_rows_send": int(sum(plan.send_counts)),
+                        "halo_recv_rows_per_peer": [int(c) for c in plan.recv_counts],
+                        "halo_bytes_recv_per_layer": int(sum(plan.recv_counts)) * D * es,
+                        "halo_bytes_per_peer_per_layer_max": int(max(plan.recv_counts)) * D * es if plan.recv_counts else 0,
+                        "local_rows": int(plan.info.num_local_nodes), "layers": len(model.processor.proc)})
+    except Exception as e:  # noqa: BLE001
+        out["plan_error"] = f"{type(e).__name__}: {e}"
+    if graph is not None and hasattr(graph, "num_collectives"):
+        out["collectives_per_forward"] = graph.num_collectives
+    return out
+
+
+def latest_traffic(tag: str):
+    """HBM bytes per launch from the newest committed rocprofv3 --pmc passes for this configuration (FETCH_SIZE x2 + WRITE_SIZE,
+    see DESIGN.md / profiles/README.md): profiles/rNN_pmc_traffic[_<config>].json."""
+    suffix = "" if tag == "o96" else f"_{tag}"
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", f"r[0-9][0-9]_pmc_traffic{suffix}.json")))
+    if not files:
+        return {}, None
+    return json.load(open(files[-1])), os.path.basename(files[-1])
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; an N-GPU request must not "
+                         "report a number measured on another rank count")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (ROCm) device; there is no CPU fallback for the product path")
     # Developer hook (never set by the driver): ANEMOI_BENCH_TRANSPORT=host runs the N > 1 code path with all ranks on ONE
-    # GPU over gloo + the test-only host transport, to exercise sharding and segmented capture on a 1-GPU box.
+    # GPU over gloo + the debug host transport, to exercise sharding and segmented capture on a 1-GPU box.
     host_transport = os.environ.get("ANEMOI_BENCH_TRANSPORT") == "host"
     if host_transport:
         local_rank = 0
@@ -354,9 +472,9 @@ def main():
 
         if host_transport:
             dist.init_process_group("gloo")
-            from tests import gpu_host_transport
+            from anemoi_core_amd.distributed import host_transport as ht
 
-            gpu_host_transport.install()
+            ht.install()
         else:
             dist.init_process_group("nccl", device_id=device)
         group = dist.group.WORLD
@@ -383,7 +501,7 @@ def main():
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
-    graph = None
+    graph, graph_checked = None, None
     with torch.inference_mode():
         for _ in range(max(2, args.warmup // 2)):  # builds the static caches, sizes the allocator
             out = step()
@@ -392,6 +510,7 @@ def main():
         # aborts through the ProcessGroupNCCL watchdog or hangs; tools/nccl_capture_probe.py), so the forward becomes a
         # chain of hipGraphs with the collectives re-issued eagerly in between (anemoi_core_amd/utils/segments.py).
         if not args.no_graph and world == 1:
+            expect = step().clone()
             try:  # capture the whole forward (kernels are enqueued on torch's current stream through the C ABI)
                 s = torch.cuda.Stream()
                 s.wait_stream(torch.cuda.current_stream())
@@ -401,11 +520,17 @@ def main():
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     out = step()
+                graph.replay()
+                torch.cuda.synchronize()
             except Exception as e:  # noqa: BLE001
-                if rank == 0:
-                    print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+                print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
                 graph = None
                 torch.cuda.synchronize()
+            if graph is not None:
+                # the kernels are deterministic: what is timed (the replay) must reproduce the eager forward bit for bit
+                graph_checked = bool(torch.equal(out, expect))
+                if not graph_checked:
+                    raise SystemExit("bench.py: the hipGraph replay of the forward differs from the eager forward; refusing to time it")
         elif not args.no_graph:
             from anemoi_core_amd.utils.segments import SegmentedGraph
 
@@ -418,6 +543,7 @@ def main():
                 torch.cuda.synchronize()
                 if not torch.equal(out, expect):  # kernels are deterministic: a replay must reproduce the eager run bit for bit
                     ok, why = 0, "segmented replay differs from the eager forward"
+                graph_checked = bool(ok)
             except Exception as e:  # noqa: BLE001
                 import traceback
 
@@ -428,7 +554,7 @@ def main():
             if int(flag.item()) == 0:
                 if why:
                     print(f"[bench] rank {rank}: segmented hipGraph capture unusable ({why}); all ranks run eagerly", file=sys.stderr)
-                graph = None
+                graph, graph_checked = None, None
                 torch.cuda.synchronize()
         run = graph.replay if graph is not None else step
         for _ in range(args.warmup):
@@ -447,59 +573,74 @@ def main():
     value = g.num_data * args.channels / (ms * 1e-3)
 
     if rank == 0:
+        kind_name = "GraphTransformer" if args.kind == "gt" else "GNN (GraphConv)"
         res = {
-            "metric": "forward nodes*channels/sec on O96 GraphTransformer",
+            "metric": f"forward nodes*channels/sec on {args.data_grid.upper()} {kind_name}",
             "value": value, "unit": "nodes*channels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype,
-            "data": "synthetic (seeded N(0,1) inputs, random-init weights, own O96/icosphere topology generator)",
-            "config": {"workload": f"AnemoiModelEncProcDec forward, {args.data_grid.upper()} data grid ({g.num_data} nodes, {args.vars} vars x 2 steps) -> "
+            "data": "synthetic (seeded N(0,1) inputs, random-init weights, own O96/N320/icosphere topology generator)",
+            "config": {"name": args.config,
+                       "workload": f"AnemoiModelEncProcDec forward, {args.data_grid.upper()} data grid ({g.num_data} nodes, {args.vars} vars x 2 steps) -> "
                                    f"icosphere res {args.hidden_res} hidden mesh ({g.num_hidden} nodes, {g.proc_edge_index.shape[1]} edges), "
-                                   f"{'GraphTransformer' if args.kind == 'gt' else 'GNN'} processor {args.layers} layers x {args.channels} ch x {args.heads} heads, "
-                                   f"enc {g.enc_edge_index.shape[1]} / dec {g.dec_edge_index.shape[1]} edges, batch 1",
+                                   f"{kind_name} processor {args.layers} layers x {args.channels} ch" + (f" x {args.heads} heads" if args.kind == "gt" else "") +
+                                   f", enc {g.enc_edge_index.shape[1]} / dec {g.dec_edge_index.shape[1]} edges, batch 1",
                        "parallelism": f"hidden mesh sharded over {world} GPU(s), halo all-to-all per layer" if world > 1 else "single GPU",
-                       "hip_graph": graph is not None,
+                       "hip_graph": graph is not None, "graph_equals_eager": graph_checked,
                        "graph_segments": getattr(graph, "num_graphs", 1) if graph is not None else 0},
         }
-        if world == 1 and args.kind == "gt" and not args.no_kernel_timing:
+        if world > 1:
+            res["rccl"] = rccl_block(model, group, world, graph)
+            if host_transport:
+                res["rccl"]["note"] = "ANEMOI_BENCH_TRANSPORT=host: all ranks on ONE GPU over the gloo debug transport - a code-path check, not a scaling number"
+        if world == 1 and not args.no_kernel_timing:
+            host_ms = max(12.0, 4.0 * ms)
             with torch.inference_mode():
-                fam = profile_forward(step, dtype)
-                res["kernels"] = time_kernels(model, g, args, dtype, device)
+                fam = profile_forward(step, dtype, host_ms)
+                if args.kind == "gt":
+                    res["kernels"] = time_kernels(model, g, args, dtype, device)
                 try:
-                    res["components"] = component_times(model, step, g.num_data, g.num_hidden, args.channels, args.layers)
+                    res["components"] = component_times(model, step, g.num_data, g.num_hidden, args.channels, args.layers, host_ms)
                 except Exception as e:  # noqa: BLE001  (an informational leg must never take the benchmark line down)
                     res["components"] = {"error": f"{type(e).__name__}: {e}"}
+            traffic, traffic_file = latest_traffic(args.config)
+
+            def roof(name, bound):
+                d = fam[name]
+                if bound == "mfma":
+                    ach, peak, unit = d["flops"] / d["us"] / 1e6, MFMA_BF16_PEAK_TFLOPS, "TFLOP/s"
+                else:
+                    ach, peak, unit = d["bytes"] / d["us"] / 1e3, HBM_PEAK_GBS, "GB/s"
+                tr = traffic.get(name)
+                return {"kernel": name, "bound": bound, "achieved": round(ach, 1), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
+                        "traffic": tr, "algorithmic_bytes_per_launch": round(d["bytes"] / d["calls"]),
+                        "traffic_over_algorithmic": round(tr / (d["bytes"] / d["calls"]), 3) if tr else None,
+                        "calls_per_step": d["calls"], "avg_launch_us": round(d["us"] / d["calls"], 2)}
+
             res["kernel_families"] = {k: {"calls": v["calls"], "total_us": round(v["us"], 1), "avg_us": round(v["us"] / v["calls"], 2),
-                                          "work": v["work"], "unit": v["unit"]} for k, v in fam.items()}
-            traffic = {}
-            tpath = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
-            if os.path.exists(tpath):  # HBM bytes per launch from rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE), see DESIGN.md
-                traffic = json.load(open(tpath))
+                                          "flops": v["flops"], "bytes": v["bytes"],
+                                          "tflops": round(v["flops"] / v["us"] / 1e6, 1) if v["flops"] else None,
+                                          "gbs_algorithmic": round(v["bytes"] / v["us"] / 1e3, 1)} for k, v in fam.items()}
             dom = max(fam, key=lambda k: fam[k]["us"])
-            d = fam[dom]
-            if d["unit"] == "flop":
-                ach, peak, unit, bound = d["work"] / d["us"] / 1e6, MFMA_BF16_PEAK_TFLOPS, "TFLOP/s", "mfma"
-            else:
-                ach, peak, unit, bound = d["work"] / d["us"] / 1e3, HBM_PEAK_GBS, "GB/s", "hbm"
-            res["roofline"] = {"kernel": dom, "bound": bound, "achieved": round(ach, 1), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
-                               "traffic": traffic.get(dom), "calls_per_step": d["calls"], "avg_launch_us": round(d["us"] / d["calls"], 2),
-                               "how": "sum of algorithmic work of all launches of the family in one forward / sum of their HIP-event durations (each bracket carries ~2.5 us of event-marker cost, so achieved is a slight under-estimate; profiles/r01_kernel_trace_summary.txt has the rocprofv3 durations)"}
-            at = fam.get("gt_attn_fused_edge_fwd_kernel")
-            if at:
-                res["roofline"]["gather_scatter"] = {"kernel": "gt_attn_fused_edge_fwd_kernel", "bound": "hbm", "achieved": round(at["work"] / at["us"] / 1e3, 1),
-                                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(at["work"] / at["us"] / 1e3 / HBM_PEAK_GBS, 4),
-                                                     "traffic": traffic.get("gt_attn_fused_edge_fwd_kernel"), "calls_per_step": at["calls"],
-                                                     "avg_launch_us": round(at["us"] / at["calls"], 2)}
-        if world == 1 and args.kind == "gt" and not args.no_cpu_baseline:
-            cfg = {"num_heads": args.heads, "num_layers": args.layers, "num_channels": args.channels}
+            res["roofline"] = roof(dom, "mfma" if fam[dom]["flops"] else "hbm")
+            res["roofline"]["traffic_source"] = traffic_file
+            res["roofline"]["how"] = ("sum of algorithmic work of all launches of the family in one forward / sum of their HIP-event durations on the "
+                                      "launch stream (each bracket carries ~2.5 us of event-marker cost, so achieved is a slight under-estimate); "
+                                      "profiles/ holds the rocprofv3 --kernel-trace --stats summary of the same command")
+            gs = "gt_attn_fused_edge_fwd_kernel" if args.kind == "gt" else "edge_ln_res_segsum_kernel"
+            if gs in fam:
+                res["roofline"]["gather_scatter"] = roof(gs, "hbm")
+        if world == 1 and not args.no_cpu_baseline:
+            cfg = {"num_heads": args.heads, "num_layers": args.layers, "num_channels": args.channels, "kind": args.kind}
             try:
                 res["gpu_eager_baseline"] = gpu_eager_baseline(params_fp32, cfg, g, x, device)
                 res["speedup_vs_gpu_eager"] = round(value / res["gpu_eager_baseline"]["value"], 2)
             except Exception as e:  # noqa: BLE001  (a baseline leg must never take the benchmark line down)
                 res["gpu_eager_baseline"] = {"error": f"{type(e).__name__}: {e}"}
             torch.cuda.empty_cache()
-            res["cpu_baseline"] = cpu_baseline(params_fp32, cfg, g, x, layers_sample=2)
-        print(json.dumps(res))
+            res["cpu_baseline"] = cpu_baseline(params_fp32, cfg, g, x)
+        print(json.dumps(res), flush=True)
     if world > 1:
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ANEMOI_HIP_ABI_VERSION 6
+#define ANEMOI_HIP_ABI_VERSION 7
 
 typedef enum { ANEMOI_F32 = 0, ANEMOI_BF16 = 1, ANEMOI_F16 = 2 } anemoi_dtype_t;
 typedef enum { ANEMOI_ACT_NONE = 0, ANEMOI_ACT_GELU = 1 } anemoi_act_t;
@@ -165,6 +165,11 @@ int anemoi_colsum(const void* x, int64_t ldx, float* out, float* workspace, int3
 /* d_pre = d_y * gelu'(pre), gelu'(x) = Phi(x) + x phi(x) (exact erf form; autograd of torch.nn.GELU, layers/utils.py:111). */
 int anemoi_gelu_bwd(const void* pre, int64_t ldp, const void* d_y, int64_t lddy, void* d_pre, int64_t lddp,
                     int32_t n_rows, int32_t D, anemoi_dtype_t dtype, void* stream);
+
+/* y = gelu(x), exact erf form: torch.nn.GELU as selected by `layer_kernels.Activation` (layers/utils.py:111) when it runs
+ * as a stand-alone module, e.g. inside the reference's own MLP (layers/mlp.py:158-169).  The fused blocks of this package
+ * apply GELU in the epilogue of the preceding GEMM instead. */
+int anemoi_gelu_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, int32_t n_rows, int32_t D, anemoi_dtype_t dtype, void* stream);
 
 /* LayerNorm folded into the GEMMs around it (inference).  For y = LN(x; gamma, beta) W^T + b:
  *     y = rstd (x (W diag gamma)^T - mean c) + d,   c = row sums of W diag(gamma),  d = W beta + b

@@ -82,3 +82,26 @@ def test_forward_on_cpu_fails_loudly(golden):
 
     with torch.no_grad(), pytest.raises(RuntimeError, match="no CPU fallback"):
         blk(c["x"], c["edge_attr"], c["edge_index"], GraphShardInfo(), 1, c["x"].shape[0])
+
+
+def test_assemble_output_repeats_skip_over_output_steps():
+    """n_step_output > 1: the skip connection is repeated over the output steps (reference layers/residual.py:53-57,
+    models/encoder_processor_decoder.py:131-158): x_out[..., out_idx] += expand(x_skip)[..., in_idx]."""
+    from anemoi_core_amd.graphs.synthetic import build_synthetic_graph
+    from anemoi_core_amd.models import AnemoiModelEncProcDec
+    from tests.helpers import make_data_indices, model_config
+
+    g = build_synthetic_graph("o8", 2)
+    T_out, V_in, V_prog = 2, 5, 3
+    model = AnemoiModelEncProcDec(model_config=model_config("gt", 32, 1, 4, 2), data_indices=make_data_indices(V_in, V_prog),
+                                  statistics={"data": None}, n_step_input=2, n_step_output=T_out, graph_data=g).eval()
+    N = g.num_data
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 2, 1, N, V_in, generator=gen)
+    dec_out = torch.randn(N, T_out * V_prog, generator=gen)  # "(batch ensemble grid) (time vars)"
+    x_skip = x[:, -1, ...]
+    got = model._assemble_output(dec_out, x_skip, 1, 1, torch.float32, "data")
+    want = dec_out.view(1, 1, N, T_out, V_prog).permute(0, 3, 1, 2, 4).clone()
+    want[..., list(range(V_prog))] += x_skip.unsqueeze(1).expand(-1, T_out, -1, -1, -1)[..., list(range(V_prog))]
+    assert got.shape == (1, T_out, 1, N, V_prog)
+    torch.testing.assert_close(got, want, rtol=0, atol=0)

@@ -239,3 +239,36 @@ def test_boundings_kernel_matches_reference(golden):
     ops.bound_columns_(xb, *program_tables(prog, DEV))
     want = O.apply_boundings(c["x"].to(torch.bfloat16).float(), c["specs"], c["name_to_index"], c["statistics"], c["name_to_index_stats"])
     assert float((xb.float().cpu() - want).abs().max()) <= 2e-2 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layer_kernels_plugins_run_standalone(dtype):
+    """The third plug-in point (reference layers/utils.py:87-142): `layer_kernels` entries with `_target_` strings select the
+    Linear / LayerNorm / Activation CLASSES.  The MI355X classes must work as ordinary modules - here in a plain
+    nn.Sequential shaped like the reference's own MLP (layers/mlp.py:158-169: Linear, Activation, Linear [, LayerNorm]) -
+    forward and backward, against torch's own modules with the same parameters."""
+    from anemoi_core_amd.layers.utils import load_layer_kernels
+
+    lkk = load_layer_kernels({"Linear": {"_target_": "anemoi_core_amd.layers.kernels.Linear"},
+                              "LayerNorm": {"_target_": "anemoi_core_amd.layers.kernels.LayerNorm"},
+                              "Activation": {"_target_": "anemoi_core_amd.layers.kernels.GELU"}})
+    torch.manual_seed(0)
+    ours = torch.nn.Sequential(lkk.Linear(64, 256), lkk.Activation(), lkk.Linear(256, 64), lkk.LayerNorm(64)).to(DEV).to(dtype)
+    ref = torch.nn.Sequential(torch.nn.Linear(64, 256), torch.nn.GELU(), torch.nn.Linear(256, 64), torch.nn.LayerNorm(64)).to(DEV)
+    ref.load_state_dict({k: v.float() for k, v in ours.state_dict().items()})
+    x = torch.randn(1000, 64, device=DEV).to(dtype)
+    xo, xr = x.clone().requires_grad_(True), x.float().clone().requires_grad_(True)
+    yo, yr = ours(xo), ref(xr)
+    tol = 2e-5 if dtype == torch.float32 else 4e-2
+    assert float((yo.float() - yr).abs().max()) <= tol
+    # the activation on its own, incl. 3-D input and the tails of erf
+    g = lkk.Activation()
+    t = torch.linspace(-9, 9, 3 * 5 * 64, device=DEV).view(3, 5, 64).to(dtype)
+    assert float((g(t).float() - torch.nn.functional.gelu(t.float())).abs().max()) <= (1e-6 if dtype == torch.float32 else 4e-2)
+    w = torch.randn_like(yr)
+    (yo.float() * w).sum().backward()
+    (yr * w).sum().backward()
+    gtol = 1e-4 if dtype == torch.float32 else 6e-2
+    assert float((xo.grad.float() - xr.grad).abs().max()) <= gtol * max(1.0, float(xr.grad.abs().max()))
+    for (n, po), (_, pr) in zip(ours.named_parameters(), ref.named_parameters()):
+        assert float((po.grad.float() - pr.grad).abs().max()) <= gtol * max(1.0, float(pr.grad.abs().max())), n
