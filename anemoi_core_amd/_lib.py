@@ -37,6 +37,9 @@ SIGNATURES = {
     "anemoi_cond_layernorm_fwd": ([_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i32, _i32, _f, C.c_int, _p], C.c_int),
     "anemoi_assemble_input": ([_p, _i64, _i64, _i32, _i32, _p, _i64, _i32, _p, _i64, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_assemble_output": ([_p, _i64, _p, _i64, _p, _p, _i64, _i32, _i32, C.c_int, _p], C.c_int),
+    "anemoi_assemble_input_norm": ([_p, C.c_int, _i64, _i64, _i32, _i32, _p, _p, _p, _i64, _i32, _p, _i64, _i32, _i32, C.c_int, _p], C.c_int),
+    "anemoi_assemble_output_norm": ([_p, _i64, C.c_int, _p, _i64, _p, _p, _p, _p, _i64, _i32, _i32, C.c_int, _p], C.c_int),
+    "anemoi_affine_columns": ([_p, _i64, _p, _i64, _p, _p, _i32, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_bound_columns": ([_p, _i64, _i32, _i32, _p, _p, _i32, C.c_int, _p], C.c_int),
     "anemoi_layernorm_fwd": ([_p, _i64, _p, _p, _p, _i64, _p, _i64, _i32, _i32, _f, C.c_int, _p], C.c_int),
     "anemoi_gt_attention_fused_edge_bwd_partial_floats": ([_i32, _i32, _i32], _i64),

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(64 * kRowWaves) void gather_rows_kernel(const T* __
 // owns a row and applies the column program in order (ops: int32 [n_ops][4] = kind, column, total column, unused;
 // params: fp32 [n_ops][2] = min / max or the normalised minimum).  kind: 1 relu, 2 leaky relu, 3 relu above a minimum,
 // 4 leaky relu above a minimum, 5 hardtanh, 6 leaky hardtanh, 7 hardtanh * x[total], 8 leaky hardtanh * x[total]
-// (slopes 0.01 as in torch / layers/activations.py:16-42).
+// (slopes 0.01 as in torch / layers/activations.py:16-42), 9 de-normalisation (x - p0) / p1 (preprocessing/normalizer.py:217-252).
 template <typename T>
 __global__ void bound_columns_kernel(T* __restrict__ x, int64_t ldx, int n_rows, const int32_t* __restrict__ ops,
                                      const float* __restrict__ params, int n_ops) {
@@ -247,6 +247,7 @@ __global__ void bound_columns_kernel(T* __restrict__ x, int64_t ldx, int n_rows,
       case 6: v = lht(v); break;
       case 7: v = to_float(from_float<T>(fminf(fmaxf(v, p0), p1))) * to_float(row[tot]); break;
       case 8: v = to_float(from_float<T>(lht(v))) * to_float(row[tot]); break;
+      case 9: v = to_float(from_float<T>(v - p0)) / p1; break;  // InputNormalizer.inverse_transform: x.subtract_(add).div_(mul) (normalizer.py:246-252)
       default: break;
     }
     row[col] = from_float<T>(v);
@@ -293,6 +294,75 @@ __global__ void assemble_input_kernel(const T* __restrict__ x, int64_t ld_t, int
     v = *reinterpret_cast<const Vec<T, Q>*>(attrs + (int64_t)n * lda + (c - T_steps * V));
   }
   *reinterpret_cast<Vec<T, Q>*>(out + (int64_t)n * ldo + c) = v;
+}
+
+// x * m + a with the two roundings of torch's `x.mul_(m).add_(a)` (no FMA contraction): bit-equal to the reference's
+// InputNormalizer.transform in fp32 (preprocessing/normalizer.py:154-190).
+__device__ __forceinline__ float mul_then_add(float x, float m, float a) {
+#pragma clang fp contract(off)
+  const float t = x * m;
+  return t + a;
+}
+
+// Input assembly WITH the input normaliser as a column program (scope row f4): as assemble_input_kernel, and the time /
+// variable columns become x * mul[v] + add[v] (fp32 arithmetic, one pass over the input).  The input may be wider than
+// the model dtype (fp32 data into a 16-bit model): TI -> fp32 -> TO.
+template <typename TI, typename TO>
+__global__ void assemble_input_norm_kernel(const TI* __restrict__ x, int64_t ld_t, int64_t ldx, int T_steps, int V, const float* __restrict__ mul,
+                                           const float* __restrict__ add, const TO* __restrict__ attrs, int64_t lda, int A, TO* __restrict__ out,
+                                           int64_t ldo, int W, int n_rows) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)n_rows * W) return;
+  const int n = (int)(i / W), c = (int)(i % W);
+  float v = 0.f;
+  if (c < T_steps * V) {
+    const int t = c / V, cv = c % V;
+    v = to_float(x[t * ld_t + (int64_t)n * ldx + cv]);
+    if (mul != nullptr) v = mul_then_add(v, mul[cv], add[cv]);
+  } else if (c < T_steps * V + A) {
+    v = to_float(attrs[(int64_t)n * lda + (c - T_steps * V)]);
+  }
+  out[(int64_t)n * ldo + c] = from_float<TO>(v);
+}
+
+// Output assembly with the skip connection taken from the RAW input (normalised on the fly) - the counterpart of
+// assemble_input_norm_kernel: out[n, v] = x_out[n, v] + (col_map[v] >= 0 ? skip[n, m] * mul[m] + add[m] : 0), m = col_map[v].
+// x_out is in the model dtype (TM), skip and out in the caller's data dtype (TS): the reference adds the residual in the
+// input's dtype (x_out.to(dtype=x.dtype), models/encoder_processor_decoder.py:145-158).
+template <typename TM, typename TS>
+__global__ void assemble_output_norm_kernel(const TM* __restrict__ x_out, int64_t ldx, const TS* __restrict__ skip, int64_t lds,
+                                            const int32_t* __restrict__ col_map, const float* __restrict__ mul, const float* __restrict__ add,
+                                            TS* __restrict__ out, int64_t ldo, int n_rows, int n_cols) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)n_rows * n_cols) return;
+  const int n = (int)(i / n_cols), v = (int)(i % n_cols);
+  float val = to_float(from_float<TS>(to_float(x_out[(int64_t)n * ldx + v])));
+  const int m = col_map[v];
+  if (m >= 0) {
+    float sk = to_float(skip[(int64_t)n * lds + m]);
+    if (mul != nullptr) sk = to_float(from_float<TS>(mul_then_add(sk, mul[m], add[m])));
+    val += sk;
+  }
+  out[(int64_t)n * ldo + v] = from_float<TS>(val);
+}
+
+// y[r, c] = x[r, c] * mul[c] + add[c] (inverse = 0) or (x[r, c] - add[c]) / mul[c] (inverse = 1): InputNormalizer.transform /
+// inverse_transform as a stand-alone kernel (preprocessing/normalizer.py:154-252); may run in place (y == x).
+template <typename T>
+__global__ void affine_columns_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy, const float* __restrict__ mul,
+                                      const float* __restrict__ add, int inverse, int n_rows, int V) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)n_rows * V) return;
+  const int r = (int)(i / V), c = (int)(i % V);
+  const float v = to_float(x[(int64_t)r * ldx + c]);
+  float o;
+  if (inverse) {
+    o = to_float(from_float<T>(v - add[c])) / mul[c];  // subtract_ then div_: two roundings in T like torch's in-place ops
+  } else {
+    o = to_float(from_float<T>(v * mul[c]));
+    o = o + add[c];
+  }
+  y[(int64_t)r * ldy + c] = from_float<T>(o);
 }
 
 // Pick the widest vector width (in elements) such that rows stay 16-byte-or-narrower aligned and D % VEC == 0.
@@ -533,4 +603,70 @@ extern "C" int anemoi_assemble_input(const void* x, int64_t ld_t, int64_t ldx, i
   }
 #undef AI_LAUNCH
   return check_launch("assemble_input_kernel");
+}
+
+extern "C" int anemoi_assemble_input_norm(const void* x, anemoi_dtype_t x_dtype, int64_t ld_t, int64_t ldx, int32_t T_steps, int32_t V,
+                                          const float* col_mul, const float* col_add, const void* attrs, int64_t lda, int32_t A, void* out,
+                                          int64_t ldo, int32_t W, int32_t n_rows, anemoi_dtype_t dtype, void* stream) {
+  ANEMOI_REQUIRE(n_rows >= 0 && T_steps > 0 && V > 0 && A >= 0 && W >= T_steps * V + A && ldo >= W && ldx >= V && (A == 0 || lda >= A),
+                 "assemble_input_norm: bad sizes");
+  ANEMOI_REQUIRE((col_mul == nullptr) == (col_add == nullptr), "assemble_input_norm: col_mul and col_add go together");
+  if (n_rows == 0) return ANEMOI_OK;
+  ANEMOI_REQUIRE(x && out && (A == 0 || attrs), "assemble_input_norm: null pointer");
+  ANEMOI_REQUIRE(x_dtype == dtype || x_dtype == ANEMOI_F32, "assemble_input_norm: the input is in the model dtype or fp32");
+  const int64_t n = (int64_t)n_rows * W;
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  hipStream_t st = as_stream(stream);
+#define AIN_LAUNCH(TI, TO)                                                                                                             \
+  hipLaunchKernelGGL((assemble_input_norm_kernel<TI, TO>), grid, block, 0, st, (const TI*)x, ld_t, ldx, T_steps, V, col_mul, col_add,  \
+                     (const TO*)attrs, lda, A, (TO*)out, ldo, W, n_rows)
+  switch (dtype) {
+    case ANEMOI_F32: AIN_LAUNCH(float, float); break;
+    case ANEMOI_BF16: if (x_dtype == ANEMOI_F32) AIN_LAUNCH(float, bf16_t); else AIN_LAUNCH(bf16_t, bf16_t); break;
+    case ANEMOI_F16: if (x_dtype == ANEMOI_F32) AIN_LAUNCH(float, f16_t); else AIN_LAUNCH(f16_t, f16_t); break;
+    default: set_error("unknown dtype"); return ANEMOI_E_INVALID;
+  }
+#undef AIN_LAUNCH
+  return check_launch("assemble_input_norm_kernel");
+}
+
+extern "C" int anemoi_assemble_output_norm(const void* x_out, int64_t ldx, anemoi_dtype_t model_dtype, const void* x_skip, int64_t lds,
+                                           const int32_t* col_map, const float* col_mul, const float* col_add, void* out, int64_t ldo,
+                                           int32_t n_rows, int32_t n_cols, anemoi_dtype_t dtype, void* stream) {
+  ANEMOI_REQUIRE(n_rows >= 0 && n_cols > 0 && ldx >= n_cols && ldo >= n_cols, "assemble_output_norm: bad sizes");
+  ANEMOI_REQUIRE((col_mul == nullptr) == (col_add == nullptr), "assemble_output_norm: col_mul and col_add go together");
+  if (n_rows == 0) return ANEMOI_OK;
+  ANEMOI_REQUIRE(x_out && x_skip && col_map && out, "assemble_output_norm: null pointer");
+  ANEMOI_REQUIRE(model_dtype == dtype || dtype == ANEMOI_F32, "assemble_output_norm: the output is in the model dtype or fp32");
+  const int64_t n = (int64_t)n_rows * n_cols;
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  hipStream_t st = as_stream(stream);
+#define AON_LAUNCH(TM, TS)                                                                                                              \
+  hipLaunchKernelGGL((assemble_output_norm_kernel<TM, TS>), grid, block, 0, st, (const TM*)x_out, ldx, (const TS*)x_skip, lds, col_map, \
+                     col_mul, col_add, (TS*)out, ldo, n_rows, n_cols)
+  switch (model_dtype) {
+    case ANEMOI_F32: AON_LAUNCH(float, float); break;
+    case ANEMOI_BF16: if (dtype == ANEMOI_F32) AON_LAUNCH(bf16_t, float); else AON_LAUNCH(bf16_t, bf16_t); break;
+    case ANEMOI_F16: if (dtype == ANEMOI_F32) AON_LAUNCH(f16_t, float); else AON_LAUNCH(f16_t, f16_t); break;
+    default: set_error("unknown dtype"); return ANEMOI_E_INVALID;
+  }
+#undef AON_LAUNCH
+  return check_launch("assemble_output_norm_kernel");
+}
+
+extern "C" int anemoi_affine_columns(const void* x, int64_t ldx, void* y, int64_t ldy, const float* col_mul, const float* col_add,
+                                     int32_t inverse, int32_t n_rows, int32_t V, anemoi_dtype_t dtype, void* stream) {
+  ANEMOI_REQUIRE(n_rows >= 0 && V > 0 && ldx >= V && ldy >= V, "affine_columns: bad sizes");
+  if (n_rows == 0) return ANEMOI_OK;
+  ANEMOI_REQUIRE(x && y && col_mul && col_add, "affine_columns: null pointer");
+  const int64_t n = (int64_t)n_rows * V;
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  hipStream_t st = as_stream(stream);
+  switch (dtype) {
+    case ANEMOI_F32: hipLaunchKernelGGL((affine_columns_kernel<float>), grid, block, 0, st, (const float*)x, ldx, (float*)y, ldy, col_mul, col_add, inverse, n_rows, V); break;
+    case ANEMOI_BF16: hipLaunchKernelGGL((affine_columns_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, col_mul, col_add, inverse, n_rows, V); break;
+    case ANEMOI_F16: hipLaunchKernelGGL((affine_columns_kernel<f16_t>), grid, block, 0, st, (const f16_t*)x, ldx, (f16_t*)y, ldy, col_mul, col_add, inverse, n_rows, V); break;
+    default: set_error("unknown dtype"); return ANEMOI_E_INVALID;
+  }
+  return check_launch("affine_columns_kernel");
 }

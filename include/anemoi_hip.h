@@ -133,7 +133,9 @@ int anemoi_cond_layernorm_bwd(const void* x, int64_t ldx, const void* scale, int
 /* Output boundings at the model edge, in place and in configuration order (layers/bounding.py:81-307;
  * models/encoder_processor_decoder.py:160-162).  ops: int32 [n_ops][4] = (kind, column, total column, 0); params: fp32
  * [n_ops][2].  kind 1 ReluBounding, 2 LeakyReluBounding, 3 / 4 Normalized(Leaky)ReluBounding (params[0] = the normalised
- * minimum), 5 / 6 (Leaky)HardtanhBounding (min, max), 7 / 8 (Leaky)FractionBounding (min, max; times column ``total``). */
+ * minimum), 5 / 6 (Leaky)HardtanhBounding (min, max), 7 / 8 (Leaky)FractionBounding (min, max; times column ``total``),
+ * 9 de-normalisation (x - params[0]) / params[1] = InputNormalizer.inverse_transform of that column
+ * (preprocessing/normalizer.py:217-252), appended after the boundings when the output normaliser is fused. */
 int anemoi_bound_columns(void* x, int64_t ldx, int32_t n_rows, int32_t n_cols, const int32_t* ops, const float* params,
                          int32_t n_ops, anemoi_dtype_t dtype, void* stream);
 
@@ -260,6 +262,32 @@ int anemoi_glu_fwd(const void* gate_value, int64_t ldgv, void* out, int64_t ldo,
                    anemoi_dtype_t dtype, void* stream);
 int anemoi_glu_bwd(const void* gate_value, int64_t ldgv, const void* d_out, int64_t lddo, void* d_gate_value, int64_t lddgv,
                    int32_t n_rows, int32_t D, int32_t kind, anemoi_dtype_t dtype, void* stream);
+
+/* ---- input normaliser at the model edges (scope row f4) ---------------------------------------------------------------
+ * The reference normalises the batch before the model and de-normalises its output after it
+ * (`pre_processors` / `post_processors` around `forward` in models/base.py:303-391; `InputNormalizer.transform`:
+ * x * _norm_mul + _norm_add per variable, `inverse_transform`: (x - _norm_add) / _norm_mul, preprocessing/normalizer.py:154-252).
+ * Here the transform rides in the kernels that touch every input / output element anyway. */
+
+/* anemoi_assemble_input with the normaliser as a column program: the T * V time/variable columns become
+ * x * col_mul[v] + col_add[v] (fp32, two roundings like torch's mul_ / add_; NULL/NULL = plain copy).  `x` may be fp32
+ * (x_dtype) while `attrs` / `out` are in the model `dtype`. */
+int anemoi_assemble_input_norm(const void* x, anemoi_dtype_t x_dtype, int64_t ld_t, int64_t ldx, int32_t T_steps, int32_t V,
+                               const float* col_mul, const float* col_add, const void* attrs, int64_t lda, int32_t A, void* out,
+                               int64_t ldo, int32_t W, int32_t n_rows, anemoi_dtype_t dtype, void* stream);
+
+/* anemoi_assemble_output with the skip connection read from the RAW input and normalised on the fly:
+ * out[n, v] = x_out[n, v] + (col_map[v] >= 0 ? x_skip[n, m] * col_mul[m] + col_add[m] : 0), m = col_map[v].
+ * x_out in `model_dtype`; x_skip / out in `dtype` (= model_dtype or fp32: the reference adds the residual in the input's
+ * dtype, models/encoder_processor_decoder.py:145-158).  The de-normalisation of the result is op 9 of anemoi_bound_columns. */
+int anemoi_assemble_output_norm(const void* x_out, int64_t ldx, anemoi_dtype_t model_dtype, const void* x_skip, int64_t lds,
+                                const int32_t* col_map, const float* col_mul, const float* col_add, void* out, int64_t ldo,
+                                int32_t n_rows, int32_t n_cols, anemoi_dtype_t dtype, void* stream);
+
+/* Stand-alone InputNormalizer.transform (inverse = 0: y = x * mul[c] + add[c]) / inverse_transform (inverse = 1:
+ * y = (x - add[c]) / mul[c]) over the last dimension of a [n_rows, V] view; y may alias x (in_place). */
+int anemoi_affine_columns(const void* x, int64_t ldx, void* y, int64_t ldy, const float* col_mul, const float* col_add,
+                          int32_t inverse, int32_t n_rows, int32_t V, anemoi_dtype_t dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -10,11 +10,12 @@
    the HIP forward in fp32 and in bf16 against `oracle.enc_proc_dec_forward` (a few seconds of host time);
  * the reference's inference chunking knobs (environment variables, `num_chunks`) change nothing.
 
-Tolerances.  fp32: max |err| <= 1e-4 * max(1, max |ref|) per mapper (the reference's own precedent is atol 1e-4 on O(1)
-outputs, models/tests/integration/triton/test_triton_gt.py:135-136); 5e-4 * max(1, max|ref|) after the 18 chained blocks of
-the full model (fp32 re-association accumulates over depth).  bf16: weights and inputs are rounded to bf16 first and the
-fp32 oracle runs on the ROUNDED values; max |err| <= 8e-2 * max(1, max|ref|) and mean |err| <= 1e-2 * max(1, mean|ref|)
-(activations are re-rounded to bf16 after every kernel: ~2^-8 relative per rounding point).
+Tolerances (s = max(1, max |ref|)).  fp32: max |err| <= 2e-5 * s per mapper and 5e-5 * s after the 18 chained blocks of the
+full model (measured on MI355X: 3.5e-6 on outputs of magnitude 3-6, i.e. ~1e-6 * s; the reference's own precedent is a
+looser atol 1e-4 on O(1) outputs, models/tests/integration/triton/test_triton_gt.py:135-136).  bf16: weights and inputs are
+rounded to bf16 first and the fp32 oracle runs on the ROUNDED values; max |err| <= 2e-2 * s and mean |err| <= 5e-3 *
+max(1, mean|ref|) (measured 7e-3 * s / 2.6e-3: activations are re-rounded to bf16 after every kernel, ~2^-8 relative per
+rounding point).
 """
 import os
 
@@ -36,13 +37,13 @@ def _report(name, got, want):
     return float(err.max()) / scale, float(err.mean()) / mscale
 
 
-def _check(name, got, want, dtype, fp32_tol=1e-4):
+def _check(name, got, want, dtype, fp32_tol=2e-5):
     assert torch.isfinite(got).all(), name
     mx, mean = _report(name, got, want)
     if dtype == torch.float32:
         assert mx <= fp32_tol, f"{name}: fp32 max err / scale {mx:.3e}"
     else:
-        assert mx <= 8e-2 and mean <= 1e-2, f"{name}: bf16 max {mx:.3e} mean {mean:.3e}"
+        assert mx <= 2e-2 and mean <= 5e-3, f"{name}: bf16 max {mx:.3e} mean {mean:.3e}"
 
 
 @pytest.fixture(scope="module")
@@ -185,7 +186,7 @@ def test_bench_model_vs_oracle(bench_model, dtype):
     with torch.no_grad():
         want = O.enc_proc_dec_forward(params, cfg, g, x)
     assert got.shape == want.shape == (1, 1, 1, g.num_data, 84)
-    _check(f"bench model (O96, 16 layers) {dtype}", got.float().cpu(), want, dtype, fp32_tol=5e-4)
+    _check(f"bench model (O96, 16 layers) {dtype}", got.float().cpu(), want, dtype, fp32_tol=5e-5)
 
 
 def test_inference_chunk_knobs_change_nothing(monkeypatch):
