@@ -152,19 +152,27 @@ class AnemoiModelEncProcDec(nn.Module):
         return out
 
     # -- glue (encoder_processor_decoder.py:98-163) ---------------------------------------------------------
-    def _assemble_input(self, x: Tensor, batch_size: int, shard_sizes, group, ds: str):
+    def _assemble_input(self, x: Tensor, batch_size: int, shard_sizes, group, ds: str, norm=None):
+        """``norm``: the dataset's InputNormalizer when ``predict_step`` fuses it (x is then the RAW batch).  Returns
+        (x_data_latent, x_skip, skip_is_raw)."""
         node_attr = self.node_attributes(ds, batch_size=batch_size)
-        x_skip = x[:, self._skip_step, ...]  # SkipConnection (layers/residual.py:60-81): last input step
         if shard_sizes is not None:
             node_attr = shard_tensor(node_attr, 0, shard_sizes, group)
         B, T, E, N, V = x.shape
-        if (_FUSED_INPUT and B == 1 and E == 1 and x.is_cuda and node_attr.dtype == x.dtype and x.stride(4) == 1
-                and not (torch.is_grad_enabled() and (x.requires_grad or node_attr.requires_grad))):
-            # inference, one member: permute + cat + alignment zeros in ONE kernel
+        fusable = (_FUSED_INPUT and B == 1 and E == 1 and x.is_cuda and x.stride(4) == 1
+                   and not (torch.is_grad_enabled() and (x.requires_grad or node_attr.requires_grad)))
+        if fusable and (node_attr.dtype == x.dtype or (norm is not None and x.dtype == torch.float32)):
+            # inference, one member: permute + cat + alignment zeros (+ the input normaliser as a column program) in ONE kernel
             width = T * V + node_attr.shape[1]
-            if x.dtype != torch.float32 and self._prepad(ds):
+            if node_attr.dtype != torch.float32 and self._prepad(ds):
                 width += (-width) % 64 if (-width) % 64 <= 16 and _PAD64 else (-width) % 8
-            return ops.assemble_input(x[0, :, 0], node_attr, width), x_skip
+            if norm is None:
+                return ops.assemble_input(x[0, :, 0], node_attr, width), x[:, self._skip_step, ...], False
+            mul, add = norm.column_program(V)
+            return ops.assemble_input(x[0, :, 0], node_attr, width, mul, add, out_dtype=node_attr.dtype), x[:, self._skip_step, ...], True
+        if norm is not None:  # not fusable: the normaliser's own kernel, then the generic path
+            x = norm.transform(x, in_place=False).to(node_attr.dtype)
+        x_skip = x[:, self._skip_step, ...]  # SkipConnection (layers/residual.py:60-81): last input step
         flat = x.permute(0, 2, 3, 1, 4).reshape(B * E * N, T * V)  # "(batch ensemble grid) (time vars)"
         cols = [flat, node_attr.to(flat.dtype)]
         width = flat.shape[1] + node_attr.shape[1]
@@ -176,7 +184,7 @@ class AnemoiModelEncProcDec(nn.Module):
             if self._pad_zeros is None or self._pad_zeros[0] != key:
                 self._pad_zeros = (key, torch.zeros((flat.shape[0], pad), dtype=flat.dtype, device=flat.device))
             cols.append(self._pad_zeros[1])
-        return torch.cat(cols, dim=-1), x_skip
+        return torch.cat(cols, dim=-1), x_skip, False
 
     def _prepad(self, ds: str) -> bool:
         """The GraphTransformer mappers embed their inputs through PaddedLinear, which accepts rows that already carry the
@@ -195,12 +203,21 @@ class AnemoiModelEncProcDec(nn.Module):
             self._hidden_padded = (key, torch.nn.functional.pad(x, (0, pad)), x)
         return self._hidden_padded[1]
 
-    def _assemble_output(self, x_out: Tensor, x_skip: Tensor, batch_size: int, ensemble_size: int, dtype, ds: str) -> Tensor:
+    def _assemble_output(self, x_out: Tensor, x_skip: Tensor, batch_size: int, ensemble_size: int, dtype, ds: str, norm=None,
+                         skip_is_raw: bool = False, denorm=None) -> Tensor:
+        """``norm`` / ``skip_is_raw``: x_skip is the RAW input and is normalised inside the residual kernel; ``denorm``: the
+        output InputNormalizer whose inverse transform is appended to the column program of the boundings."""
         N = x_out.shape[0] // (batch_size * ensemble_size)
         in_idx, out_idx = getattr(self, f"_in_idx_{ds}"), getattr(self, f"_out_idx_{ds}")
         col_map = getattr(self, f"_col_map_{ds}")
-        if (col_map is not None and batch_size == 1 and ensemble_size == 1 and self.n_step_output == 1 and x_out.is_cuda and x_out.dtype == dtype
-                and x_skip.dtype == dtype and not (torch.is_grad_enabled() and (x_out.requires_grad or x_skip.requires_grad))):
+        fusable = (col_map is not None and batch_size == 1 and ensemble_size == 1 and self.n_step_output == 1 and x_out.is_cuda
+                   and not (torch.is_grad_enabled() and (x_out.requires_grad or x_skip.requires_grad)))
+        if skip_is_raw and not fusable:
+            x_skip, skip_is_raw = norm.transform(x_skip, in_place=False), False
+        if fusable and skip_is_raw and x_skip.dtype == dtype and dtype in (x_out.dtype, torch.float32):
+            mul, add = norm.column_program(x_skip.shape[-1])
+            x_out = ops.assemble_output(x_out, x_skip.reshape(N, -1), col_map, mul, add).view(1, 1, 1, N, -1)
+        elif fusable and x_out.dtype == dtype and x_skip.dtype == dtype:
             # one kernel for cast / residual on the prognostic columns (instead of clone + index_select + index_add_)
             x_out = ops.assemble_output(x_out, x_skip.reshape(N, -1), col_map).view(1, 1, 1, N, -1)
         else:
@@ -208,21 +225,30 @@ class AnemoiModelEncProcDec(nn.Module):
             # SkipConnection._expand_time (layers/residual.py:53-57): the skip is repeated over the output steps
             skip = x_skip.unsqueeze(1).expand(-1, self.n_step_output, -1, -1, -1)
             x_out.index_add_(-1, out_idx, skip.index_select(-1, in_idx).to(dtype))
-        if len(self.boundings[ds]):  # all configured boundings as ONE in-place column program (configuration order)
+        if len(self.boundings[ds]) or denorm is not None:
+            # all configured boundings (configuration order) and, fused, the output de-normalisation as ONE in-place column program
             from ..layers.bounding import apply_program_torch, program_tables
 
             if torch.is_grad_enabled() and x_out.requires_grad:
                 x_out = apply_program_torch(x_out, [op for b in self.boundings[ds] for op in b.program()])
+                if denorm is not None:
+                    x_out = denorm.inverse_transform(x_out, in_place=False)
             else:
-                # the column program and its device tables are built ONCE per (dataset, device): program() of the normalised
-                # boundings reads a registered buffer (.tolist() = a device->host sync, illegal under hipGraph capture)
-                key = (ds, str(x_out.device))
+                # the column program and its device tables are built ONCE per (dataset, device, normaliser state): program() of
+                # the normalised boundings reads a registered buffer (.tolist() = a device->host sync, illegal under hipGraph capture)
+                key = (ds, str(x_out.device), None if denorm is None else (id(denorm), denorm._norm_mul._version, denorm._norm_add._version))
                 if key not in self._bound_tables:
-                    self._bound_tables[key] = program_tables([op for b in self.boundings[ds] for op in b.program()], x_out.device)
+                    prog = [op for b in self.boundings[ds] for op in b.program()]
+                    if denorm is not None:
+                        prog += denorm.inverse_program(x_out.shape[-1])
+                    self._bound_tables[key] = program_tables(prog, x_out.device)
                 ops.bound_columns_(x_out, *self._bound_tables[key])
         return x_out
 
-    def forward(self, x: dict, *, model_comm_group=None, grid_shard_sizes: Optional[dict] = None, **kwargs) -> dict:
+    def forward(self, x: dict, *, model_comm_group=None, grid_shard_sizes: Optional[dict] = None, _fused_norm: Optional[dict] = None,
+                **kwargs) -> dict:
+        """``_fused_norm`` (set by ``predict_step`` only): {dataset: (input normaliser, output normaliser)} - x is then the RAW
+        batch and the output is de-normalised."""
         names = list(x.keys())
         batch_size = x[names[0]].shape[0]
         ensemble_size = x[names[0]].shape[2]
@@ -237,8 +263,9 @@ class AnemoiModelEncProcDec(nn.Module):
         latents, skips, data_latents, data_shards = {}, {}, {}, {}
         for ds in names:
             shard_sizes_data = grid_shard_sizes[ds] if in_out_sharded[ds] else None
-            x_data_latent, x_skip = self._assemble_input(x[ds], batch_size, shard_sizes_data, model_comm_group, ds)
-            skips[ds], data_shards[ds] = x_skip, shard_sizes_data
+            norm_in, norm_out = (_fused_norm or {}).get(ds, (None, None))
+            x_data_latent, x_skip, raw = self._assemble_input(x[ds], batch_size, shard_sizes_data, model_comm_group, ds, norm=norm_in)
+            skips[ds], data_shards[ds] = (x_skip, raw, norm_in, norm_out), shard_sizes_data
             ea, ei, es = self.encoder_graph_provider[ds].get_edges(batch_size=batch_size, model_comm_group=model_comm_group)
             info = BipartiteGraphShardInfo(src_nodes=shard_sizes_data, dst_nodes=shard_sizes_hidden, edges=es)
             x_data_latent, x_latent = self.encoder[ds]((x_data_latent, x_hidden_latent.to(x_data_latent.dtype)), batch_size=batch_size,
@@ -257,5 +284,55 @@ class AnemoiModelEncProcDec(nn.Module):
             info = BipartiteGraphShardInfo(src_nodes=shard_sizes_hidden, dst_nodes=data_shards[ds], edges=es)
             x_out = self.decoder[ds]((x_latent_proc, data_latents[ds]), batch_size=batch_size, shard_info=info, edge_attr=ea,
                                      edge_index=ei, model_comm_group=model_comm_group, keep_x_dst_sharded=in_out_sharded[ds])
-            out[ds] = self._assemble_output(x_out, skips[ds], batch_size, ensemble_size, x[ds].dtype, ds)
+            x_skip, raw, norm_in, norm_out = skips[ds]
+            out[ds] = self._assemble_output(x_out, x_skip, batch_size, ensemble_size, x[ds].dtype, ds, norm=norm_in, skip_is_raw=raw,
+                                            denorm=norm_out)
         return out
+
+    # -- predict_step (models/base.py:303-391) ----------------------------------------------------------------------------
+    @staticmethod
+    def _sole_normalizer(procs, inverse: bool):
+        """The InputNormalizer of a ``Processors`` chain that consists of nothing else (what the model edge can fuse), else None."""
+        from ..preprocessing import InputNormalizer, Processors
+
+        if isinstance(procs, InputNormalizer):
+            return procs
+        if isinstance(procs, Processors) and procs.inverse == inverse and len(procs.processors) == 1:
+            only = next(iter(procs.processors.values()))
+            if isinstance(only, InputNormalizer):
+                return only
+        return None
+
+    def predict_step(self, batch: dict, pre_processors, post_processors, n_step_input: int, model_comm_group=None,
+                     gather_out: bool = True, **kwargs) -> dict:
+        """Pre-process, forward, post-process (reference models/base.py:303-391): ``batch[ds]`` is [batch, time, grid, vars] of
+        RAW data.  When a dataset's pre- / post-processor chains are just the input normaliser, it is fused into the model
+        edges: the transform runs inside the input assembly kernel (and on the skip connection inside the residual kernel),
+        the inverse inside the output column program - no pass of its own over the data."""
+        from ..distributed.primitives import gather_tensor
+
+        with torch.no_grad():
+            names = list(batch.keys())
+            for ds in names:
+                assert len(batch[ds].shape) == 4, (
+                    f"The {ds} input tensor has an incorrect shape: expected a 4-dimensional tensor, got {batch[ds].shape}!")
+            x = {ds: batch[ds][:, 0:n_step_input, None, ...] for ds in names}  # dummy ensemble dimension as 3rd index
+            grid_shard_sizes = None
+            if model_comm_group is not None:
+                grid_shard_sizes = {ds: get_shard_sizes(x[ds], -2, model_comm_group) for ds in names}
+                x = {ds: shard_tensor(x[ds], -2, grid_shard_sizes[ds], model_comm_group) for ds in names}
+            fused = {}
+            for ds in names:
+                pre, post = self._sole_normalizer(pre_processors[ds], False), self._sole_normalizer(post_processors[ds], True)
+                if pre is not None and post is not None and x[ds].is_cuda:
+                    fused[ds] = (pre, post)
+                else:
+                    x[ds] = pre_processors[ds](x[ds], in_place=False)
+            y_hat = self.forward(x, model_comm_group=model_comm_group, grid_shard_sizes=grid_shard_sizes, _fused_norm=fused, **kwargs)
+            for ds in names:
+                if ds not in fused:
+                    y_hat[ds] = post_processors[ds](y_hat[ds], in_place=False)
+            if gather_out and model_comm_group is not None:
+                for ds in names:
+                    y_hat[ds] = gather_tensor(y_hat[ds], -2, grid_shard_sizes[ds], model_comm_group)
+        return y_hat

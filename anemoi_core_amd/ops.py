@@ -685,29 +685,66 @@ def glu_backward(gate_value: Tensor, d_out: Tensor, kind: str) -> Tensor:
     return out
 
 
-def assemble_input(x: Tensor, attrs: Optional[Tensor], width: int) -> Tensor:
-    """x [T, N, V] (time slices of one batch / ensemble member), attrs [N, A] -> [N, width] = [x[0] | ... | x[T-1] | attrs | 0...]."""
-    _dev(x, attrs)
+def assemble_input(x: Tensor, attrs: Optional[Tensor], width: int, col_mul: Optional[Tensor] = None, col_add: Optional[Tensor] = None,
+                   out_dtype: Optional[torch.dtype] = None) -> Tensor:
+    """x [T, N, V] (time slices of one batch / ensemble member), attrs [N, A] -> [N, width] = [x[0] | ... | x[T-1] | attrs | 0...].
+    With ``col_mul`` / ``col_add`` (fp32 [V]) the time / variable columns become x * mul[v] + add[v] (the input normaliser as a
+    column program); ``out_dtype``: the model dtype when x is fp32 data fed to a 16-bit model (default: x's dtype)."""
+    _dev(x, attrs, col_mul, col_add)
     T, N, V = x.shape
     A = 0 if attrs is None else attrs.shape[1]
-    if x.stride(2) != 1 or width < T * V + A or (attrs is not None and (attrs.shape[0] != N or attrs.dtype != x.dtype)):
-        raise ValueError("assemble_input: x must be [T, N, V] with contiguous variables, attrs [N, A] of the same dtype")
-    out = torch.empty((N, width), dtype=x.dtype, device=x.device)
-    ap, lda = _rows(attrs, "attrs", x.dtype)
-    _lib.check(_lib.load().anemoi_assemble_input(x.data_ptr(), x.stride(0), x.stride(1), T, V, ap, lda, A, out.data_ptr(), width, width, N,
-                                                 _dt(x), _stream()), "assemble_input")
+    odt = x.dtype if out_dtype is None else out_dtype
+    if x.stride(2) != 1 or width < T * V + A or (attrs is not None and (attrs.shape[0] != N or attrs.dtype != odt)):
+        raise ValueError("assemble_input: x must be [T, N, V] with contiguous variables, attrs [N, A] of the output dtype")
+    out = torch.empty((N, width), dtype=odt, device=x.device)
+    ap, lda = _rows(attrs, "attrs", odt)
+    if col_mul is None and col_add is None and odt == x.dtype:
+        _lib.check(_lib.load().anemoi_assemble_input(x.data_ptr(), x.stride(0), x.stride(1), T, V, ap, lda, A, out.data_ptr(), width, width, N,
+                                                     _dt(x), _stream()), "assemble_input")
+        return out
+    if (col_mul is None) != (col_add is None):
+        raise ValueError("assemble_input: col_mul and col_add go together")
+    if x.dtype != odt and x.dtype != torch.float32:
+        raise ValueError("assemble_input: x must be in the output dtype or fp32")
+    _lib.check(_lib.load().anemoi_assemble_input_norm(x.data_ptr(), _dt(x), x.stride(0), x.stride(1), T, V, _vec(col_mul, "col_mul", V, torch.float32),
+                                                      _vec(col_add, "col_add", V, torch.float32), ap, lda, A, out.data_ptr(), width, width, N,
+                                                      _DT[odt], _stream()), "assemble_input_norm")
     return out
 
 
-def assemble_output(x_out: Tensor, x_skip: Tensor, col_map: Tensor) -> Tensor:
+def assemble_output(x_out: Tensor, x_skip: Tensor, col_map: Tensor, col_mul: Optional[Tensor] = None, col_add: Optional[Tensor] = None) -> Tensor:
     """out[n, v] = x_out[n, v] + x_skip[n, col_map[v]] (where col_map[v] >= 0); x_out [N, V_out], x_skip [N, V_in] (row
-    stride allowed), col_map int32 [V_out]."""
-    _dev(x_out, x_skip, col_map)
+    stride allowed), col_map int32 [V_out].  With ``col_mul`` / ``col_add`` (fp32 [V_in]) the skip is the RAW input, normalised
+    on the fly (x_skip * mul[m] + add[m]); the result has x_skip's dtype (the model dtype or fp32)."""
+    _dev(x_out, x_skip, col_map, col_mul, col_add)
     N, V = x_out.shape
-    out = torch.empty((N, V), dtype=x_out.dtype, device=x_out.device)
-    (xp, ldx), (sp, lds) = _rows(x_out, "x_out"), _rows(x_skip, "x_skip", x_out.dtype)
-    _lib.check(_lib.load().anemoi_assemble_output(xp, ldx, sp, lds, col_map.data_ptr(), out.data_ptr(), V, N, V, _dt(x_out), _stream()), "assemble_output")
+    out = torch.empty((N, V), dtype=x_skip.dtype, device=x_out.device)
+    (xp, ldx), (sp, lds) = _rows(x_out, "x_out"), _rows(x_skip, "x_skip")
+    if col_mul is None and col_add is None and x_skip.dtype == x_out.dtype:
+        _lib.check(_lib.load().anemoi_assemble_output(xp, ldx, sp, lds, col_map.data_ptr(), out.data_ptr(), V, N, V, _dt(x_out), _stream()), "assemble_output")
+        return out
+    Vin = x_skip.shape[1]
+    _lib.check(_lib.load().anemoi_assemble_output_norm(xp, ldx, _dt(x_out), sp, lds, col_map.data_ptr(), _vec(col_mul, "col_mul", Vin, torch.float32),
+                                                       _vec(col_add, "col_add", Vin, torch.float32), out.data_ptr(), V, N, V, _dt(x_skip), _stream()),
+               "assemble_output_norm")
     return out
+
+
+def affine_columns(x: Tensor, col_mul: Tensor, col_add: Tensor, inverse: bool = False, out: Optional[Tensor] = None) -> Tensor:
+    """Per-variable affine map over the last dimension: x * mul + add, or (x - add) / mul with ``inverse`` (InputNormalizer
+    transform / inverse_transform).  ``out`` may be x itself (in place)."""
+    _dev(x, col_mul, col_add, out)
+    V = x.shape[-1]
+    if not x.is_contiguous():
+        raise ValueError("affine_columns: x must be contiguous")
+    y = torch.empty_like(x) if out is None else out
+    if y.shape != x.shape or y.dtype != x.dtype or not y.is_contiguous():
+        raise ValueError("affine_columns: out must match x")
+    n = x.numel() // V
+    _lib.check(_lib.load().anemoi_affine_columns(x.data_ptr(), V, y.data_ptr(), V, _vec(col_mul, "col_mul", V, torch.float32),
+                                                 _vec(col_add, "col_add", V, torch.float32), 1 if inverse else 0, n, V, _dt(x), _stream()),
+               "affine_columns")
+    return y
 
 
 def bound_columns_(x: Tensor, op_table: Tensor, param_table: Tensor) -> Tensor:

@@ -506,9 +506,96 @@ def gen_variants():
     save("variants.pt", out)
 
 
+def gen_edges():
+    """Model-edge fixtures (scope row f4): the reference's InputNormalizer (preprocessing/normalizer.py), the reference's
+    predict_step around its tiny model (models/base.py:303-391: normalise -> forward -> de-normalise, forcing and diagnostic
+    variables so that input / output / model-output index sets differ) and a graph FILE in PyG's pickle layout."""
+    from omegaconf import DictConfig
+
+    from anemoi.models.data_indices.collection import IndexCollection
+    from anemoi.models.models import AnemoiModelEncProcDec
+    from anemoi.models.preprocessing import Processors
+    from anemoi.models.preprocessing.normalizer import InputNormalizer
+
+    gen = torch.Generator().manual_seed(4242)
+    out = {}
+    # ---- normaliser alone: every method, a remap, forcing + diagnostic variables
+    names = ["a", "b", "c", "d", "e", "f", "g", "h"]
+    n2i = {n: i for i, n in enumerate(names)}
+    data_cfg = {"normalizer": {"default": "mean-std", "remap": {"h": "a"}, "min-max": ["b"], "max": ["c"], "none": ["d"], "std": ["e"]},
+                "forcing": ["d", "e"], "diagnostic": ["g"]}
+    stats = {"mean": torch.randn(8, generator=gen).double().numpy() * 3.0, "stdev": torch.rand(8, generator=gen).double().numpy() * 2.0 + 0.5,
+             "minimum": -torch.rand(8, generator=gen).double().numpy() * 5.0 - 1.0, "maximum": torch.rand(8, generator=gen).double().numpy() * 5.0 + 1.0}
+    cfg = DictConfig({"data": data_cfg})
+    di = IndexCollection(data_config=cfg.data, name_to_index=n2i)
+    nm = InputNormalizer(config=cfg.data.normalizer, data_indices=di, statistics={k: v.copy() for k, v in stats.items()})
+    idx = dict(data_input_full=di.data.input.full.clone(), data_output_full=di.data.output.full.clone(),
+               data_input_name_to_index=dict(di.data.input.name_to_index), data_output_name_to_index=dict(di.data.output.name_to_index),
+               model_input_name_to_index=dict(di.model.input.name_to_index), model_output_name_to_index=dict(di.model.output.name_to_index),
+               model_input_prognostic=di.model.input.prognostic.clone(), model_output_prognostic=di.model.output.prognostic.clone(),
+               model_input_full=di.model.input.full.clone(), model_output_full=di.model.output.full.clone())
+    x_all = 4.0 * torch.randn(3, 5, 8, generator=gen)
+    x_in = 4.0 * torch.randn(3, 5, len(di.data.input.full), generator=gen)
+    x_out = 4.0 * torch.randn(3, 5, len(di.data.output.full), generator=gen)
+    out["normalizer"] = dict(
+        data_config=data_cfg, name_to_index=n2i, statistics={k: torch.as_tensor(v) for k, v in stats.items()}, indices=idx, buffers=_sd(nm),
+        x_all=x_all, t_all=nm.transform(x_all, in_place=False), i_all=nm.inverse_transform(x_all, in_place=False),
+        x_in=x_in, t_in=nm.transform(x_in, in_place=False), x_out=x_out, i_out=nm.inverse_transform(x_out, in_place=False),
+        data_index=[0, 2, 7], t_idx=nm.transform(x_all[..., [0, 2, 7]].contiguous(), in_place=False, data_index=[0, 2, 7]),
+        i_idx=nm.inverse_transform(x_all[..., [0, 2, 7]].contiguous(), in_place=False, data_index=[0, 2, 7]))
+
+    # ---- predict_step of the reference's tiny GraphTransformer model with the normaliser as pre / post processor
+    g = build_synthetic_graph("o8", 3)
+    names = [f"v{i}" for i in range(6)]
+    n2i = {n: i for i, n in enumerate(names)}
+    data_cfg = {"normalizer": {"default": "mean-std", "min-max": ["v1"], "max": ["v2"], "std": ["v4"]}, "forcing": ["v4"], "diagnostic": ["v5"]}
+    stats = {"mean": torch.randn(6, generator=gen).double().numpy(), "stdev": torch.rand(6, generator=gen).double().numpy() + 0.5,
+             "minimum": -torch.rand(6, generator=gen).double().numpy() * 3.0 - 1.0, "maximum": torch.rand(6, generator=gen).double().numpy() * 3.0 + 1.0}
+    cfg = DictConfig({"data": data_cfg})
+    di = IndexCollection(data_config=cfg.data, name_to_index=n2i)
+    torch.manual_seed(77)
+    model = AnemoiModelEncProcDec(model_config=model_config("gt", 64, 2, 4, 8), data_indices={"data": di}, statistics={"data": stats},
+                                  n_step_input=2, n_step_output=1, graph_data=make_hetero(g)).eval()
+    _randomise(model, gen, scale=0.3)
+    nm = InputNormalizer(config=cfg.data.normalizer, data_indices=di, statistics={k: v.copy() for k, v in stats.items()})
+    pre, post = Processors([["normalizer", nm]]), Processors([["normalizer", nm]], inverse=True)
+    batch = 2.0 * torch.randn(1, 3, g.num_data, len(di.data.input.full), generator=gen) + 0.5  # one spare time step: [:, 0:2] is used
+    with torch.no_grad():
+        y = model.predict_step({"data": batch}, {"data": pre}, {"data": post}, 2)["data"]
+        y_norm = model({"data": pre(batch[:, 0:2, None, ...], in_place=False)})["data"]  # the normalised-space output, for diagnosis
+    idx = dict(data_input_full=di.data.input.full.clone(), data_output_full=di.data.output.full.clone(),
+               data_input_name_to_index=dict(di.data.input.name_to_index), data_output_name_to_index=dict(di.data.output.name_to_index),
+               model_input_name_to_index=dict(di.model.input.name_to_index), model_output_name_to_index=dict(di.model.output.name_to_index),
+               model_input_prognostic=di.model.input.prognostic.clone(), model_output_prognostic=di.model.output.prognostic.clone(),
+               model_input_full=di.model.input.full.clone(), model_output_full=di.model.output.full.clone())
+    out["predict_step"] = dict(cfg=dict(kind="gt", num_channels=64, num_layers=2, num_heads=4, trainable=8, n_step_input=2, data_grid="o8", hidden_resolution=3),
+                               data_config=data_cfg, name_to_index=n2i, statistics={k: torch.as_tensor(v) for k, v in stats.items()}, indices=idx,
+                               params=_sd(model), batch=batch, out=y, out_normalised=y_norm)
+    print("predict_step out", tuple(y.shape), float(y.abs().mean()))
+    save("edges.pt", out)
+
+    # ---- a graph FILE as anemoi-graphs writes it: torch.save(HeteroData) (graphs/src/anemoi/graphs/create.py), PyG pickle layout
+    g2 = build_synthetic_graph("o8", 2)
+    hd = rs.PygHeteroData()
+    hd["data"].x = torch.from_numpy(g2.data_latlon)
+    hd["data"].node_type = "ReducedGaussianGridNodes"
+    hd["data"].area_weight = torch.rand(g2.num_data, 1, generator=gen)
+    hd["hidden"].x = torch.from_numpy(g2.hidden_latlon)
+    hd["hidden"].node_type = "TriNodes"
+    for key, ei, ea in ((("data", "to", "hidden"), g2.enc_edge_index, g2.enc_edge_attr), (("hidden", "to", "hidden"), g2.proc_edge_index, g2.proc_edge_attr),
+                        (("hidden", "to", "data"), g2.dec_edge_index, g2.dec_edge_attr)):
+        hd[key].edge_index = torch.from_numpy(ei)
+        hd[key].edge_type = "CutOffEdges"
+        hd[key].edge_length = torch.from_numpy(ea[:, :1].copy())
+        hd[key].edge_dirs = torch.from_numpy(ea[:, 1:].copy())
+    path = os.path.join(HERE, "graph_file.pt")
+    torch.save(hd, path)
+    print(f"graph_file.pt: {os.path.getsize(path)/1024:.0f} KiB")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ["conv", "blocks", "proc", "model", "grads", "sharding", "variants"]
+    which = sys.argv[1:] or ["conv", "blocks", "proc", "model", "grads", "sharding", "variants", "edges"]
     if "conv" in which:
         gen_conv()
     if "blocks" in which:
@@ -523,3 +610,5 @@ if __name__ == "__main__":
         gen_sharding()
     if "variants" in which:
         gen_variants()
+    if "edges" in which:
+        gen_edges()

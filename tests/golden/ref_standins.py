@@ -175,6 +175,69 @@ class _HeteroData:
         return list(self._edges.items())
 
 
+# --------------------------------------------------------------------------- PyG pickle layout (graph FILES only)
+# What `torch.save(HeteroData)` puts on disk (torch-geometric >= 2.3, restated from its published source): the classes
+# below have the same module / class names and the same __dict__ layout, so a file written through them unpickles like a
+# file written by the real package.  They are used ONLY to write the graph-file fixture (make_golden.py: gen_edges).
+class _PygBaseStorage:
+    """torch_geometric.data.storage.BaseStorage: attributes live in ``_mapping``; ``_parent`` is pickled dereferenced."""
+
+    def __init__(self, _parent=None, _key=None):
+        self.__dict__["_mapping"] = {}
+        if _parent is not None:
+            self.__dict__["_parent"] = _parent
+        if _key is not None:
+            self.__dict__["_key"] = _key
+
+    def __setattr__(self, k, v):
+        if k.startswith("_"):
+            self.__dict__[k] = v
+        else:
+            self.__dict__["_mapping"][k] = v
+
+
+class _PygNodeStorage(_PygBaseStorage):
+    pass
+
+
+class _PygEdgeStorage(_PygBaseStorage):
+    pass
+
+
+class _PygDataTensorAttr:
+    pass
+
+
+class _PygDataEdgeAttr:
+    pass
+
+
+class _PygHeteroData:
+    """torch_geometric.data.hetero_data.HeteroData: the five __dict__ entries a pickled instance carries."""
+
+    def __init__(self):
+        d = self.__dict__
+        d["_edge_attr_cls"] = _PygDataEdgeAttr
+        d["_tensor_attr_cls"] = _PygDataTensorAttr
+        d["_global_store"] = _PygBaseStorage(_parent=self)
+        d["_node_store_dict"] = {}
+        d["_edge_store_dict"] = {}
+
+    def __getitem__(self, key):
+        if isinstance(key, tuple):
+            table, cls = self.__dict__["_edge_store_dict"], _PygEdgeStorage
+        else:
+            table, cls = self.__dict__["_node_store_dict"], _PygNodeStorage
+        if key not in table:
+            table[key] = cls(_parent=self, _key=key)
+        return table[key]
+
+
+def _name_as(cls, module, name):
+    cls.__module__, cls.__name__, cls.__qualname__ = module, name, name
+    return cls
+
+
 # --------------------------------------------------------------------------- hydra / omegaconf / anemoi.utils
 class _DotDict(dict):
     """anemoi.utils.config.DotDict: dict with attribute access, recursive."""
@@ -267,6 +330,15 @@ def install(extra_paths: Tuple[str, ...] = ()) -> None:
     utils_m.sparse = sparse_m
     data_m = mod("torch_geometric.data")
     data_m.HeteroData = _HeteroData
+    # the pickle-layout classes of graph FILES, under the module paths the real package pickles them with
+    hd_m, st_m, dd_m = mod("torch_geometric.data.hetero_data"), mod("torch_geometric.data.storage"), mod("torch_geometric.data.data")
+    hd_m.HeteroData = _name_as(_PygHeteroData, "torch_geometric.data.hetero_data", "HeteroData")
+    st_m.BaseStorage = _name_as(_PygBaseStorage, "torch_geometric.data.storage", "BaseStorage")
+    st_m.NodeStorage = _name_as(_PygNodeStorage, "torch_geometric.data.storage", "NodeStorage")
+    st_m.EdgeStorage = _name_as(_PygEdgeStorage, "torch_geometric.data.storage", "EdgeStorage")
+    dd_m.DataTensorAttr = _name_as(_PygDataTensorAttr, "torch_geometric.data.data", "DataTensorAttr")
+    dd_m.DataEdgeAttr = _name_as(_PygDataEdgeAttr, "torch_geometric.data.data", "DataEdgeAttr")
+    data_m.hetero_data, data_m.storage, data_m.data = hd_m, st_m, dd_m
     tg.typing, tg.nn, tg.utils, tg.data = typing_m, nn_m, utils_m, data_m
 
     hy = mod("hydra")
@@ -316,3 +388,4 @@ def install(extra_paths: Tuple[str, ...] = ()) -> None:
 
 DotDict = _DotDict
 HeteroData = _HeteroData
+PygHeteroData = _PygHeteroData

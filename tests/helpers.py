@@ -23,3 +23,19 @@ def build_model_from_fixture(case):
 
 def lk():
     return load_layer_kernels()
+
+
+def indices_from_fixture(idx):
+    """An IndexCollection-shaped object (what the reference's `data_indices[dataset]` offers to the model and to the
+    normaliser) from the index tensors / name maps a fixture stores (tests/golden/make_golden.py: gen_edges)."""
+    from types import SimpleNamespace
+
+    grp = lambda full, n2i, **kw: IndexGroup(full=full, name_to_index=n2i, **kw)  # noqa: E731
+    return SimpleNamespace(
+        data=SimpleNamespace(input=grp(idx["data_input_full"], idx["data_input_name_to_index"]),
+                             output=grp(idx["data_output_full"], idx["data_output_name_to_index"])),
+        model=SimpleNamespace(input=grp(idx["model_input_full"], idx["model_input_name_to_index"], prognostic=idx["model_input_prognostic"]),
+                              output=grp(idx["model_output_full"], idx["model_output_name_to_index"], prognostic=idx["model_output_prognostic"],
+                                         diagnostic=[]),
+                              _forcing=[]),
+        name_to_index=idx["data_input_name_to_index"])
