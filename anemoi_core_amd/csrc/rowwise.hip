@@ -359,8 +359,12 @@ __global__ void affine_columns_kernel(const T* __restrict__ x, int64_t ldx, T* _
   if (inverse) {
     o = to_float(from_float<T>(v - add[c])) / mul[c];  // subtract_ then div_: two roundings in T like torch's in-place ops
   } else {
-    o = to_float(from_float<T>(v * mul[c]));
-    o = o + add[c];
+    if constexpr (sizeof(T) == 4) {
+      o = mul_then_add(v, mul[c], add[c]);  // two fp32 roundings, never an FMA
+    } else {
+      o = to_float(from_float<T>(v * mul[c]));  // mul_ rounds to T, then add_ rounds again
+      o = o + add[c];
+    }
   }
   y[(int64_t)r * ldy + c] = from_float<T>(o);
 }

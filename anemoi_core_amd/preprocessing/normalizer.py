@@ -137,13 +137,13 @@ class InputNormalizer(BasePreprocessor):
     # ---------------------------------------------------------------------------------- reference API
     def transform(self, x: Tensor, in_place: bool = True, data_index=None) -> Tensor:
         """x [..., nvars] -> x * mul + add (in place unless told otherwise)."""
-        return self._apply(x, in_place, data_index, inverse=False)
+        return self._affine(x, in_place, data_index, inverse=False)
 
     def inverse_transform(self, x: Tensor, in_place: bool = True, data_index=None) -> Tensor:
         """x [..., nvars | nvars_pred] -> (x - add) / mul."""
-        return self._apply(x, in_place, data_index, inverse=True)
+        return self._affine(x, in_place, data_index, inverse=True)
 
-    def _apply(self, x: Tensor, in_place: bool, data_index, inverse: bool) -> Tensor:
+    def _affine(self, x: Tensor, in_place: bool, data_index, inverse: bool) -> Tensor:
         mul, add = self._select(x.shape[-1], inverse, data_index)
         if x.is_cuda and x.dtype in (torch.float32, torch.bfloat16, torch.float16) and x.is_contiguous():
             from .. import ops
