@@ -57,6 +57,7 @@ struct LinArgs {
   void* y_pre = nullptr;  // training, with act = GELU on the DMA-ring kernels: the pre-activation is stored here as well (saves
   int64_t ldy_pre = 0;    // the backward a recomputing GEMM)
   int tail_rows = 0;  // big-tile kernel only: rows [n_rows, n_rows + tail_rows) are computed on the VALU, a column per wave
+  int fast_epi = 1;   // interior tiles take mfma_epilogue_fast (ANEMOI_GEMM_FAST_EPI=0: the generic epilogue everywhere, for A/B runs)
 };
 
 // ---------------------------------------------------------------------------------------------- generic (VALU)
@@ -348,9 +349,103 @@ enum : int { EPI_RES = 1, EPI_GATHER = 2, EPI_GELU = 4, EPI_STATS = 8, EPI_LNFOL
 // (guide T21).  Interior tiles issue exactly kEpiStores = 8 stores per wave.
 constexpr int kEpiStores = 8;
 
+// Fast path of the epilogue below for INTERIOR tiles (every row and column of the tile exists) with bias / residual / gather /
+// GELU only - the hot case.  The generic epilogue carries, per 16-byte store, the predicates of ragged tiles, the 4-column tail
+// of O % 8 == 4, the fp32-atomic split-K branch and 64-bit address products: measured on MI355X its on-chip work (stores
+// removed) was 11-13 us of a 35 us [10242 x 512] -> 2048 GEMM and 17 us with GELU, against 22 us for the whole kernel without
+// an epilogue.  Here: no predicates, one 64-bit base per lane + uniform row offsets, and NO waits between a band's LDS writes
+// and its read-back (a wave's LDS instructions execute in order, so the read-back sees the writes; only the compiler has
+// to be kept from reordering them) - the transposition of band mi+1 overlaps the arithmetic and stores of band mi.
+template <typename T, int EPI, int MI>
+__device__ __forceinline__ void mfma_epilogue_fast(const LinArgs& a, f32x4 (&acc)[MI][4], int m0, int n0, int wr, int wc, int lane,
+                                                   unsigned char* epi) {
+  using V8 = Vec<T, 8>;
+  const int cp = lane & 7;
+  const int nc = n0 + wc * 64 + cp * 8;
+  const int mrow0 = m0 + wr * (16 * MI) + (lane >> 3);
+  float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (a.bias != nullptr) {
+    const V8 braw = *reinterpret_cast<const V8*>((const T*)a.bias + nc);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) bv[r] = to_float(braw.v[r]);
+  }
+  T* __restrict__ ylane = (T*)a.y + (int64_t)mrow0 * a.ldy + nc;
+  const T* __restrict__ rlane = (EPI & EPI_RES) ? (const T*)a.residual + (int64_t)mrow0 * a.ldr + nc : nullptr;
+  // LDS addresses: write = MFMA layout (row lane & 15, 16-byte slot ni * 4 + lane >> 4, 32-byte pairs XOR-swizzled by the row),
+  // read-back = 8 consecutive columns per lane, 8 lanes per row
+  const int wrow = lane & 15;
+  unsigned char* wbase = epi + wrow * 256;
+  int wphys[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int slot = ni * 4 + (lane >> 4);
+    wphys[ni] = ((((slot >> 1) ^ (wrow & 7)) << 1) | (slot & 1)) * 16;
+  }
+  const unsigned char* rsrc[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int row = it * 8 + (lane >> 3);
+    rsrc[it] = epi + row * 256 + ((cp ^ (row & 7)) << 5);
+  }
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    V8 rv[2], t1[2], t2[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      rv[it] = V8{};
+      t1[it] = V8{};
+      t2[it] = V8{};
+      if constexpr ((EPI & EPI_RES) != 0) rv[it] = *reinterpret_cast<const V8*>(rlane + (int64_t)(mi * 16 + it * 8) * a.ldr);
+      if constexpr ((EPI & EPI_GATHER) != 0) {
+        const int m = mrow0 + mi * 16 + it * 8;
+        t1[it] = *reinterpret_cast<const V8*>((const T*)a.g1 + (int64_t)a.idx1[m] * a.ldg1 + nc);
+        if (a.g2 != nullptr) t2[it] = *reinterpret_cast<const V8*>((const T*)a.g2 + (int64_t)a.idx2[m] * a.ldg2 + nc);
+      }
+    }
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) *reinterpret_cast<f32x4*>(wbase + wphys[ni]) = acc[mi][ni];
+    asm volatile("" ::: "memory");  // compiler barrier only: the LDS executes a wave's instructions in order
+    f32x4 c[2][2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      c[it][0] = *reinterpret_cast<const f32x4*>(rsrc[it]);
+      c[it][1] = *reinterpret_cast<const f32x4*>(rsrc[it] + 16);
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      float vv[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) vv[r] = c[it][r >> 2][r & 3] + bv[r];
+      if constexpr ((EPI & EPI_GATHER) != 0) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) vv[r] += to_float(t1[it].v[r]) + to_float(t2[it].v[r]);
+      }
+      if constexpr ((EPI & EPI_GELU) != 0) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) vv[r] = gelu_fast(vv[r]);
+      }
+      if constexpr ((EPI & EPI_RES) != 0) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) vv[r] += to_float(rv[it].v[r]);
+      }
+      V8 o8;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) o8.v[r] = from_float<T>(vv[r]);
+      *reinterpret_cast<V8*>(ylane + (int64_t)(mi * 16 + it * 8) * a.ldy) = o8;
+    }
+  }
+}
+
 template <typename T, int EPI, int MI = 4>
 __device__ __forceinline__ void mfma_epilogue_band(const LinArgs& a, f32x4 (&acc)[MI][4], int m0, int n0, int wr, int wc,
                                                    int lane, unsigned char* epi, bool interior, const float* ln_rows = nullptr) {
+  if constexpr ((EPI & ~(EPI_RES | EPI_GATHER | EPI_GELU)) == 0) {
+    if (interior && !a.f32_atomic && a.fast_epi) {  // wave-uniform: one branch per tile
+      mfma_epilogue_fast<T, EPI, MI>(a, acc, m0, n0, wr, wc, lane, epi);
+      return;
+    }
+  }
   const T* __restrict__ bias = (const T*)a.bias;
   T* __restrict__ y = (T*)a.y;
   using V8 = Vec<T, 8>;
@@ -727,109 +822,6 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void linear_mfma_persistent_kernel
   }
 }
 
-// ---------------------------------------------------------------------------------------------- small M: K split over waves
-// Few output tiles (one rank's rows of a sharded mesh, small meshes): a lone 64 x 128 tile worked by two waves walks its
-// K-loop at ~0.6 us per 64-wide step (DMA issue, fragment reads and 32 MFMAs serialised in each wave), so a K = 2048 GEMM on
-// 1.3 k rows takes 23 us on a mostly idle chip.  Here the tile gets 8 waves = 4 K-groups x 2 column halves: a stage holds 128
-// K elements, group kg multiplies the 32-wide block kg of every stage (16 MFMAs per wave and stage, 6 DMA pieces per wave),
-// and the four partial accumulators are added through LDS in group order (deterministic) before the usual epilogue.
-//   LDS stage = [64 + 128 rows][256 B], 16-byte slots XOR-swizzled with (row & 15): conflict-free fragment ds_read_b128 (16
-//   lanes = 16 rows of one slot column) while a DMA piece stays lane-linear (4 rows x 16 slots, the lane fetches the slot that
-//   belongs at its position).
-constexpr int SK = 128, SM = 64, SN = 128, kSStages = 3;
-constexpr int kSRow = SK * 2, kSA = SM * kSRow, kSStage = (SM + SN) * kSRow;
-
-template <typename T, int EPI>
-__global__ __launch_bounds__(512, 1) void linear_mfma_splitwave_kernel(LinArgs a, int tiles_n) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kg = wave >> 1, wc = wave & 1;
-  const int m0 = (blockIdx.x / tiles_n) * SM, n0 = (blockIdx.x % tiles_n) * SN;
-  const int nk = a.K1 / SK;
-  const uint32_t smem_l = (uint32_t)(size_t)(lds_void_t*)smem;
-
-  // DMA: 16 A pieces + 32 W pieces (4 rows x 256 B) per stage, 6 per wave
-  const int pr = lane >> 4, pos = lane & 15;
-  const char* src_row[6];
-  uint32_t dst_off[6];
-#pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    const int p = wave * 6 + j;
-    const bool is_a = p < 16;
-    const int row_t = (is_a ? p : p - 16) * 4 + pr;
-    const int slot = pos ^ (row_t & 15);
-    const int64_t row_g = is_a ? min(m0 + row_t, a.n_rows - 1) : min(n0 + row_t, a.O - 1);  // clamped rows are never stored
-    src_row[j] = (is_a ? (const char*)a.x + row_g * a.ldx * 2 : (const char*)a.w + row_g * a.ldw * 2) + slot * 16;
-    dst_off[j] = (is_a ? 0 : kSA) + (is_a ? p : p - 16) * 1024;
-  }
-  auto issue = [&](int kt) {
-    const uint32_t base = smem_l + (kt % kSStages) * kSStage;
-#pragma unroll
-    for (int j = 0; j < 6; ++j)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(src_row[j] + (int64_t)kt * kSRow), (lds_void_t*)(size_t)(base + dst_off[j]), 16, 0, 0);
-  };
-
-  // fragments: row (lane & 15) of every 16-row block, logical slot 4 kg + (lane >> 4)
-  const int frow = lane & 15;
-  const int fphys = ((kg * 4 + (lane >> 4)) ^ frow) << 4;
-  const int a_rd = frow * kSRow + fphys;
-  const int w_rd = kSA + (wc * 64 + frow) * kSRow + fphys;
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll
-  for (int p = 0; p < kSStages - 1; ++p)
-    if (p < nk) issue(p);
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + kSStages - 2 < nk) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kSStages - 2) * 6) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();  // stage kt complete for every wave; stage kt-1 no longer read by anybody
-    if (kt + kSStages - 1 < nk) issue(kt + kSStages - 1);
-    const unsigned char* st = smem + (kt % kSStages) * kSStage;
-    frag8 fa[4], fw[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      fa[i] = *reinterpret_cast<const frag8*>(st + a_rd + i * 16 * kSRow);
-      fw[i] = *reinterpret_cast<const frag8*>(st + w_rd + i * 16 * kSRow);
-    }
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16<T>(fw[ni], fa[mi], acc[mi][ni]);
-  }
-
-  // add the four K-groups in group order; 16 KiB of LDS per non-leading wave, 4 KiB epilogue bands behind them
-  __syncthreads();
-  if (kg > 0) {
-    f32x4* dst = reinterpret_cast<f32x4*>(smem + (wave - 2) * 16384) + lane;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) dst[(i * 4 + j) * 64] = acc[i][j];
-  }
-  __syncthreads();
-  if (kg == 0) {
-#pragma unroll
-    for (int gsrc = 1; gsrc < 4; ++gsrc) {
-      const f32x4* src = reinterpret_cast<const f32x4*>(smem + ((gsrc - 1) * 2 + wc) * 16384) + lane;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] += src[(i * 4 + j) * 64];
-    }
-    const bool interior = (m0 + SM <= a.n_rows) && (n0 + SN <= a.O);
-    mfma_epilogue_band<T, EPI>(a, acc, m0, n0, 0, wc, lane, smem + 6 * 16384 + wc * 4096, interior);
-  }
-}
-
-
 // ---------------------------------------------------------------------------------------------- tail rows
 // A handful of rows (the 2 rows by which an icosphere's 10 * 4^r + 2 nodes exceed a multiple of the big tile): one wave
 // per output column, lanes split K in 16-byte chunks, fp32 dot product + butterfly, lane 0 applies the epilogue.
@@ -888,6 +880,138 @@ __device__ __forceinline__ void tail_rows_valu(const LinArgs& a, int m_begin, in
   }
 }
 
+// ---------------------------------------------------------------------------------------------- small M: K split over waves
+// Few output tiles (one rank's rows of a sharded mesh, small meshes): a lone 64 x 128 tile worked by two waves walks its
+// K-loop at ~0.6 us per 64-wide step (DMA issue, fragment reads and 32 MFMAs serialised in each wave), so a K = 2048 GEMM on
+// 1.3 k rows takes 23 us on a mostly idle chip.  Here the tile gets 8 waves = 4 K-groups x 2 column halves: a stage holds 128
+// K elements, group kg multiplies the 32-wide block kg of every stage (16 MFMAs per wave and stage, 6 DMA pieces per wave),
+// and the four partial accumulators are added through LDS in group order (deterministic) before the usual epilogue.
+//   LDS stage = [64 + 128 rows][256 B], 16-byte slots XOR-swizzled with (row & 15): conflict-free fragment ds_read_b128 (16
+//   lanes = 16 rows of one slot column) while a DMA piece stays lane-linear (4 rows x 16 slots, the lane fetches the slot that
+//   belongs at its position).
+constexpr int SK = 128, SM = 64, SN = 128, kSStages = 3;
+constexpr int kSRow = SK * 2;
+
+// Generalised: (16 MI WR) x 128 output tile, 8 waves = KG K-groups x WR row groups x 2 column halves, every wave an (16 MI) x 64
+// sub-tile over its 128 / KG slice of each 128-wide K stage; STAGES-deep DMA ring of [(16 MI WR) + 128 rows][256 B].
+//   <MI 4, WR 1, KG 4, 3 stages>  64 x 128: few tiles (small M), see above.
+//   <MI 5, WR 2, KG 2, 2 stages> 160 x 128: the NARROW outputs of the hot path (projection and MLP-2: O = 512).  On the 256 x 128
+//       / 192 x 128 ring kernels these walk a 64-wide K-step in ~1.0 us (40-48 KiB of operands, 2 barriers) - a quarter of the
+//       rate the LDS-DMA path reaches (tools/dma_rate_probe.hip: 72 KiB in 0.7 us) - because every step pays the fixed price of
+//       its waits and barriers.  128-wide stages halve the number of steps, and [10240 x K] -> 512 is exactly 64 x 4 = 256 such
+//       tiles = one per CU (the 2 rows beyond 64 x 160 of an icosphere mesh ride on the VALU, as in the big-tile kernel).
+template <typename T, int EPI, int MI, int WR, int KG, int STAGES>
+__global__ __launch_bounds__(512, 1) void linear_mfma_splitwave_kernel(LinArgs a, int tiles_n, int num_tiles) {
+  static_assert(KG * WR * 2 == 8, "8 waves");
+  constexpr int TM = 16 * MI * WR;                 // tile rows
+  constexpr int kA = TM * kSRow, kStage = (TM + SN) * kSRow;
+  constexpr int kPieces = (TM + SN) / 4;           // 1-KiB DMA pieces (4 rows x 256 B) per stage
+  static_assert(kPieces % 8 == 0, "pieces must divide evenly over the 8 waves");
+  constexpr int kPPW = kPieces / 8;
+  constexpr int kKB = 4 / KG;                      // 32-wide k-blocks of a stage per K-group
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave & 1, wr = (wave >> 1) % WR, kg = (wave >> 1) / WR;
+  int id = blockIdx.x;
+  {  // XCD-aware bijective remap: the column tiles of a row panel run on one XCD (the A panel is fetched into one L2)
+    const int q = num_tiles >> 3, r = num_tiles & 7, xcd = id & 7, pos = id >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+  }
+  const int m0 = (id / tiles_n) * TM, n0 = (id % tiles_n) * SN;
+  const int nk = a.K1 / SK;
+  const uint32_t smem_l = (uint32_t)(size_t)(lds_void_t*)smem;
+
+  // DMA: TM / 4 A pieces + 32 W pieces (4 rows x 256 B) per stage, kPPW per wave
+  const int pr = lane >> 4, pos = lane & 15;
+  const char* src_row[kPPW];
+  uint32_t dst_off[kPPW];
+#pragma unroll
+  for (int j = 0; j < kPPW; ++j) {
+    const int p = wave * kPPW + j;
+    const bool is_a = p < TM / 4;
+    const int row_t = (is_a ? p : p - TM / 4) * 4 + pr;
+    const int slot = pos ^ (row_t & 15);
+    const int64_t row_g = is_a ? min(m0 + row_t, a.n_rows - 1) : min(n0 + row_t, a.O - 1);  // clamped rows are never stored
+    src_row[j] = (is_a ? (const char*)a.x + row_g * a.ldx * 2 : (const char*)a.w + row_g * a.ldw * 2) + slot * 16;
+    dst_off[j] = (is_a ? 0 : kA) + (is_a ? p : p - TM / 4) * 1024;
+  }
+  auto issue = [&](int kt) {
+    const uint32_t base = smem_l + (kt % STAGES) * kStage;
+#pragma unroll
+    for (int j = 0; j < kPPW; ++j)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(src_row[j] + (int64_t)kt * kSRow), (lds_void_t*)(size_t)(base + dst_off[j]), 16, 0, 0);
+  };
+#pragma unroll
+  for (int p = 0; p < STAGES - 1; ++p)
+    if (p < nk) issue(p);
+  // the tail rows (a few rows beyond a multiple of the tile height) ride in the shadow of the first stages' flight time
+  if (a.tail_rows > 0) tail_rows_valu<T, false>(a, a.n_rows, a.n_rows + a.tail_rows, (int)blockIdx.x * 8 + wave, (int)gridDim.x * 8, lane);
+
+  // fragments: row (lane & 15) of every 16-row block, logical slot (kg kKB + kb) 4 + (lane >> 4)
+  const int frow = lane & 15;
+  int a_rd[kKB], w_rd[kKB];
+#pragma unroll
+  for (int kb = 0; kb < kKB; ++kb) {
+    const int fphys = (((kg * kKB + kb) * 4 + (lane >> 4)) ^ frow) << 4;
+    a_rd[kb] = (wr * 16 * MI + frow) * kSRow + fphys;
+    w_rd[kb] = kA + (wc * 64 + frow) * kSRow + fphys;
+  }
+
+  f32x4 acc[MI][4];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + STAGES - 2 < nk) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * kPPW) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();  // stage kt complete for every wave; stage kt-1 no longer read by anybody
+    if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1);
+    const unsigned char* st = smem + (kt % STAGES) * kStage;
+#pragma unroll
+    for (int kb = 0; kb < kKB; ++kb) {
+      frag8 fw[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fw[i] = *reinterpret_cast<const frag8*>(st + w_rd[kb] + i * 16 * kSRow);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const frag8 fa = *reinterpret_cast<const frag8*>(st + a_rd[kb] + mi * 16 * kSRow);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16<T>(fw[ni], fa, acc[mi][ni]);
+      }
+    }
+  }
+
+  // add the K-groups in group order (deterministic): MI KiB x 4 of LDS per non-leading wave, 4 KiB epilogue bands behind them
+  constexpr int kAccBytes = MI * 4 * 1024;
+  __syncthreads();
+  if (kg > 0) {
+    f32x4* dst = reinterpret_cast<f32x4*>(smem + (wave - 2 * WR) * kAccBytes) + lane;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dst[(i * 4 + j) * 64] = acc[i][j];
+  }
+  __syncthreads();
+  if (kg == 0) {
+#pragma unroll
+    for (int gsrc = 1; gsrc < KG; ++gsrc) {
+      const f32x4* src = reinterpret_cast<const f32x4*>(smem + (((gsrc - 1) * WR + wr) * 2 + wc) * kAccBytes) + lane;
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += src[(i * 4 + j) * 64];
+    }
+    const bool interior = (m0 + TM <= a.n_rows) && (n0 + SN <= a.O);
+    mfma_epilogue_band<T, EPI, MI>(a, acc, m0, n0, wr, wc, lane, smem + (KG - 1) * WR * 2 * kAccBytes + (wr * 2 + wc) * 4096, interior);
+  }
+}
+
+
 // ---------------------------------------------------------------------------------------------- big-tile kernel
 // (32*MI) x 256 output tile per 8-wave workgroup, 2 (M) x 4 (N) waves of (16*MI) x 64.  Why: with every CU streaming,
 // the LDS-DMA path sustains only ~20-25 B/clk/CU next to running MFMAs (12-13 TB/s over the chip; the 256 x 128 kernel
@@ -906,7 +1030,7 @@ __global__ __launch_bounds__(512, 1) void linear_mfma_bigtile_kernel(LinArgs a, 
   constexpr int kPPW = kAPW + kWPW;
   constexpr int kStageBytes = (TBM + TBN) * BK * 2;
   constexpr int kStores = 2 * MI;  // stores per wave of an interior epilogue
-  static_assert(kPPW <= MI, "one DMA piece per 16-row band of the first K-half");
+  static_assert(kPPW <= 2 * MI, "one DMA piece per 16-row band of a K-step");
   static_assert(kPPW + kStores <= 63, "vmcnt is a 6-bit counter");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2][A tile | W tile] [1 KiB dummy]
   // LDS destinations of the DMA as 32-bit LDS addresses (no flat -> local pointer casts on the issue path)
@@ -1073,7 +1197,7 @@ __global__ __launch_bounds__(512, 1) void linear_mfma_bigtile_kernel(LinArgs a, 
           const frag8 fa = *reinterpret_cast<const frag8*>(st + a_rd[ks] + mi * 16 * BK * 2);
 #pragma unroll
           for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16<T>(fw[ni], fa, acc[mi][ni]);  // D^T tile: rows n, cols m
-          if (ks == 0 && mi < kPPW) issue_piece(mi);
+          if (ks * MI + mi < kPPW) issue_piece(ks * MI + mi);
         }
       }
       end_issue();
@@ -1137,16 +1261,20 @@ static int launch_persistent_wm(const LinArgs& a, hipStream_t st) {
   return check_launch("linear_mfma_persistent_kernel");
 }
 
-template <typename T, int EPI>
+template <typename T, int EPI, int MI = 4, int WR = 1, int KG = 4, int STAGES = kSStages>
 static int launch_splitwave(const LinArgs& a, hipStream_t st) {
-  constexpr int smem_bytes = kSStages * kSStage;  // 144 KiB (the reduction / epilogue staging reuses it)
+  constexpr int TM = 16 * MI * WR;
+  constexpr int ring = STAGES * (TM + SN) * kSRow;
+  constexpr int fin = (KG - 1) * WR * 2 * MI * 4 * 1024 + WR * 2 * 4096;  // K-group sums + epilogue bands (reuse the ring)
+  constexpr int smem_bytes = ring > fin ? ring : fin;
+  static_assert(smem_bytes <= 160 * 1024, "LDS");
   static PerDeviceOnce attr_once;
   if (attr_once.first()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_mfma_splitwave_kernel<T, EPI>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_mfma_splitwave_kernel<T, EPI, MI, WR, KG, STAGES>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
   }
-  const int tm = (a.n_rows + SM - 1) / SM, tn = (a.O + SN - 1) / SN;
-  hipLaunchKernelGGL((linear_mfma_splitwave_kernel<T, EPI>), dim3(tm * tn), dim3(512), smem_bytes, st, a, tn);
+  const int tm = (a.n_rows + TM - 1) / TM, tn = (a.O + SN - 1) / SN;
+  hipLaunchKernelGGL((linear_mfma_splitwave_kernel<T, EPI, MI, WR, KG, STAGES>), dim3(tm * tn), dim3(512), smem_bytes, st, a, tn, tm * tn);
   return check_launch("linear_mfma_splitwave_kernel");
 }
 
@@ -1192,7 +1320,32 @@ static int launch_persistent(const LinArgs& a, hipStream_t st) {
     LinArgs m = a;
     m.n_rows = main_rows;
     m.tail_rows = split ? rem : 0;
+    // Up to one round of 320 x 256 tiles: every CU ends its only tile at the same moment and the whole output (42 MB at
+    // [10242 x 512] -> 2048) is written behind the last K-step: ~8 us at the ~5 TB/s HBM takes writes, with nothing to overlap
+    // (tools/gemm_phase_timing.py).  160 x 256 tiles instead: two per CU, the first tile's output drains under the second
+    // tile's K-loop, whose rate is set by the MFMAs (power-limited clock: 1.9 us per 320-row K-step on random data against
+    // 0.7 us for its DMA, tools/dma_rate_probe.hip), not by the 44 % extra operand bytes.
+    static const int half_mi = [] { const char* e = getenv("ANEMOI_GEMM_BIG_MI"); return e ? atoi(e) : 5; }();
+    const int64_t t320 = (int64_t)((main_rows + 319) / 320) * ((a.O + 255) / 256);
+    if (half_mi == 5 && t320 <= 256 && main_rows % 160 == 0) return launch_bigtile<T, EPI, 5>(m, st);
     return launch_bigtile<T, EPI, 10>(m, st);
+  }
+  // narrow outputs with a long K in ONE round of 160 x 128 tiles (MLP-2 of the hidden mesh: [10242 x 2048] -> 512 = 64 x 4 tiles + 2
+  // tail rows): 128-wide K stages, K split over two wave groups (linear_mfma_splitwave_kernel<.., 5, 2, 2, 2>).  Measured on
+  // MI355X: 33.3 us against 34.5 on the 192 x 128 ring kernel; at K = 512 (projection) it is 1.2 us SLOWER, hence K >= 1024.
+  if constexpr ((EPI & (EPI_STATS | EPI_LNFOLD | EPI_PRE)) == 0) {
+    static const bool narrow = [] { const char* e = getenv("ANEMOI_GEMM_NARROW"); return !(e && e[0] == '0'); }();
+    constexpr int TM = 160;
+    const int rem160 = a.n_rows % TM;
+    const bool split160 = rem160 > 0 && rem160 <= 32 && a.n_rows > TM;
+    const int rows160 = split160 ? a.n_rows - rem160 : a.n_rows;
+    const int64_t t160 = (int64_t)((rows160 + TM - 1) / TM) * ((a.O + SN - 1) / SN);
+    if (narrow && t160 > 128 && t160 <= 256 && a.K2 == 0 && a.K1 >= 1024 && a.K1 % SK == 0 && a.splits == 1 && !a.f32_atomic && !big) {
+      LinArgs m = a;
+      m.n_rows = rows160;
+      m.tail_rows = split160 ? rem160 : 0;
+      return launch_splitwave<T, EPI, 5, 2, 2, 2>(m, st);
+    }
   }
   // few tiles (small M, e.g. one rank's rows of a sharded mesh): 64 x 128 tiles on more CUs; the K-loop of a lone tile
   // is bound by the ~40 cycles a CU needs per 1-KiB LDS-DMA piece, i.e. by the tile's operand bytes, like the model says
@@ -1349,6 +1502,8 @@ static int linear_fwd_impl(const void* x, int64_t ldx, int32_t K1, const void* x
   ANEMOI_REQUIRE((g1 == nullptr) == (idx1 == nullptr) && (g2 == nullptr) == (idx2 == nullptr), "linear_fwd: gather term needs both table and index");
   ANEMOI_REQUIRE(act == ANEMOI_ACT_NONE || act == ANEMOI_ACT_GELU, "linear_fwd: unknown activation %d", (int)act);
   LinArgs a{x, ldx, K1, x2, ldx2, K2, w, ldw, bias, g1, ldg1, idx1, g2, ldg2, idx2, residual, ldr, y, ldy, n_rows, O, (int)act};
+  static const int fast_epi = [] { const char* e = getenv("ANEMOI_GEMM_FAST_EPI"); return (e && e[0] == '0') ? 0 : 1; }();
+  a.fast_epi = fast_epi;
   hipStream_t st = as_stream(stream);
   if (y_pre != nullptr) {  // only the DMA-ring kernels (shared epilogue) store the pre-activation
     a.y_pre = y_pre;
