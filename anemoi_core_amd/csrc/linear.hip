@@ -387,20 +387,34 @@ __device__ __forceinline__ void mfma_epilogue_fast(const LinArgs& a, f32x4 (&acc
     const int row = it * 8 + (lane >> 3);
     rsrc[it] = epi + row * 256 + ((cp ^ (row & 7)) << 5);
   }
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-    V8 rv[2], t1[2], t2[2];
+  // residual / gather rows of band mi+1 are requested BEFORE the stores of band mi: vmcnt retires in issue order (stores
+  // included), so a load issued after a store cannot be waited for without waiting for that store's write acknowledgement too
+  V8 rv[2], t1[2], t2[2], rv_n[2], t1_n[2], t2_n[2];
+  auto fetch = [&](int mi, V8 (&r)[2], V8 (&g1)[2], V8 (&g2)[2]) {
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-      rv[it] = V8{};
-      t1[it] = V8{};
-      t2[it] = V8{};
-      if constexpr ((EPI & EPI_RES) != 0) rv[it] = *reinterpret_cast<const V8*>(rlane + (int64_t)(mi * 16 + it * 8) * a.ldr);
+      r[it] = V8{};
+      g1[it] = V8{};
+      g2[it] = V8{};
+      if constexpr ((EPI & EPI_RES) != 0) r[it] = *reinterpret_cast<const V8*>(rlane + (int64_t)(mi * 16 + it * 8) * a.ldr);
       if constexpr ((EPI & EPI_GATHER) != 0) {
         const int m = mrow0 + mi * 16 + it * 8;
-        t1[it] = *reinterpret_cast<const V8*>((const T*)a.g1 + (int64_t)a.idx1[m] * a.ldg1 + nc);
-        if (a.g2 != nullptr) t2[it] = *reinterpret_cast<const V8*>((const T*)a.g2 + (int64_t)a.idx2[m] * a.ldg2 + nc);
+        g1[it] = *reinterpret_cast<const V8*>((const T*)a.g1 + (int64_t)a.idx1[m] * a.ldg1 + nc);
+        if (a.g2 != nullptr) g2[it] = *reinterpret_cast<const V8*>((const T*)a.g2 + (int64_t)a.idx2[m] * a.ldg2 + nc);
       }
+    }
+  };
+  if constexpr ((EPI & (EPI_RES | EPI_GATHER)) != 0) fetch(0, rv_n, t1_n, t2_n);
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      rv[it] = rv_n[it];
+      t1[it] = t1_n[it];
+      t2[it] = t2_n[it];
+    }
+    if constexpr ((EPI & (EPI_RES | EPI_GATHER)) != 0) {
+      if (mi + 1 < MI) fetch(mi + 1, rv_n, t1_n, t2_n);
     }
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) *reinterpret_cast<f32x4*>(wbase + wphys[ni]) = acc[mi][ni];

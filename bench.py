@@ -200,36 +200,41 @@ def profile_forward(step, dtype, host_ms: float = 12.0):
             e0.record()
             out = fn(*a, **kw)
             e1.record()
-            rec.append((work(out, *a, **kw), e0, e1))
+            rec.append((work(out, a, kw), e0, e1))
             return out
         return inner
 
-    def lin_work(out, x, w, bias=None, **kw):
+    def lin_work(res_, a_, kw):
+        x, w = a_[0], a_[1]
         N, K, O = x.shape[0], w.shape[1], w.shape[0]
         mfma = x.dtype != torch.float32 and x.shape[1] % 8 == 0 and (kw.get("x2") is None or kw["x2"].shape[1] % 8 == 0) and O % 4 == 0
         extra = sum(1 for k in ("residual", "g1", "g2") if kw.get(k) is not None)
         byts = es * (N * K + O * K + N * O * (1 + extra)) + 4 * N * sum(1 for k in ("idx1", "idx2") if kw.get(k) is not None)
         return ("linear_mfma_*" if mfma else "linear_generic_kernel"), 2.0 * N * K * O, byts
 
-    def attn_work(out, q, k, v, feat, wp, csc, H, **kw):
+    def attn_work(res_, a_, kw):
+        q, feat, csc = a_[0], a_[3], a_[5]
         D = q.shape[1]
         # compulsory traffic: q, out, self-term (3 N_dst D) + k, v (2 N_src D) + edge features + indices (lin_edge fused)
         return "gt_attn_fused_edge_fwd_kernel", 0.0, es * (3 * csc.n_dst * D + 2 * csc.n_src * D) + 4 * csc.num_edges * feat.shape[1] + 4 * (csc.num_edges + csc.n_dst + 1)
 
-    def ln_work(out, x, *a, **kw):
+    def ln_work(res_, a_, kw):
+        x = a_[0]
         return "layernorm_fwd_kernel", 0.0, 2 * x.numel() * es + (x.numel() * es if kw.get("residual") is not None else 0)
 
-    def gemm_work(out, x, w, *a, **kw):  # the LayerNorm-fold GEMMs (statistics producer / folding consumer)
+    def gemm_work(res_, a_, kw):
+        x, w = a_[0], a_[1]  # the LayerNorm-fold GEMMs (statistics producer / folding consumer)
         N, K, O = x.shape[0], w.shape[1], w.shape[0]
         return "linear_mfma_*", 2.0 * N * K * O, es * (N * K + O * K + N * O)
 
-    def segsum_work(out, z, e_old, gamma, beta, eps, csc):  # read z, e_old; write e_new, agg (2(3 M D + N D))
+    def segsum_work(res_, a_, kw):
+        z, csc = a_[0], a_[5]  # read z, e_old; write e_new, agg (2(3 M D + N D))
         M, D = z.shape
         return "edge_ln_res_segsum_kernel", 0.0, es * (3 * M * D + csc.n_dst * D) + 4 * (csc.n_dst + 1)
 
     def rows_work(name):
-        def f(out, a, *rest, **kw):
-            o = out if isinstance(out, torch.Tensor) else out[0]
+        def f(res_, a_, kw):
+            o = res_ if isinstance(res_, torch.Tensor) else res_[0]
             return name, 0.0, 2 * o.numel() * es
         return f
 
