@@ -144,6 +144,7 @@ constexpr int kTileBytes = BM * BK * 2;  // one operand tile (16 KiB)
 
 using frag8 = __attribute__((ext_vector_type(8))) short;  // 8 x 16-bit operand elements (4 VGPRs)
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 
 template <typename T>
@@ -358,13 +359,24 @@ constexpr int kEpiStores = 8;
 // to be kept from reordering them) - the transposition of band mi+1 overlaps the arithmetic and stores of band mi.
 template <typename T, int EPI, int MI>
 __device__ __forceinline__ void mfma_epilogue_fast(const LinArgs& a, f32x4 (&acc)[MI][4], int m0, int n0, int wr, int wc, int lane,
-                                                   unsigned char* epi) {
+                                                   unsigned char* epi, const float* ln_rows = nullptr) {
   using V8 = Vec<T, 8>;
   const int cp = lane & 7;
   const int nc = n0 + wc * 64 + cp * 8;
   const int mrow0 = m0 + wr * (16 * MI) + (lane >> 3);
   float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (a.bias != nullptr) {
+  float lc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if constexpr ((EPI & EPI_LNFOLD) != 0) {  // LayerNorm fold: c = row sums of the gamma-scaled weight, d = W beta + bias (fp32)
+    const f32x4 c0 = *reinterpret_cast<const f32x4*>(a.ln_c + nc), c1 = *reinterpret_cast<const f32x4*>(a.ln_c + nc + 4);
+    const f32x4 d0 = *reinterpret_cast<const f32x4*>(a.ln_d + nc), d1 = *reinterpret_cast<const f32x4*>(a.ln_d + nc + 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      lc[r] = c0[r];
+      lc[4 + r] = c1[r];
+      bv[r] = d0[r];
+      bv[4 + r] = d1[r];
+    }
+  } else if (a.bias != nullptr) {
     const V8 braw = *reinterpret_cast<const V8*>((const T*)a.bias + nc);
 #pragma unroll
     for (int r = 0; r < 8; ++r) bv[r] = to_float(braw.v[r]);
@@ -429,8 +441,14 @@ __device__ __forceinline__ void mfma_epilogue_fast(const LinArgs& a, f32x4 (&acc
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       float vv[8];
+      if constexpr ((EPI & EPI_LNFOLD) != 0) {  // mean / rstd of the tile's rows sit in LDS (written at the start of the tile)
+        const f32x2 mr = *reinterpret_cast<const f32x2*>(ln_rows + 2 * (wr * (16 * MI) + (lane >> 3) + mi * 16 + it * 8));
 #pragma unroll
-      for (int r = 0; r < 8; ++r) vv[r] = c[it][r >> 2][r & 3] + bv[r];
+        for (int r = 0; r < 8; ++r) vv[r] = fmaf(mr[1], fmaf(-mr[0], lc[r], c[it][r >> 2][r & 3]), bv[r]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) vv[r] = c[it][r >> 2][r & 3] + bv[r];
+      }
       if constexpr ((EPI & EPI_GATHER) != 0) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) vv[r] += to_float(t1[it].v[r]) + to_float(t2[it].v[r]);
@@ -446,6 +464,23 @@ __device__ __forceinline__ void mfma_epilogue_fast(const LinArgs& a, f32x4 (&acc
       V8 o8;
 #pragma unroll
       for (int r = 0; r < 8; ++r) o8.v[r] = from_float<T>(vv[r]);
+      if constexpr ((EPI & EPI_STATS) != 0) {
+        // sums of what is actually stored (rounded), over this wave's 64-column strip of the row: DPP butterfly over the 8
+        // lanes of the row, one plain store per (row, strip) - no atomics, every slot written, deterministic
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const float t = to_float(o8.v[r]);
+          s1 += t;
+          s2 = fmaf(t, t, s2);
+        }
+        s1 = group_sum<8>(s1);
+        s2 = group_sum<8>(s2);
+        if (cp == 0) {
+          const int m = mrow0 + mi * 16 + it * 8;
+          *reinterpret_cast<f32x2*>(a.stats_out + ((int64_t)m * (a.O >> 6) + ((n0 + wc * 64) >> 6)) * 2) = f32x2{s1, s2};
+        }
+      }
       *reinterpret_cast<V8*>(ylane + (int64_t)(mi * 16 + it * 8) * a.ldy) = o8;
     }
   }
@@ -454,9 +489,9 @@ __device__ __forceinline__ void mfma_epilogue_fast(const LinArgs& a, f32x4 (&acc
 template <typename T, int EPI, int MI = 4>
 __device__ __forceinline__ void mfma_epilogue_band(const LinArgs& a, f32x4 (&acc)[MI][4], int m0, int n0, int wr, int wc,
                                                    int lane, unsigned char* epi, bool interior, const float* ln_rows = nullptr) {
-  if constexpr ((EPI & ~(EPI_RES | EPI_GATHER | EPI_GELU)) == 0) {
+  if constexpr ((EPI & ~(EPI_RES | EPI_GATHER | EPI_GELU | EPI_STATS | EPI_LNFOLD)) == 0) {
     if (interior && !a.f32_atomic && a.fast_epi) {  // wave-uniform: one branch per tile
-      mfma_epilogue_fast<T, EPI, MI>(a, acc, m0, n0, wr, wc, lane, epi);
+      mfma_epilogue_fast<T, EPI, MI>(a, acc, m0, n0, wr, wc, lane, epi, ln_rows);
       return;
     }
   }
@@ -1417,10 +1452,19 @@ static int launch_mfma(const LinArgs& a, hipStream_t st) {
 
 template <typename T>
 static int launch_stats_producer(const LinArgs& a, hipStream_t st) {
-  // y = x W^T + b + residual, plus the row statistics of y for the LayerNorm the next GEMM folds in (O = 512-class outputs)
+  // y = x W^T + b + residual, plus the row statistics of y for the LayerNorm the next GEMM folds in (O = 512-class outputs):
+  // the kernel choice of launch_persistent for this shape, with the statistics epilogue
   const int nk = (a.K1 + a.K2) / BK;
   const double c4 = tile_cost_us(256, 128, a.n_rows, a.O, nk), c3 = tile_cost_us(192, 128, a.n_rows, a.O, nk);
   constexpr int EPI = EPI_RES | EPI_STATS;
+  {
+    constexpr int TM = 160;
+    const int rem160 = a.n_rows % TM;
+    const bool split160 = rem160 > 0 && rem160 <= 32 && a.n_rows > TM;
+    const int rows160 = split160 ? a.n_rows - rem160 : a.n_rows;
+    const int64_t t160 = (int64_t)((rows160 + TM - 1) / TM) * ((a.O + SN - 1) / SN);
+    if (t160 > 128 && t160 <= 256 && a.K2 == 0 && a.K1 >= 1024 && a.K1 % SK == 0 && !split160) return launch_splitwave<T, EPI, 5, 2, 2, 2>(a, st);
+  }
   return c3 < c4 ? launch_persistent_wm<T, EPI, 3, true>(a, st) : launch_persistent_wm<T, EPI, 4, true>(a, st);
 }
 
@@ -1433,6 +1477,9 @@ static int launch_lnfold_consumer(const LinArgs& a, hipStream_t st) {
     m.n_rows = a.n_rows - rem;
     m.tail_rows = rem;
   }
+  const int64_t t320 = (int64_t)((m.n_rows + 319) / 320) * ((a.O + 255) / 256);
+  if (t320 <= 256 && m.n_rows % 160 == 0)  // two 160 x 256 tiles per CU (see launch_persistent)
+    return a.act == ANEMOI_ACT_GELU ? launch_bigtile<T, EPI_LNFOLD | EPI_GELU, 5>(m, st) : launch_bigtile<T, EPI_LNFOLD, 5>(m, st);
   return a.act == ANEMOI_ACT_GELU ? launch_bigtile<T, EPI_LNFOLD | EPI_GELU, 10>(m, st) : launch_bigtile<T, EPI_LNFOLD, 10>(m, st);
 }
 

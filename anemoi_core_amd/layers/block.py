@@ -28,11 +28,11 @@ from .utils import compute_mlp_hidden_dim
 from ..utils.tensors import version
 
 ANEMOI_DEBUG_SHARDING = os.environ.get("ANEMOI_DEBUG_SHARDING", "") != ""
-# LayerNorm folded into the neighbouring GEMMs (anemoi_linear_stats_fwd / anemoi_linear_lnfold_fwd).  Opt-in: it removes 32 of
-# the 39 LayerNorm launches of the O96 forward but makes the consuming GEMMs' epilogues heavier (the 160-accumulator big-tile
-# kernel has no registers to spare): -1.4 % forward time in a same-box A/B, nothing on another box.
+# LayerNorm folded into the neighbouring GEMMs (anemoi_linear_stats_fwd / anemoi_linear_lnfold_fwd): 32 of the 39 LayerNorm
+# launches of the O96 forward disappear.  On by default since both sides run on the fast interior-tile epilogue (-2.3 % forward
+# time in same-box A/Bs; it was neutral with the generic epilogue: DESIGN.md section 5).  ANEMOI_LN_FOLD=0: LayerNorm + GEMM.
 _FUSED_EDGE_BWD = os.environ.get("ANEMOI_FUSED_EDGE_BWD", "1") == "1"  # 0: train through the materialised-E op (reference op boundary)
-_LN_FOLD = os.environ.get("ANEMOI_LN_FOLD", "0") == "1"
+_LN_FOLD = os.environ.get("ANEMOI_LN_FOLD", "1") == "1"
 
 
 class _FusedWeights:
