@@ -455,7 +455,7 @@ __device__ __forceinline__ void mfma_epilogue_fast(const LinArgs& a, f32x4 (&acc
       }
       if constexpr ((EPI & EPI_GELU) != 0) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) vv[r] = gelu_fast(vv[r]);
+        for (int r = 0; r < 8; r += 2) gelu_fast2(vv[r], vv[r + 1]);
       }
       if constexpr ((EPI & EPI_RES) != 0) {
 #pragma unroll
