@@ -902,12 +902,17 @@ __device__ __forceinline__ void tail_rows_valu(const LinArgs& a, int m_begin, in
       }
       acc = wave_sum(acc);
       float ln_mu = 0.f, ln_rs = 1.f;
-      if (a.stats_in) {  // strip sums of the row: one strip per lane + butterfly instead of a serial walk in lane 0
-        const float* st = a.stats_in + (int64_t)m * a.ln_strips * 2;
+      if (a.ln_c) {  // LayerNorm fold: the statistics of a tail row are taken from the row itself (the producer's tail rows,
+        // computed a column per wave as here, leave no strip sums)
         float s1 = 0.f, s2 = 0.f;
-        for (int q = lane; q < a.ln_strips; q += 64) {
-          s1 += st[2 * q];
-          s2 += st[2 * q + 1];
+        for (int k = lane * 8; k < a.K1; k += 512) {
+          float xv[8];
+          load_vec<T, 8>(xr + k, xv);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            s1 += xv[i];
+            s2 = fmaf(xv[i], xv[i], s2);
+          }
         }
         s1 = wave_sum(s1);
         s2 = wave_sum(s2);
@@ -916,7 +921,7 @@ __device__ __forceinline__ void tail_rows_valu(const LinArgs& a, int m_begin, in
       }
       if (lane == 0) {
         float vv = acc;
-        if (a.stats_in) vv = ln_rs * (vv - ln_mu * a.ln_c[n]) + a.ln_d[n];  // LayerNorm fold, as in the MFMA epilogue
+        if (a.ln_c) vv = ln_rs * (vv - ln_mu * a.ln_c[n]) + a.ln_d[n];  // LayerNorm fold, as in the MFMA epilogue
         if (a.bias) vv += to_float(((const T*)a.bias)[n]);
         if (a.g1) vv += to_float(((const T*)a.g1)[(int64_t)a.idx1[m] * a.ldg1 + n]);
         if (a.g2) vv += to_float(((const T*)a.g2)[(int64_t)a.idx2[m] * a.ldg2 + n]);
@@ -984,15 +989,20 @@ __global__ __launch_bounds__(512, 1) void linear_mfma_splitwave_kernel(LinArgs a
     src_row[j] = (is_a ? (const char*)a.x + row_g * a.ldx * 2 : (const char*)a.w + row_g * a.ldw * 2) + slot * 16;
     dst_off[j] = (is_a ? 0 : kA) + (is_a ? p : p - TM / 4) * 1024;
   }
-  auto issue = [&](int kt) {
-    const uint32_t base = smem_l + (kt % STAGES) * kStage;
-#pragma unroll
-    for (int j = 0; j < kPPW; ++j)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(src_row[j] + (int64_t)kt * kSRow), (lds_void_t*)(size_t)(base + dst_off[j]), 16, 0, 0);
+  // The pieces of a stage are issued ONE BY ONE between the MFMA groups of the step that runs two (or one) stages earlier: a
+  // burst of kPPW global_load_lds right behind the barrier costs the wave ~100 cycles per piece during which it feeds no
+  // MFMA - as long as the step's whole matrix work (measured: 1.7 us per 128-wide step with the burst).  Past the last
+  // stage the pieces re-fetch into a dummy KiB so that every step issues the same number (uniform counted waits).
+  const uint32_t dummy_l = smem_l + STAGES * kStage;
+  auto piece = [&](int j, int kt_src, uint32_t base, bool valid) {
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)(src_row[j] + (int64_t)kt_src * kSRow), (lds_void_t*)(size_t)(valid ? base + dst_off[j] : dummy_l), 16, 0, 0);
   };
 #pragma unroll
-  for (int p = 0; p < STAGES - 1; ++p)
-    if (p < nk) issue(p);
+  for (int p = 0; p < STAGES - 1; ++p) {
+    const bool valid = p < nk;
+#pragma unroll
+    for (int j = 0; j < kPPW; ++j) piece(j, valid ? p : 0, smem_l + (p % STAGES) * kStage, valid);
+  }
   // the tail rows (a few rows beyond a multiple of the tile height) ride in the shadow of the first stages' flight time
   if (a.tail_rows > 0) tail_rows_valu<T, false>(a, a.n_rows, a.n_rows + a.tail_rows, (int)blockIdx.x * 8 + wave, (int)gridDim.x * 8, lane);
 
@@ -1012,14 +1022,16 @@ __global__ __launch_bounds__(512, 1) void linear_mfma_splitwave_kernel(LinArgs a
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  constexpr int kGroups = kKB * MI;                          // MFMA groups (4 MFMAs each) per wave and step
+  constexpr int kPerGroup = (kPPW + kGroups - 1) / kGroups;  // pieces issued behind each group
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + STAGES - 2 < nk) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * kPPW) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * kPPW) : "memory");  // stage kt landed; STAGES-2 newer ones may fly
     __builtin_amdgcn_s_barrier();  // stage kt complete for every wave; stage kt-1 no longer read by anybody
-    if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1);
+    asm volatile("" ::: "memory");
+    const int ktn = kt + STAGES - 1;
+    const bool valid = ktn < nk;
+    const uint32_t nbase = smem_l + (ktn % STAGES) * kStage;
+    const int kt_src = valid ? ktn : kt;
     const unsigned char* st = smem + (kt % STAGES) * kStage;
 #pragma unroll
     for (int kb = 0; kb < kKB; ++kb) {
@@ -1031,9 +1043,15 @@ __global__ __launch_bounds__(512, 1) void linear_mfma_splitwave_kernel(LinArgs a
         const frag8 fa = *reinterpret_cast<const frag8*>(st + a_rd[kb] + mi * 16 * kSRow);
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16<T>(fw[ni], fa, acc[mi][ni]);
+#pragma unroll
+        for (int q = 0; q < kPerGroup; ++q) {
+          const int j = (kb * MI + mi) * kPerGroup + q;
+          if (j < kPPW) piece(j, kt_src, nbase, valid);
+        }
       }
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing dummy pieces
 
   // add the K-groups in group order (deterministic): MI KiB x 4 of LDS per non-leading wave, 4 KiB epilogue bands behind them
   constexpr int kAccBytes = MI * 4 * 1024;
@@ -1313,7 +1331,7 @@ static int launch_persistent_wm(const LinArgs& a, hipStream_t st) {
 template <typename T, int EPI, int MI = 4, int WR = 1, int KG = 4, int STAGES = kSStages>
 static int launch_splitwave(const LinArgs& a, hipStream_t st) {
   constexpr int TM = 16 * MI * WR;
-  constexpr int ring = STAGES * (TM + SN) * kSRow;
+  constexpr int ring = STAGES * (TM + SN) * kSRow + 1024;  // + the dummy KiB of the trailing DMA pieces
   constexpr int fin = (KG - 1) * WR * 2 * MI * 4 * 1024 + WR * 2 * 4096;  // K-group sums + epilogue bands (reuse the ring)
   constexpr int smem_bytes = ring > fin ? ring : fin;
   static_assert(smem_bytes <= 160 * 1024, "LDS");
@@ -1463,7 +1481,13 @@ static int launch_stats_producer(const LinArgs& a, hipStream_t st) {
     const bool split160 = rem160 > 0 && rem160 <= 32 && a.n_rows > TM;
     const int rows160 = split160 ? a.n_rows - rem160 : a.n_rows;
     const int64_t t160 = (int64_t)((rows160 + TM - 1) / TM) * ((a.O + SN - 1) / SN);
-    if (t160 > 128 && t160 <= 256 && a.K2 == 0 && a.K1 >= 1024 && a.K1 % SK == 0 && !split160) return launch_splitwave<T, EPI, 5, 2, 2, 2>(a, st);
+    static const bool narrow = [] { const char* e = getenv("ANEMOI_GEMM_NARROW"); return !(e && e[0] == '0'); }();
+    if (narrow && t160 > 128 && t160 <= 256 && a.K2 == 0 && a.K1 >= 1024 && a.K1 % SK == 0) {
+      LinArgs m = a;  // tail rows: computed a column per wave, WITHOUT strip sums (the consumer takes their statistics from the rows)
+      m.n_rows = rows160;
+      m.tail_rows = split160 ? rem160 : 0;
+      return launch_splitwave<T, EPI, 5, 2, 2, 2>(m, st);
+    }
   }
   return c3 < c4 ? launch_persistent_wm<T, EPI, 3, true>(a, st) : launch_persistent_wm<T, EPI, 4, true>(a, st);
 }

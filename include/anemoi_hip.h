@@ -181,6 +181,10 @@ int anemoi_gelu_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, int32_t n_
  *    no atomics, no zeroing, deterministic.  O and K multiples of 64.
  *  - anemoi_linear_lnfold_fwd: y = act(LN(x) W^T + b) from raw x [n_rows, K], w_scaled = W diag(gamma) [O, K], fp32 c, d [O]
  *    and stats_in = the producer's statistics of x (strips * 64 == K).  Partials are added in a fixed order.
+ *  The pair is a two-kernel protocol: when n_rows exceeds a multiple of 160 by at most 32 (the "+ 2" of an icosphere's
+ *  10 * 4^r + 2 nodes) the producer may compute those trailing rows outside its tiles and leaves their stats_out entries
+ *  UNWRITTEN; the consumer never reads them - it takes the statistics of its own trailing rows (n_rows % 320 <= 32) from the
+ *  rows themselves.
  * Replaces the two LayerNorm launches of a GraphTransformerProcessorBlock (layer_norm_attention / layer_norm_mlp_dst,
  * layers/block.py:1237, 1271) in the unsharded inference path.  Returns ANEMOI_E_UNSUPPORTED for shapes / alignments the
  * ring kernels do not take (the caller falls back to LayerNorm + anemoi_linear_fwd). */

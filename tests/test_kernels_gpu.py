@@ -353,8 +353,12 @@ def test_layernorm_folded_into_neighbouring_gemms(ops, dtype, N):
     plain = ops.linear(d(h), d(w2), d(b2), residual=d(res)).float()  # may be another kernel (K summed in another order): 1 ulp
     assert float((y.float() - plain).abs().max()) <= 1e-2 * float(plain.abs().max())
     yf = y.float()
-    s = stats.sum(1)
-    assert float((s[:, 0] - yf.sum(1)).abs().max()) < 1e-3 and float((s[:, 1] - (yf * yf).sum(1)).abs().max()) < 1e-3 * float((yf * yf).sum(1).max())
+    # a few rows beyond a multiple of the 160-row tile (the icosphere's "+ 2") are computed a column per wave and carry NO strip
+    # sums (include/anemoi_hip.h): the folding consumer takes the statistics of such rows from the rows themselves
+    nst = N - N % 160 if 0 < N % 160 <= 32 and N > 160 else N
+    s = stats[:nst].sum(1)
+    assert float((s[:, 0] - yf[:nst].sum(1)).abs().max()) < 1e-3
+    assert float((s[:, 1] - (yf[:nst] * yf[:nst]).sum(1)).abs().max()) < 1e-3 * float((yf * yf).sum(1).max())
     ws = (w1.float() * gamma.float()).to(dtype)
     c, dd = ws.float().sum(1).contiguous(), (w1.float() @ beta.float() + b1.float()).contiguous()
     for act in (None, "gelu"):
