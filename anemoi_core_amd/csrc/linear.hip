@@ -944,7 +944,7 @@ __device__ __forceinline__ void tail_rows_valu(const LinArgs& a, int m_begin, in
 //   lanes = 16 rows of one slot column) while a DMA piece stays lane-linear (4 rows x 16 slots, the lane fetches the slot that
 //   belongs at its position).
 constexpr int SK = 128, SM = 64, SN = 128, kSStages = 3;
-constexpr int kSRow = SK * 2;
+
 
 // Generalised: (16 MI WR) x 128 output tile, 8 waves = KG K-groups x WR row groups x 2 column halves, every wave an (16 MI) x 64
 // sub-tile over its 128 / KG slice of each 128-wide K stage; STAGES-deep DMA ring of [(16 MI WR) + 128 rows][256 B].
@@ -954,15 +954,18 @@ constexpr int kSRow = SK * 2;
 //       rate the LDS-DMA path reaches (tools/dma_rate_probe.hip: 72 KiB in 0.7 us) - because every step pays the fixed price of
 //       its waits and barriers.  128-wide stages halve the number of steps, and [10240 x K] -> 512 is exactly 64 x 4 = 256 such
 //       tiles = one per CU (the 2 rows beyond 64 x 160 of an icosphere mesh ride on the VALU, as in the big-tile kernel).
-template <typename T, int EPI, int MI, int WR, int KG, int STAGES>
+template <typename T, int EPI, int MI, int WR, int KG, int STAGES, int SKW = SK>
 __global__ __launch_bounds__(512, 1) void linear_mfma_splitwave_kernel(LinArgs a, int tiles_n, int num_tiles) {
   static_assert(KG * WR * 2 == 8, "8 waves");
+  static_assert(SKW == 128 || SKW == 64, "stage width");
   constexpr int TM = 16 * MI * WR;                 // tile rows
-  constexpr int kA = TM * kSRow, kStage = (TM + SN) * kSRow;
-  constexpr int kPieces = (TM + SN) / 4;           // 1-KiB DMA pieces (4 rows x 256 B) per stage
-  static_assert(kPieces % 8 == 0, "pieces must divide evenly over the 8 waves");
-  constexpr int kPPW = kPieces / 8;
-  constexpr int kKB = 4 / KG;                      // 32-wide k-blocks of a stage per K-group
+  constexpr int kRow = SKW * 2;                    // bytes of a stage row: 256 (16 slots of 16 B) or 128 (8 slots)
+  constexpr int kRPP = 1024 / kRow, kLPR = kRow / 16;  // rows per 1-KiB DMA piece, lanes per row
+  constexpr int kA = TM * kRow, kStage = (TM + SN) * kRow;
+  constexpr int kAP = TM / kRPP, kPieces = (TM + SN) / kRPP;
+  constexpr int kPPW = (kPieces + 7) / 8;          // per wave; surplus pieces (uneven division) go to the dummy KiB
+  constexpr int kKB = (SKW / 32) / KG;             // 32-wide k-blocks of a stage per K-group
+  static_assert(kKB >= 1, "K-groups");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wc = wave & 1, wr = (wave >> 1) % WR, kg = (wave >> 1) / WR;
@@ -972,30 +975,36 @@ __global__ __launch_bounds__(512, 1) void linear_mfma_splitwave_kernel(LinArgs a
     id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
   }
   const int m0 = (id / tiles_n) * TM, n0 = (id % tiles_n) * SN;
-  const int nk = a.K1 / SK;
+  const int nk = a.K1 / SKW;
   const uint32_t smem_l = (uint32_t)(size_t)(lds_void_t*)smem;
+  // 16-byte slots of a row are XOR-swizzled so that the fragment ds_read_b128 (16 rows, one logical slot) are conflict-free:
+  // 16 slots per row: slot ^ (row & 15); 8 slots per row (two rows per 256-byte bank line): slot ^ ((row >> 1) & 7)
+  auto swz = [](int row) { return SKW == 128 ? (row & 15) : ((row >> 1) & 7); };
 
-  // DMA: TM / 4 A pieces + 32 W pieces (4 rows x 256 B) per stage, kPPW per wave
-  const int pr = lane >> 4, pos = lane & 15;
+  // DMA: TM / kRPP A pieces + 128 / kRPP W pieces (kRPP rows x kRow bytes) per stage, kPPW per wave
+  const int pr = lane / kLPR, pos = lane % kLPR;
   const char* src_row[kPPW];
   uint32_t dst_off[kPPW];
+  bool real[kPPW];
 #pragma unroll
   for (int j = 0; j < kPPW; ++j) {
-    const int p = wave * kPPW + j;
-    const bool is_a = p < TM / 4;
-    const int row_t = (is_a ? p : p - TM / 4) * 4 + pr;
-    const int slot = pos ^ (row_t & 15);
+    const int p0 = wave * kPPW + j;
+    real[j] = p0 < kPieces;
+    const int p = real[j] ? p0 : kPieces - 1;
+    const bool is_a = p < kAP;
+    const int row_t = (is_a ? p : p - kAP) * kRPP + pr;
+    const int slot = pos ^ swz(row_t);
     const int64_t row_g = is_a ? min(m0 + row_t, a.n_rows - 1) : min(n0 + row_t, a.O - 1);  // clamped rows are never stored
     src_row[j] = (is_a ? (const char*)a.x + row_g * a.ldx * 2 : (const char*)a.w + row_g * a.ldw * 2) + slot * 16;
-    dst_off[j] = (is_a ? 0 : kA) + (is_a ? p : p - TM / 4) * 1024;
+    dst_off[j] = (is_a ? 0 : kA) + (is_a ? p : p - kAP) * 1024;
   }
-  // The pieces of a stage are issued ONE BY ONE between the MFMA groups of the step that runs two (or one) stages earlier: a
+  // The pieces of a stage are issued ONE BY ONE between the MFMA groups of the step that runs STAGES-1 steps earlier: a
   // burst of kPPW global_load_lds right behind the barrier costs the wave ~100 cycles per piece during which it feeds no
   // MFMA - as long as the step's whole matrix work (measured: 1.7 us per 128-wide step with the burst).  Past the last
   // stage the pieces re-fetch into a dummy KiB so that every step issues the same number (uniform counted waits).
   const uint32_t dummy_l = smem_l + STAGES * kStage;
   auto piece = [&](int j, int kt_src, uint32_t base, bool valid) {
-    __builtin_amdgcn_global_load_lds((gbl_void_t*)(src_row[j] + (int64_t)kt_src * kSRow), (lds_void_t*)(size_t)(valid ? base + dst_off[j] : dummy_l), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)(src_row[j] + (int64_t)kt_src * kRow), (lds_void_t*)(size_t)((valid && real[j]) ? base + dst_off[j] : dummy_l), 16, 0, 0);
   };
 #pragma unroll
   for (int p = 0; p < STAGES - 1; ++p) {
@@ -1006,14 +1015,15 @@ __global__ __launch_bounds__(512, 1) void linear_mfma_splitwave_kernel(LinArgs a
   // the tail rows (a few rows beyond a multiple of the tile height) ride in the shadow of the first stages' flight time
   if (a.tail_rows > 0) tail_rows_valu<T, false>(a, a.n_rows, a.n_rows + a.tail_rows, (int)blockIdx.x * 8 + wave, (int)gridDim.x * 8, lane);
 
-  // fragments: row (lane & 15) of every 16-row block, logical slot (kg kKB + kb) 4 + (lane >> 4)
+  // fragments: row (lane & 15) of every 16-row block (the swizzle term is the same for all of them), logical slot
+  // (kg kKB + kb) 4 + (lane >> 4)
   const int frow = lane & 15;
   int a_rd[kKB], w_rd[kKB];
 #pragma unroll
   for (int kb = 0; kb < kKB; ++kb) {
-    const int fphys = (((kg * kKB + kb) * 4 + (lane >> 4)) ^ frow) << 4;
-    a_rd[kb] = (wr * 16 * MI + frow) * kSRow + fphys;
-    w_rd[kb] = kA + (wc * 64 + frow) * kSRow + fphys;
+    const int fphys = (((kg * kKB + kb) * 4 + (lane >> 4)) ^ swz(frow)) << 4;
+    a_rd[kb] = (wr * 16 * MI + frow) * kRow + fphys;
+    w_rd[kb] = kA + (wc * 64 + frow) * kRow + fphys;
   }
 
   f32x4 acc[MI][4];
@@ -1037,10 +1047,10 @@ __global__ __launch_bounds__(512, 1) void linear_mfma_splitwave_kernel(LinArgs a
     for (int kb = 0; kb < kKB; ++kb) {
       frag8 fw[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fw[i] = *reinterpret_cast<const frag8*>(st + w_rd[kb] + i * 16 * kSRow);
+      for (int i = 0; i < 4; ++i) fw[i] = *reinterpret_cast<const frag8*>(st + w_rd[kb] + i * 16 * kRow);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
-        const frag8 fa = *reinterpret_cast<const frag8*>(st + a_rd[kb] + mi * 16 * kSRow);
+        const frag8 fa = *reinterpret_cast<const frag8*>(st + a_rd[kb] + mi * 16 * kRow);
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16<T>(fw[ni], fa, acc[mi][ni]);
 #pragma unroll
@@ -1328,20 +1338,20 @@ static int launch_persistent_wm(const LinArgs& a, hipStream_t st) {
   return check_launch("linear_mfma_persistent_kernel");
 }
 
-template <typename T, int EPI, int MI = 4, int WR = 1, int KG = 4, int STAGES = kSStages>
+template <typename T, int EPI, int MI = 4, int WR = 1, int KG = 4, int STAGES = kSStages, int SKW = SK>
 static int launch_splitwave(const LinArgs& a, hipStream_t st) {
   constexpr int TM = 16 * MI * WR;
-  constexpr int ring = STAGES * (TM + SN) * kSRow + 1024;  // + the dummy KiB of the trailing DMA pieces
+  constexpr int ring = STAGES * (TM + SN) * SKW * 2 + 1024;  // + the dummy KiB of the trailing DMA pieces
   constexpr int fin = (KG - 1) * WR * 2 * MI * 4 * 1024 + WR * 2 * 4096;  // K-group sums + epilogue bands (reuse the ring)
   constexpr int smem_bytes = ring > fin ? ring : fin;
   static_assert(smem_bytes <= 160 * 1024, "LDS");
   static PerDeviceOnce attr_once;
   if (attr_once.first()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_mfma_splitwave_kernel<T, EPI, MI, WR, KG, STAGES>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_mfma_splitwave_kernel<T, EPI, MI, WR, KG, STAGES, SKW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
   }
   const int tm = (a.n_rows + TM - 1) / TM, tn = (a.O + SN - 1) / SN;
-  hipLaunchKernelGGL((linear_mfma_splitwave_kernel<T, EPI, MI, WR, KG, STAGES>), dim3(tm * tn), dim3(512), smem_bytes, st, a, tn, tm * tn);
+  hipLaunchKernelGGL((linear_mfma_splitwave_kernel<T, EPI, MI, WR, KG, STAGES, SKW>), dim3(tm * tn), dim3(512), smem_bytes, st, a, tn, tm * tn);
   return check_launch("linear_mfma_splitwave_kernel");
 }
 
@@ -1411,6 +1421,8 @@ static int launch_persistent(const LinArgs& a, hipStream_t st) {
       LinArgs m = a;
       m.n_rows = rows160;
       m.tail_rows = split160 ? rem160 : 0;
+      static const int n64 = [] { const char* e = getenv("ANEMOI_GEMM_NARROW64"); return e ? atoi(e) : 0; }();
+      if (n64) return launch_splitwave<T, EPI, 5, 2, 2, 4, 64>(m, st);  // 64-wide stages, 4-deep ring
       return launch_splitwave<T, EPI, 5, 2, 2, 2>(m, st);
     }
   }
@@ -1486,6 +1498,8 @@ static int launch_stats_producer(const LinArgs& a, hipStream_t st) {
       LinArgs m = a;  // tail rows: computed a column per wave, WITHOUT strip sums (the consumer takes their statistics from the rows)
       m.n_rows = rows160;
       m.tail_rows = split160 ? rem160 : 0;
+      static const int n64 = [] { const char* e = getenv("ANEMOI_GEMM_NARROW64"); return e ? atoi(e) : 0; }();
+      if (n64) return launch_splitwave<T, EPI, 5, 2, 2, 4, 64>(m, st);
       return launch_splitwave<T, EPI, 5, 2, 2, 2>(m, st);
     }
   }
