@@ -8,3 +8,4 @@ from .synthetic import (  # noqa: F401
     multiscale_edges,
     octahedral_grid,
 )
+from .io import GraphData, load_graph_from_file, save_graph, validate_loaded_graph  # noqa: E402,F401
