@@ -136,7 +136,7 @@ struct WLayout {
   static constexpr int kFloats = 64 * kChunk;
 };
 
-template <typename T, int VEC, int LPH, int FE_PAD>
+template <typename T, int VEC, int LPH, int FE_PAD, bool KVADJ>
 __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void gt_attn_fused_edge_fwd_kernel(
     const T* __restrict__ q, int64_t ldq, const T* __restrict__ k, int64_t ldk, const T* __restrict__ v, int64_t ldv,
     const float* __restrict__ feat, const float* __restrict__ w_packed, const int32_t* __restrict__ row,
@@ -188,6 +188,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void gt_attn_fused_edge_fwd
   const int d_hi = min(n_dst, d_lo + per_xcd);
 
   using Raw = Vec<T, VEC>;  // a row slice as loaded (converted to fp32 only when consumed)
+  const float sl2e = scale * 1.4426950408889634f;  // p = 2^((s' - m') * scale * log2 e)
+  const float thr = kDeferThr / scale;
   constexpr int PF = 3;     // edges in flight per wave (modulo-unrolled: no register rotation, counted waits)
 
   for (int d = d_lo + wave_in_xcd; d < d_hi; d += waves_in_xcd) {
@@ -201,9 +203,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void gt_attn_fused_edge_fwd
     float qv[VEC], acc[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-      qv[j] = to_float(q_raw.v[j]) * scale;
+      qv[j] = to_float(q_raw.v[j]);
       acc[j] = 0.f;
     }
+    // Scores are kept in units of 1/scale (s' = <q, k + e>, the softmax argument is scale * s'): the scale rides in the
+    // exponent's multiplier (one multiply per edge less).
     // qw[f] = (1/LPH) * sum over the head's channels of q[c] * W'[c][f]  (pre-divided: every lane of the
     // head adds the same edge-feature term before the head butterfly).
     float qw[FE_PAD], sf[FE_PAD];
@@ -238,9 +242,20 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void gt_attn_fused_edge_fwd
         j = min(j, n - 1);  // refills past the end re-read the last edge: an UNCONDITIONAL load keeps the ring registers
                             // free of select/copy code (a conditional one made the compiler wait for the load at once)
         const int s = __builtin_amdgcn_readlane(my_src, j);
-        kr = *reinterpret_cast<const Raw*>(k + (int64_t)s * ldk + c0);
-        vr = *reinterpret_cast<const Raw*>(v + (int64_t)s * ldv + c0);
-        const float* a = feat + (int64_t)(chunk + j) * FE_PAD;  // wave-uniform address -> scalar loads
+        const float* a;  // wave-uniform address -> scalar loads
+        if constexpr (KVADJ) {
+          // v = the D columns after k in the same buffer (the fused projection's layout): ONE address and an immediate
+          // offset; the row offset in 32 bits (checked at launch) - 13 scalar instructions fewer per edge, and this
+          // kernel is bound by instruction issue
+          const T* kp = k + (uint32_t)((uint32_t)s * (uint32_t)ldk) + c0;
+          kr = *reinterpret_cast<const Raw*>(kp);
+          vr = *reinterpret_cast<const Raw*>(kp + 64 * VEC);
+          a = feat + (int64_t)(chunk + j) * FE_PAD;
+        } else {
+          kr = *reinterpret_cast<const Raw*>(k + (int64_t)s * ldk + c0);
+          vr = *reinterpret_cast<const Raw*>(v + (int64_t)s * ldv + c0);
+          a = feat + (int64_t)(chunk + j) * FE_PAD;
+        }
 #pragma unroll
         for (int f = 0; f < FE_PAD; ++f) fr[f] = a[f];
       };
@@ -251,13 +266,22 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void gt_attn_fused_edge_fwd
         for (int st = 0; st < PF; ++st) {
           const int j = j0 + st;
           if (j < n) {
-            float dot = dot_rows<T, VEC>(q_raw, kb[st]) * scale;
+            float dot = dot_rows<T, VEC>(q_raw, kb[st]);
+            if constexpr (FE_PAD % 2 == 0) {  // feature pairs on packed FMAs (scalar-register pairs as loaded)
+              f32x2 d2[2] = {{dot, 0.f}, {0.f, 0.f}};  // two chains: dependent packed FMAs back to back cost a wait state each
 #pragma unroll
-            for (int f = 0; f < FE_PAD; ++f) dot = fmaf(fb[st][f], qw[f], dot);
+              for (int f = 0; f < FE_PAD; f += 2)
+                d2[(f / 2) & 1] = __builtin_elementwise_fma(f32x2{fb[st][f], fb[st][f + 1]}, f32x2{qw[f], qw[f + 1]}, d2[(f / 2) & 1]);
+              d2[0] += d2[1];
+              dot = d2[0][0] + d2[0][1];
+            } else {
+#pragma unroll
+              for (int f = 0; f < FE_PAD; ++f) dot = fmaf(fb[st][f], qw[f], dot);
+            }
             dot = group_sum<LPH>(dot);
-            if (__builtin_amdgcn_ballot_w64(dot > m + kDeferThr) != 0) {  // always on the first edge, rare afterwards
+            if (__builtin_amdgcn_ballot_w64(dot > m + thr) != 0) {  // always on the first edge, rare afterwards
               const float m_new = fmaxf(m, dot);
-              const float corr = __expf(m - m_new);  // exp(-inf) = 0 on the first edge
+              const float corr = __builtin_amdgcn_exp2f((m - m_new) * sl2e);  // 2^(-inf) = 0 on the first edge
               l *= corr;
 #pragma unroll
               for (int jj = 0; jj < VEC; ++jj) acc[jj] *= corr;
@@ -265,7 +289,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void gt_attn_fused_edge_fwd
               for (int f = 0; f < FE_PAD; ++f) sf[f] *= corr;
               m = m_new;
             }
-            const float p = __expf(dot - m);
+            const float p = __builtin_amdgcn_exp2f((dot - m) * sl2e);
             l += p;
 #pragma unroll
             for (int jj = 0; jj < VEC; ++jj) acc[jj] = fmaf(p, to_float(vb[st].v[jj]), acc[jj]);
@@ -311,7 +335,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void gt_attn_fused_edge_fwd
       for (int j = 0; j < VEC; ++j) o[j] += ad[j];
     }
     store_vec<T, VEC>(out + (int64_t)d * ldo + c0, o);
-    if (lse != nullptr && (lane % LPH) == 0) lse[(int64_t)d * H + lane / LPH] = (end > beg) ? m + __logf(l) : 0.f;
+    if (lse != nullptr && (lane % LPH) == 0) lse[(int64_t)d * H + lane / LPH] = (end > beg) ? m * scale + __logf(l) : 0.f;
   }
 }
 
@@ -442,7 +466,11 @@ static int launch_fast(const AttnArgs& a) {
     blocks = blocks < max_blocks ? blocks : max_blocks;
     blocks = (blocks + 7) & ~7;  // a whole number of workgroups per XCD
     const dim3 grid(blocks);
-    hipLaunchKernelGGL((gt_attn_fused_edge_fwd_kernel<T, VEC, LPH, FE_PAD>), grid, block, L::kFloats * sizeof(float),
+    // the fused [q|k|v|self] projection buffer: v sits right behind k in every row
+    const bool kv_adjacent = (const T*)a.v == (const T*)a.k + 64 * VEC && a.ldv == a.ldk &&
+                             (int64_t)a.n_src * a.ldk < (int64_t(1) << 32);
+    auto kern = kv_adjacent ? gt_attn_fused_edge_fwd_kernel<T, VEC, LPH, FE_PAD, true> : gt_attn_fused_edge_fwd_kernel<T, VEC, LPH, FE_PAD, false>;
+    hipLaunchKernelGGL(kern, grid, block, L::kFloats * sizeof(float),
                        a.stream, (const T*)a.q, a.ldq, (const T*)a.k, a.ldk, (const T*)a.v, a.ldv, a.feat, a.w_packed,
                        a.row, a.colptr, (const T*)a.addend, a.ldadd, (T*)a.out, a.ldo, a.lse, a.n_dst, a.H, scale);
     return check_launch("gt_attn_fused_edge_fwd_kernel");
