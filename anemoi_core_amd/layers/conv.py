@@ -10,6 +10,7 @@ from torch import Tensor, nn
 from .. import ops
 from .graphcache import get_csc, get_reverse_csr
 from .mlp import MLP
+from ..utils.tensors import version
 
 
 class GraphTransformerConv(nn.Module):
@@ -50,6 +51,15 @@ class GraphConv(nn.Module):
         self.edge_mlp = MLP(3 * in_channels, out_channels, out_channels, layer_kernels=layer_kernels,
                             n_extra_layers=mlp_extra_layers + 1, mlp_implementation=mlp_implementation)
 
+    def _stacked_node_weight(self, w: Tensor, D: int) -> Tensor:
+        sig = (w.data_ptr(), version(w), w.dtype, str(w.device))
+        hit = self.__dict__.get("_stacked")
+        if hit is None or hit[0] != sig:
+            with torch.no_grad():
+                hit = (sig, torch.cat([w[:, :D], w[:, D:2 * D]], dim=0).contiguous())
+            self.__dict__["_stacked"] = hit
+        return hit[1]
+
     def forward(self, x, edge_attr: Tensor, edge_index: Tensor, size=None, edges_are_dst_sorted: bool = True):
         x_src, x_dst = (x, x) if isinstance(x, Tensor) else x
         size = (x_src.shape[0], x_dst.shape[0]) if size is None else size
@@ -59,8 +69,14 @@ class GraphConv(nn.Module):
         D = self.in_channels
         lin0 = self.edge_mlp.mlp[0]
         w = lin0.weight  # [out, 3D] = [W_i | W_j | W_e]
-        p_dst = ops.linear(x_dst, w[:, :D])
-        p_src = ops.linear(x_src, w[:, D:2 * D])
+        if x_src is x_dst and not ops._needs_grad(x_src, w):
+            # processor (one node set), inference: [x W_i^T | x W_j^T] as ONE node-level GEMM with the stacked weight
+            # [W_i; W_j] (rebuilt only when the parameter changes); the edge GEMM gathers from the two column halves
+            p = ops.linear(x_dst, self._stacked_node_weight(w, D))
+            p_dst, p_src = p[:, :w.shape[0]], p[:, w.shape[0]:]
+        else:
+            p_dst = ops.linear(x_dst, w[:, :D])
+            p_src = ops.linear(x_src, w[:, D:2 * D])
         seg = {}
         if ops._needs_grad(p_dst, p_src, edge_attr, w):  # training: the adjoint of the two row gathers = segment sums
             rowptr, edge_ids, _ = get_reverse_csr(csc)

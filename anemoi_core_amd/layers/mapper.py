@@ -158,7 +158,7 @@ class GraphTransformerBaseMapper(BaseMapper):
                                       (xs.shape[0], xd.shape[0]), model_comm_group, edges_are_dst_sorted=True, **kwargs)
         out_dst = self.post_process(x_dst_out)
         if sharded and not keep_x_dst_sharded:
-            out_dst = comm.gather_tensor(out_dst, 0, g["partition"].dst_splits, model_comm_group)
+            out_dst = comm.gather_tensor(out_dst.contiguous(), 0, g["partition"].dst_splits, model_comm_group)
         return out_dst
 
 
@@ -197,7 +197,7 @@ class GraphTransformerBaseMapper(BaseMapper):
                                       edges_are_dst_sorted=True, **kwargs)
         out_dst = self.post_process(x_dst_out)
         if not keep_x_dst_sharded:
-            out_dst = comm.gather_tensor(out_dst, 0, list(dst_sizes), group)
+            out_dst = comm.gather_tensor(out_dst.contiguous(), 0, list(dst_sizes), group)
         return out_dst
 
 
@@ -242,7 +242,14 @@ class GraphTransformerBackwardMapper(GraphTransformerBaseMapper):
 
     def post_process(self, x_dst):
         ln, lin = self.node_data_extractor[0], self.node_data_extractor[1]
-        return ops.linear(ops.layer_norm(x_dst, ln.weight, ln.bias, ln.eps), lin.weight, lin.bias)
+        h = ops.layer_norm(x_dst, ln.weight, ln.bias, ln.eps)
+        O = lin.out_features
+        if O % 8 and h.is_cuda and h.dtype != torch.float32 and not ops._needs_grad(h, lin.weight, lin.bias):
+            # inference: rows of the output padded to 16 bytes (a strided [N, O] view is returned), which is what the DMA-ring
+            # GEMM kernels need for their epilogue - the variable count (84 at O96) is rarely a multiple of 8
+            buf = torch.empty((h.shape[0], (O + 7) // 8 * 8), dtype=h.dtype, device=h.device)
+            return ops.linear(h, lin.weight, lin.bias, out=buf[:, :O])
+        return ops.linear(h, lin.weight, lin.bias)
 
 
 # ============================================================================================ GNN mappers

@@ -221,7 +221,7 @@ class AnemoiModelEncProcDec(nn.Module):
             # one kernel for cast / residual on the prognostic columns (instead of clone + index_select + index_add_)
             x_out = ops.assemble_output(x_out, x_skip.reshape(N, -1), col_map).view(1, 1, 1, N, -1)
         else:
-            x_out = x_out.view(batch_size, ensemble_size, N, self.n_step_output, -1).permute(0, 3, 1, 2, 4).to(dtype=dtype).clone()
+            x_out = x_out.reshape(batch_size, ensemble_size, N, self.n_step_output, -1).permute(0, 3, 1, 2, 4).to(dtype=dtype).clone()
             # SkipConnection._expand_time (layers/residual.py:53-57): the skip is repeated over the output steps
             skip = x_skip.unsqueeze(1).expand(-1, self.n_step_output, -1, -1, -1)
             x_out.index_add_(-1, out_idx, skip.index_select(-1, in_idx).to(dtype))

@@ -6,8 +6,9 @@
    oracle is evaluated on a random sample of destination rows (each destination depends on all hidden rows but on no other
    destination), the encoder's on all of them;
  * O96 -> res 6 encoder: 64 hidden nodes have NO in-edge (empty softmax segment -> attention output 0);
- * config 2, the exact benchmark model (O96 -> res 5, 16 processor layers, 512 channels, 16 heads, 84 variables x 2 steps):
-   the HIP forward in fp32 and in bf16 against `oracle.enc_proc_dec_forward` (a few seconds of host time);
+ * config 2, the exact benchmark model (O96 -> res 5, 16 processor layers, 512 channels, 16 heads, 84 variables x 2 steps)
+   and config 5 (the same with GNN / GraphConv encoder, processor and decoder): the HIP forward in fp32 and in bf16 against
+   `oracle.enc_proc_dec_forward` (a few seconds of host time each);
  * the reference's inference chunking knobs (environment variables, `num_chunks`) change nothing.
 
 Tolerances (s = max(1, max |ref|)).  fp32: max |err| <= 2e-5 * s per mapper and 5e-5 * s after the 18 chained blocks of the
@@ -150,28 +151,33 @@ def test_o96_res6_encoder_zero_in_degree_vs_oracle(dtype):
     _check(f"O96->res6 encoder {dtype}, the {int(iso.sum())} zero-in-degree rows", got[iso], want[iso], dtype)
 
 
-@pytest.fixture(scope="module")
-def bench_model():
-    """bench.py's model, built exactly as bench.build() does (config o96)."""
+_BENCH_MODELS: dict = {}
+
+
+def _bench_model(kind):
+    """bench.py's model, built exactly as bench.build() does (config o96 / gnn)."""
     import argparse
 
     import bench
 
-    args = argparse.Namespace(data_grid="o96", hidden_res=5, kind="gt", channels=512, layers=16, heads=16, vars=84)
-    g, model, x = bench.build(args, DEV)
-    params = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    return g, model, x, params
+    if kind not in _BENCH_MODELS:
+        args = argparse.Namespace(data_grid="o96", hidden_res=5, kind=kind, channels=512, layers=16, heads=16, vars=84)
+        g, model, x = bench.build(args, DEV)
+        _BENCH_MODELS[kind] = (g, model, x, {k: v.detach().clone() for k, v in model.state_dict().items()})
+    return _BENCH_MODELS[kind]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_bench_model_vs_oracle(bench_model, dtype):
-    """BASELINE config 2 = the benchmark: the full 16-layer O96 forward against the CPU oracle (same weights, same inputs)."""
+@pytest.mark.parametrize("kind", ["gt", "gnn"])
+def test_bench_model_vs_oracle(kind, dtype):
+    """BASELINE config 2 (GraphTransformer) = the benchmark, and config 5 (GNNProcessor, same graph): the full 16-layer O96
+    forward against the CPU oracle (same weights, same inputs)."""
     import copy
 
     from oracle import gt_oracle as O
 
-    g, model, x, params = bench_model
-    cfg = dict(kind="gt", num_heads=16, num_layers=16, num_channels=512)
+    g, model, x, params = _bench_model(kind)
+    cfg = dict(kind=kind, num_heads=16, num_layers=16, num_channels=512)
     m = copy.deepcopy(model)
     if dtype != torch.float32:
         m = m.to(dtype)
@@ -186,7 +192,9 @@ def test_bench_model_vs_oracle(bench_model, dtype):
     with torch.no_grad():
         want = O.enc_proc_dec_forward(params, cfg, g, x)
     assert got.shape == want.shape == (1, 1, 1, g.num_data, 84)
-    _check(f"bench model (O96, 16 layers) {dtype}", got.float().cpu(), want, dtype, fp32_tol=5e-5)
+    _check(f"bench model ({kind}, O96, 16 layers) {dtype}", got.float().cpu(), want, dtype, fp32_tol=5e-5)
+    del m
+    torch.cuda.empty_cache()
 
 
 def test_inference_chunk_knobs_change_nothing(monkeypatch):
