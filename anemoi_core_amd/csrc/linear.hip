@@ -1480,13 +1480,13 @@ static int launch_mfma(const LinArgs& a, hipStream_t st) {
   return check_launch("linear_mfma_kernel");
 }
 
-template <typename T>
+template <typename T, bool RES = true>
 static int launch_stats_producer(const LinArgs& a, hipStream_t st) {
   // y = x W^T + b + residual, plus the row statistics of y for the LayerNorm the next GEMM folds in (O = 512-class outputs):
   // the kernel choice of launch_persistent for this shape, with the statistics epilogue
   const int nk = (a.K1 + a.K2) / BK;
   const double c4 = tile_cost_us(256, 128, a.n_rows, a.O, nk), c3 = tile_cost_us(192, 128, a.n_rows, a.O, nk);
-  constexpr int EPI = EPI_RES | EPI_STATS;
+  constexpr int EPI = (RES ? EPI_RES : 0) | EPI_STATS;  // without a residual: the embedding in front of a mapper's LayerNorm
   {
     constexpr int TM = 160;
     const int rem160 = a.n_rows % TM;
@@ -1503,7 +1503,9 @@ static int launch_stats_producer(const LinArgs& a, hipStream_t st) {
       return launch_splitwave<T, EPI, 5, 2, 2, 2>(m, st);
     }
   }
-  return c3 < c4 ? launch_persistent_wm<T, EPI, 3, true>(a, st) : launch_persistent_wm<T, EPI, 4, true>(a, st);
+  (void)c3;
+  (void)c4;
+  return launch_persistent<T, EPI>(a, st);  // the kernel choice of the same shape without statistics (big tiles at 40 320 rows)
 }
 
 template <typename T>
@@ -1516,7 +1518,10 @@ static int launch_lnfold_consumer(const LinArgs& a, hipStream_t st) {
     m.tail_rows = rem;
   }
   const int64_t t320 = (int64_t)((m.n_rows + 319) / 320) * ((a.O + 255) / 256);
-  if (t320 <= 256 && m.n_rows % 160 == 0)  // two 160 x 256 tiles per CU (see launch_persistent)
+  // 160-row tiles also beyond one round (40 320-row mapper GEMMs): the fold's epilogue has no registers to spare at 160
+  // accumulators per lane (MI = 10: +7 us on [40320 x 512] -> 1024), at 80 it is free; ANEMOI_LNFOLD_MI5=0 restores the rule
+  static const int always5 = [] { const char* e = getenv("ANEMOI_LNFOLD_MI5"); return e ? atoi(e) : 1; }();
+  if ((t320 <= 256 || always5) && m.n_rows % 160 == 0)  // two 160 x 256 tiles per CU (see launch_persistent)
     return a.act == ANEMOI_ACT_GELU ? launch_bigtile<T, EPI_LNFOLD | EPI_GELU, 5>(m, st) : launch_bigtile<T, EPI_LNFOLD, 5>(m, st);
   return a.act == ANEMOI_ACT_GELU ? launch_bigtile<T, EPI_LNFOLD | EPI_GELU, 10>(m, st) : launch_bigtile<T, EPI_LNFOLD, 10>(m, st);
 }
@@ -1549,7 +1554,7 @@ extern "C" int anemoi_linear_splitk_f32(const void* x, int64_t ldx, const void* 
 extern "C" int anemoi_linear_stats_fwd(const void* x, int64_t ldx, int32_t K, const void* w, int64_t ldw, const void* bias,
                                        const void* residual, int64_t ldr, void* y, int64_t ldy, float* stats_out, int32_t n_rows,
                                        int32_t O, anemoi_dtype_t dtype, void* stream) {
-  ANEMOI_REQUIRE(n_rows > 0 && O > 0 && K > 0 && x && w && y && residual && stats_out, "linear_stats_fwd: bad arguments");
+  ANEMOI_REQUIRE(n_rows > 0 && O > 0 && K > 0 && x && w && y && stats_out, "linear_stats_fwd: bad arguments");
   ANEMOI_REQUIRE(dtype == ANEMOI_BF16 || dtype == ANEMOI_F16, "linear_stats_fwd: 16-bit operands only");
   ANEMOI_REQUIRE(O % 64 == 0 && K % BK == 0, "linear_stats_fwd: O=%d and K=%d must be multiples of 64", O, K);
   LinArgs a{x, ldx, K, nullptr, 0, 0, w, ldw, bias, nullptr, 0, nullptr, nullptr, 0, nullptr, residual, ldr, y, ldy, n_rows, O, (int)ANEMOI_ACT_NONE};
@@ -1560,6 +1565,7 @@ extern "C" int anemoi_linear_stats_fwd(const void* x, int64_t ldx, int32_t K, co
     return ANEMOI_E_UNSUPPORTED;
   }
   hipStream_t st = as_stream(stream);
+  if (residual == nullptr) return dtype == ANEMOI_BF16 ? launch_stats_producer<bf16_t, false>(a, st) : launch_stats_producer<f16_t, false>(a, st);
   return dtype == ANEMOI_BF16 ? launch_stats_producer<bf16_t>(a, st) : launch_stats_producer<f16_t>(a, st);
 }
 

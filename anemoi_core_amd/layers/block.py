@@ -331,12 +331,25 @@ class GraphTransformerMapperBlock(GraphTransformerBaseBlock):
         A = self.attn_channels
         ln_s, ln_d = self.layer_norm_attention_src, self.layer_norm_attention_dest
         cond_src, cond_dst = cond if cond is not None else (None, None)  # block.py:979-980
-        xs_n = apply_layer_norm(ln_s, x_src, cond_src)
-        xd_n = apply_layer_norm(ln_d, x_dst, cond_dst)
-        w_qs, b_qs = self._fused.get("qs", [self.lin_query, self.lin_self])
-        w_kv, b_kv = self._fused.get("kv", [self.lin_key, self.lin_value])
-        qs = ops.linear(xd_n, w_qs, b_qs)
-        kv = ops.linear(xs_n, w_kv, b_kv)
+        # LayerNorm + projection per side; with the row statistics left by the mapper's embedding (``ln_stats``, inference) the
+        # LayerNorm is applied inside the projection GEMM from raw rows
+        st = layer_kwargs.get("ln_stats") or {}
+        qs = kv = None
+        if cond is None:
+            e = st.get("dst")
+            if e is not None and e[0] is x_dst and self._ln_fold_ok(ln_d, x_dst):
+                ws, c, d = self._fused.ln_folded("qs", [self.lin_query, self.lin_self], ln_d)
+                qs = ops.linear_ln_folded(x_dst, ws, c, d, e[1], ln_d.eps)
+            e = st.get("src")
+            if e is not None and e[0] is x_src and self._ln_fold_ok(ln_s, x_src):
+                ws, c, d = self._fused.ln_folded("kv", [self.lin_key, self.lin_value], ln_s)
+                kv = ops.linear_ln_folded(x_src, ws, c, d, e[1], ln_s.eps)
+        if qs is None:
+            w_qs, b_qs = self._fused.get("qs", [self.lin_query, self.lin_self])
+            qs = ops.linear(apply_layer_norm(ln_d, x_dst, cond_dst), w_qs, b_qs)
+        if kv is None:
+            w_kv, b_kv = self._fused.get("kv", [self.lin_key, self.lin_value])
+            kv = ops.linear(apply_layer_norm(ln_s, x_src, cond_src), w_kv, b_kv)
         if heads:
             train = ops._needs_grad(qs, kv, edge_attr, self.lin_edge.weight)
             out = self._heads_attention(qs[:, :A], kv[:, :A], kv[:, A:], edge_attr, edge_index, shard_info.src_nodes,

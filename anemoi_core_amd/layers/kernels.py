@@ -104,6 +104,20 @@ class PaddedLinear:
         self._sig = None
         self._w = None
 
+    def with_row_stats(self, x: Tensor, lin: nn.Linear):
+        """(y, stats) as ``ops.linear_with_row_stats`` (the LayerNorm that follows is folded into ITS consumer), or (y, None)
+        when the shape does not take that path.  Inference only."""
+        K, W = lin.weight.shape[1], x.shape[-1]
+        if x.dtype != torch.float32 and W % 64 == 0 and W >= K and not ops._needs_grad(x, lin.weight, lin.bias):
+            w = lin.weight
+            if W != K:
+                self(x[:0], lin)  # builds / refreshes the zero-padded weight copy
+                w = self._w
+            r = ops.linear_with_row_stats(x, w, lin.bias)
+            if r is not None:
+                return r
+        return self(x, lin), None
+
     def __call__(self, x: Tensor, lin: nn.Linear, **kw) -> Tensor:
         K, W = lin.weight.shape[1], x.shape[-1]
         if x.dtype == torch.float32 or (W == K and K % 8 == 0):

@@ -120,6 +120,17 @@ class GraphTransformerBaseMapper(BaseMapper):
         self.emb_nodes_dst = self.layer_factory.Linear(self.in_channels_dst, self.hidden_dim)
         self._emb_src, self._emb_dst = PaddedLinear(), PaddedLinear()
 
+    def _embed(self, padded: PaddedLinear, x: Tensor, lin, side: str, ln_stats: Optional[dict]) -> Tensor:
+        """The node embedding; with ``ln_stats`` (inference) it also leaves the row statistics of its output there when the
+        block's LayerNorm on that side can be folded into the GEMM behind it."""
+        ln = self.proc.layer_norm_attention_src if side == "src" else self.proc.layer_norm_attention_dest
+        if ln_stats is not None and x.is_cuda and x.dtype != torch.float32 and self.proc._ln_fold_ok(ln, x):
+            y, stats = padded.with_row_stats(x, lin)
+            if stats is not None:
+                ln_stats[side] = (y, stats)
+            return y
+        return padded(x, lin)
+
     # subclasses: pre_process(x_src_compact, x_dst) -> embedded pair, post_process(x_dst)
     def forward(self, x, batch_size: int, shard_info: BipartiteGraphShardInfo, edge_attr: Tensor, edge_index: Tensor,
                 model_comm_group=None, keep_x_dst_sharded: bool = False, edges_are_dst_sorted: bool = True, cond=None, **kwargs):
@@ -153,9 +164,12 @@ class GraphTransformerBaseMapper(BaseMapper):
             elif not g["all_connected"]:
                 c_src = ops.gather_rows(c_src, g["src_ids32"])
             kwargs["cond"] = (c_src, c_dst)
-        xs, xd = self.pre_process((x_src_c, x_dst))
+        # inference: the embeddings also emit the row statistics of their outputs, and the block folds LayerNorm_src / _dst into
+        # the k|v and q|self GEMMs (no LayerNorm launches on the 40 320-row side)
+        ln_stats = {} if cond is None else None
+        xs, xd = self.pre_process((x_src_c, x_dst), ln_stats=ln_stats)
         (_, x_dst_out), _ = self.proc((xs, xd), g["edge_attr"], g["edge_index"], shard_info, batch_size,
-                                      (xs.shape[0], xd.shape[0]), model_comm_group, edges_are_dst_sorted=True, **kwargs)
+                                      (xs.shape[0], xd.shape[0]), model_comm_group, edges_are_dst_sorted=True, ln_stats=ln_stats, **kwargs)
         out_dst = self.post_process(x_dst_out)
         if sharded and not keep_x_dst_sharded:
             out_dst = comm.gather_tensor(out_dst.contiguous(), 0, g["partition"].dst_splits, model_comm_group)
@@ -209,9 +223,10 @@ class GraphTransformerForwardMapper(GraphTransformerBaseMapper):
         super().__init__(out_channels_dst=None, **kwargs)
         self.emb_nodes_src = self.layer_factory.Linear(self.in_channels_src, self.hidden_dim)
 
-    def pre_process(self, x):
+    def pre_process(self, x, ln_stats: Optional[dict] = None):
         x_src, x_dst = x
-        return self._emb_src(x_src, self.emb_nodes_src), self._emb_dst(x_dst, self.emb_nodes_dst)
+        return (self._embed(self._emb_src, x_src, self.emb_nodes_src, "src", ln_stats),
+                self._embed(self._emb_dst, x_dst, self.emb_nodes_dst, "dst", ln_stats))
 
     def post_process(self, x_dst, **kwargs):
         return x_dst
@@ -236,9 +251,9 @@ class GraphTransformerBackwardMapper(GraphTransformerBaseMapper):
                     if module.bias is not None:
                         nn.init.constant_(module.bias, 0.0)
 
-    def pre_process(self, x):
+    def pre_process(self, x, ln_stats: Optional[dict] = None):
         x_src, x_dst = x
-        return x_src, self._emb_dst(x_dst, self.emb_nodes_dst)
+        return x_src, self._embed(self._emb_dst, x_dst, self.emb_nodes_dst, "dst", ln_stats)
 
     def post_process(self, x_dst):
         ln, lin = self.node_data_extractor[0], self.node_data_extractor[1]

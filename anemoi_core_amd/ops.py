@@ -616,8 +616,8 @@ def linear_wgrad(dz: Tensor, x: Tensor, with_bias_grad: bool = False):
     return (dw, db) if with_bias_grad else dw
 
 
-def linear_with_row_stats(x: Tensor, weight: Tensor, bias: Optional[Tensor], residual: Tensor):
-    """(y, stats) with y = x W^T + bias + residual and stats [N, O/64, 2] fp32 = per 64-column strip (sum, sum of squares) of
+def linear_with_row_stats(x: Tensor, weight: Tensor, bias: Optional[Tensor], residual: Optional[Tensor] = None):
+    """(y, stats) with y = x W^T + bias [+ residual] and stats [N, O/64, 2] fp32 = per 64-column strip (sum, sum of squares) of
     the stored rows of y — what ``linear_ln_folded`` needs to apply the LayerNorm of y.  None if the shape is not eligible."""
     _dev(x, weight, bias, residual)
     N, K = x.shape

@@ -176,7 +176,8 @@ int anemoi_gelu_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, int32_t n_
 /* LayerNorm folded into the GEMMs around it (inference).  For y = LN(x; gamma, beta) W^T + b:
  *     y = rstd (x (W diag gamma)^T - mean c) + d,   c = row sums of W diag(gamma),  d = W beta + b
  * so the normalisation needs only the per-row mean / rstd of x, and those come for free from the GEMM that PRODUCED x:
- *  - anemoi_linear_stats_fwd: y = x W^T + bias + residual (as anemoi_linear_fwd) and stats_out[n_rows][O/64][2] (fp32) =
+ *  - anemoi_linear_stats_fwd: y = x W^T + bias + residual (as anemoi_linear_fwd; residual may be NULL: the embedding in
+ *    front of a mapper's LayerNorm, layers/mapper.py:556-570) and stats_out[n_rows][O/64][2] (fp32) =
  *    (sum, sum of squares) of every 64-column strip of the stored (rounded) output row.  Plain stores, one per (row, strip):
  *    no atomics, no zeroing, deterministic.  O and K multiples of 64.
  *  - anemoi_linear_lnfold_fwd: y = act(LN(x) W^T + b) from raw x [n_rows, K], w_scaled = W diag(gamma) [O, K], fp32 c, d [O]
@@ -186,7 +187,8 @@ int anemoi_gelu_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, int32_t n_
  *  UNWRITTEN; the consumer never reads them - it takes the statistics of its own trailing rows (n_rows % 320 <= 32) from the
  *  rows themselves.
  * Replaces the two LayerNorm launches of a GraphTransformerProcessorBlock (layer_norm_attention / layer_norm_mlp_dst,
- * layers/block.py:1237, 1271) in the unsharded inference path.  Returns ANEMOI_E_UNSUPPORTED for shapes / alignments the
+ * layers/block.py:1237, 1271) and layer_norm_attention_src / _dest of a GraphTransformerMapperBlock (layers/block.py:979-984)
+ * in the unsharded inference path.  Returns ANEMOI_E_UNSUPPORTED for shapes / alignments the
  * ring kernels do not take (the caller falls back to LayerNorm + anemoi_linear_fwd). */
 int anemoi_linear_stats_fwd(const void* x, int64_t ldx, int32_t K, const void* w, int64_t ldw, const void* bias,
                             const void* residual, int64_t ldr, void* y, int64_t ldy, float* stats_out, int32_t n_rows,
