@@ -1404,7 +1404,10 @@ static int launch_persistent(const LinArgs& a, hipStream_t st) {
     // 0.7 us for its DMA, tools/dma_rate_probe.hip), not by the 44 % extra operand bytes.
     static const int half_mi = [] { const char* e = getenv("ANEMOI_GEMM_BIG_MI"); return e ? atoi(e) : 5; }();
     const int64_t t320 = (int64_t)((main_rows + 319) / 320) * ((a.O + 255) / 256);
-    if (half_mi == 5 && t320 <= 256 && main_rows % 160 == 0) return launch_bigtile<T, EPI, 5>(m, st);
+    // ... and up to two rounds of them (GraphConv's [81840 x 512] -> 512 edge GEMMs: 8.66 -> 8.36 ms per GNN forward); beyond
+    // that the drain is hidden anyway and the 320-row tile's lower operand traffic wins (N320: 15.5 against 15.85 ms)
+    static const int max_t320 = [] { const char* e = getenv("ANEMOI_GEMM_BIG_MI5_T320"); return e ? atoi(e) : 512; }();
+    if (half_mi == 5 && t320 <= max_t320) return launch_bigtile<T, EPI, 5>(m, st);
     return launch_bigtile<T, EPI, 10>(m, st);
   }
   // narrow outputs with a long K in ONE round of 160 x 128 tiles (MLP-2 of the hidden mesh: [10242 x 2048] -> 512 = 64 x 4 tiles + 2
