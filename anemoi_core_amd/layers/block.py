@@ -357,7 +357,7 @@ class GraphTransformerMapperBlock(GraphTransformerBaseBlock):
         else:
             out = self._attention(qs[:, :A], kv[:, :A], kv[:, A:], qs[:, A:], edge_attr, csc,
                                   fused=dict(bufs=(qs, kv), q=(0, 0), s=(0, A), k=(1, 0), v=(1, A)))
-        nodes_new_dst = self._post_attention(out, x_dst, cond_dst)
+        nodes_new_dst = self._post_attention(out, x_dst, cond_dst, layer_kwargs.get("ln_chain"))  # chain: statistics for the processor's first LayerNorm
         if self.update_src_nodes:
             ln = self.layer_norm_mlp_src
             nodes_new_src = self.node_src_mlp(apply_layer_norm(ln, x_src, cond_src), residual=x_src)

@@ -74,6 +74,7 @@ class GraphTransformerProcessor(BaseProcessor):
     def forward(self, x: Tensor, batch_size: int, shard_info: GraphShardInfo, edge_attr: Tensor, edge_index: Tensor,
                 model_comm_group=None, edges_are_dst_sorted: bool = True, *args, **kwargs) -> Tensor:
         size = sum(shard_info.nodes) if shard_info.nodes_are_sharded() else x.shape[0]
+        ln_chain = kwargs.pop("ln_chain", None)  # the encoder's last GEMM may have left the row statistics of x (model glue)
         edge_attr, edge_index = ensure_edges_are_dst_sorted(
             edge_attr, edge_index, edges_are_sharded=shard_info.edges_are_sharded(), model_comm_group=model_comm_group,
             edges_are_dst_sorted=edges_are_dst_sorted,
@@ -88,7 +89,7 @@ class GraphTransformerProcessor(BaseProcessor):
         x, _ = self.run_layers(
             (x, edge_attr), edge_index=edge_index, shard_info=shard_info, batch_size=batch_size, size=size,
             model_comm_group=model_comm_group, edges_are_dst_sorted=True, halo_cache=self._halo_cache, edge_prep={},
-            ln_chain={},  # row statistics handed from a block's last GEMM to the next block's first (LayerNorm fold)
+            ln_chain={} if ln_chain is None else ln_chain,  # row statistics handed from a block's last GEMM to the next block's first (LayerNorm fold)
             **kwargs,
         )
         return x

@@ -261,6 +261,13 @@ class AnemoiModelEncProcDec(nn.Module):
         shard_sizes_hidden = get_shard_sizes(x_hidden_latent, 0, model_comm_group)
         x_hidden_latent = shard_tensor(x_hidden_latent, 0, shard_sizes_hidden, model_comm_group)
         latents, skips, data_latents, data_shards = {}, {}, {}, {}
+        # LayerNorm fold across the encoder / processor boundary (inference, one dataset, GraphTransformer on both sides): the
+        # encoder's last GEMM leaves the row statistics the processor's first LayerNorm needs
+        from ..layers.mapper import GraphTransformerForwardMapper
+        from ..layers.processor import GraphTransformerProcessor
+
+        chain_kw = ({"ln_chain": {}} if len(names) == 1 and isinstance(self.encoder[names[0]], GraphTransformerForwardMapper)
+                    and isinstance(self.processor, GraphTransformerProcessor) else {})
         for ds in names:
             shard_sizes_data = grid_shard_sizes[ds] if in_out_sharded[ds] else None
             norm_in, norm_out = (_fused_norm or {}).get(ds, (None, None))
@@ -270,12 +277,12 @@ class AnemoiModelEncProcDec(nn.Module):
             info = BipartiteGraphShardInfo(src_nodes=shard_sizes_data, dst_nodes=shard_sizes_hidden, edges=es)
             x_data_latent, x_latent = self.encoder[ds]((x_data_latent, x_hidden_latent.to(x_data_latent.dtype)), batch_size=batch_size,
                                                        shard_info=info, edge_attr=ea, edge_index=ei,
-                                                       model_comm_group=model_comm_group, keep_x_dst_sharded=True)
+                                                       model_comm_group=model_comm_group, keep_x_dst_sharded=True, **chain_kw)
             data_latents[ds], latents[ds] = x_data_latent, x_latent
         x_latent = latents[names[0]] if len(names) == 1 else sum(latents.values())
         ea, ei, es = self.processor_graph_provider.get_edges(batch_size=batch_size, model_comm_group=model_comm_group)
         x_latent_proc = self.processor(x=x_latent, batch_size=batch_size, shard_info=GraphShardInfo(nodes=shard_sizes_hidden, edges=es),
-                                       edge_attr=ea, edge_index=ei, model_comm_group=model_comm_group)
+                                       edge_attr=ea, edge_index=ei, model_comm_group=model_comm_group, **chain_kw)
         if self.latent_skip:
             x_latent_proc = x_latent_proc + x_latent
         out = {}
