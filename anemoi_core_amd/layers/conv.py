@@ -19,13 +19,16 @@ class GraphTransformerConv(nn.Module):
 
     def __init__(self, out_channels: int, dropout: float = 0.0, **kwargs):
         super().__init__()
-        if dropout != 0.0:
-            raise NotImplementedError("attention dropout is not supported by the fused kernel")
+        if not 0.0 <= dropout < 1.0:
+            raise ValueError(f"dropout must be in [0, 1), got {dropout}")
         self.out_channels = out_channels
-        self.dropout = dropout
+        self.dropout = dropout  # conv.py:145: dropout on the attention weights, active in training mode only
 
     def forward(self, query: Tensor, key: Tensor, value: Tensor, edge_attr: Optional[Tensor], edge_index: Tensor,
                 size=None, edges_are_dst_sorted: bool = False) -> Tensor:
+        if self.dropout > 0.0 and self.training:
+            # the reference's blocks never set it (block.py builds the conv without dropout); in eval mode it is the identity
+            raise NotImplementedError("attention dropout in training mode is not supported by the fused kernels (eval mode: no-op)")
         n_dst, H, C = query.shape
         size = (key.shape[0], n_dst) if size is None else size
         csc = get_csc(edge_index, size, edges_are_dst_sorted)

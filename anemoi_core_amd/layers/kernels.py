@@ -104,35 +104,46 @@ class PaddedLinear:
         self._sig = None
         self._w = None
 
-    def with_row_stats(self, x: Tensor, lin: nn.Linear):
-        """(y, stats) as ``ops.linear_with_row_stats`` (the LayerNorm that follows is folded into ITS consumer), or (y, None)
-        when the shape does not take that path.  Inference only."""
+    def _prep(self, x: Tensor, lin: nn.Linear, wide: bool = False):
+        """(x, weight) with the K dimension zero-padded as the MFMA kernels need it: a multiple of 8 (16-byte rows), or - for
+        tall inputs (or ``wide``) whose K is small or within 16 columns of it - of 64, so that the GEMM takes the DMA-ring
+        kernels (an 81 840-row edge embedding with K = 3 is bound by its 84 MB of output either way; the register-staged
+        kernel needs 44-90 us for it, the ring kernels ~20)."""
         K, W = lin.weight.shape[1], x.shape[-1]
-        if x.dtype != torch.float32 and W % 64 == 0 and W >= K and not ops._needs_grad(x, lin.weight, lin.bias):
-            w = lin.weight
-            if W != K:
-                self(x[:0], lin)  # builds / refreshes the zero-padded weight copy
-                w = self._w
-            r = ops.linear_with_row_stats(x, w, lin.bias)
-            if r is not None:
-                return r
-        return self(x, lin), None
-
-    def __call__(self, x: Tensor, lin: nn.Linear, **kw) -> Tensor:
-        K, W = lin.weight.shape[1], x.shape[-1]
-        if x.dtype == torch.float32 or (W == K and K % 8 == 0):
-            return ops.linear(x, lin.weight, lin.bias, **kw)
         if W == K:
-            x = torch.nn.functional.pad(x, (0, (-K) % 8))
-            W = x.shape[-1]
+            to64 = (wide or x.shape[0] >= 4096) and K % 64 and (K < 64 or (-K) % 64 <= 16)
+            pad = (-K) % 64 if to64 else (-K) % 8
+            if pad:
+                x = torch.nn.functional.pad(x, (0, pad))
+                W = x.shape[-1]
         elif W < K or W % 8:  # else: the caller already appended zero columns (one padded copy shared by several consumers,
             # possibly up to a multiple of 64 so that the GEMM takes the DMA-ring kernels)
             raise ValueError(f"input width {W} is neither in_features {K} nor a zero-padded width (multiple of 8 >= {K})")
+        if W == K:
+            return x, lin.weight
         if torch.is_grad_enabled() and lin.weight.requires_grad:  # training: gradients flow through the padding
-            return ops.linear(x, torch.nn.functional.pad(lin.weight, (0, W - K)), lin.bias, **kw)
+            return x, torch.nn.functional.pad(lin.weight, (0, W - K))
         sig = (lin.weight.data_ptr(), version(lin.weight), lin.weight.dtype, str(lin.weight.device), W)
         if self._sig != sig:
             with torch.no_grad():
                 self._w = torch.nn.functional.pad(lin.weight, (0, W - K)).contiguous()
             self._sig = sig
-        return ops.linear(x, self._w, lin.bias, **kw)
+        return x, self._w
+
+    def with_row_stats(self, x: Tensor, lin: nn.Linear):
+        """(y, stats) as ``ops.linear_with_row_stats`` (the LayerNorm that follows is folded into ITS consumer), or (y, None)
+        when the shape does not take that path.  Inference only."""
+        if x.dtype != torch.float32 and not ops._needs_grad(x, lin.weight, lin.bias):
+            xp, w = self._prep(x, lin, wide=True)
+            if xp.shape[-1] % 64 == 0:
+                r = ops.linear_with_row_stats(xp, w, lin.bias)
+                if r is not None:
+                    return r
+            return ops.linear(xp, w, lin.bias), None
+        return self(x, lin), None
+
+    def __call__(self, x: Tensor, lin: nn.Linear, **kw) -> Tensor:
+        if x.dtype == torch.float32:
+            return ops.linear(x, lin.weight, lin.bias, **kw)
+        x, w = self._prep(x, lin)
+        return ops.linear(x, w, lin.bias, **kw)

@@ -195,7 +195,9 @@ class AnemoiModelEncProcDec(nn.Module):
         """Node attributes of the hidden mesh; outside training (a static tensor) with the zero columns of the 16-byte row
         alignment already appended, once."""
         x = self.node_attributes(self._graph_name_hidden, batch_size=batch_size)
-        pad = (-x.shape[1]) % 8
+        # a handful of attribute columns: pad K to 64 (a static [N_hidden, 64] tensor) so that the hidden-node embedding takes the
+        # DMA-ring kernels and can emit the row statistics of the encoder's destination LayerNorm
+        pad = (-x.shape[1]) % 64 if _PAD64 and x.shape[1] < 64 else (-x.shape[1]) % 8
         if not pad or x.dtype == torch.float32 or (torch.is_grad_enabled() and x.requires_grad) or not all(self._prepad(ds) for ds in self.dataset_names):
             return x
         key = (x.data_ptr(), version(x), tuple(x.shape), x.dtype)
