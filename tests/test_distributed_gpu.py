@@ -213,3 +213,69 @@ def test_heads_strategy_full_model_on_hip_kernels():
     c = load_golden("model_tiny.pt")["gt"]
     for o in _spawn(_heads_model_worker, 2):
         assert float((o["out"] - c["out"]).abs().max()) < 2e-4
+
+
+_RCCL_ONE_RANK = r'''
+import os, sys, tempfile
+import torch, torch.distributed as dist
+sys.path.insert(0, os.environ["ANEMOI_REPO"])
+from anemoi_core_amd import ops
+from anemoi_core_amd.distributed import primitives as P
+from anemoi_core_amd.utils.segments import SegmentedGraph
+
+torch.cuda.set_device(0)
+with tempfile.TemporaryDirectory() as tmp:
+    dist.init_process_group("nccl", init_method=f"file://{tmp}/init", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    group = dist.group.WORLD
+    assert dist.get_backend(group) == "nccl"
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    n, k, D = 1000, 96, 512
+    x = torch.randn(n, D, device=dev).to(torch.bfloat16)
+    w = (torch.randn(256, D, device=dev) * D ** -0.5).to(torch.bfloat16)
+    g, b = torch.ones(D, device=dev, dtype=torch.bfloat16), torch.zeros(D, device=dev, dtype=torch.bfloat16)
+    send_index = torch.randperm(n, device=dev)[:k].to(torch.int32).contiguous()
+
+    def step():
+        buf = torch.empty(n + k, D, device=dev, dtype=torch.bfloat16)
+        ops.layer_norm(x, g, b, 1e-5, out=buf[:n])
+        P.halo_exchange_into(buf, n, send_index, [k], [k], group, ops.gather_rows)   # RCCL all_to_all_single (to self)
+        y = ops.linear(buf, w)
+        s = y.float().sum(0, keepdim=True)
+        P._all_reduce_sum(s, group)                                                     # RCCL all_reduce
+        return y, s
+
+    with torch.inference_mode():
+        for _ in range(2):
+            y0, s0 = step()
+        torch.cuda.synchronize()
+        want_halo = ops.layer_norm(x, g, b, 1e-5)[send_index.long()]
+        assert torch.equal(ops.linear(want_halo, w), y0[n:]), "halo rows"
+        sg = SegmentedGraph()
+        y, s = sg.capture(step)
+        assert sg.num_collectives == 2 and sg.num_graphs == 3, (sg.num_collectives, sg.num_graphs)
+        sg.replay(); torch.cuda.synchronize()
+        assert torch.equal(y, y0) and torch.equal(s, s0)
+        x.mul_(-0.5)                                   # new input at the same address: the replay must follow it
+        y1, s1 = step(); torch.cuda.synchronize()
+        sg.replay(); torch.cuda.synchronize()
+        assert torch.equal(y, y1) and torch.equal(s, s1) and not torch.equal(y1, y0)
+    dist.destroy_process_group()
+print("RCCL-ONE-RANK-OK")
+'''
+
+
+def test_rccl_collectives_between_graph_segments_one_rank():
+    """The product's N > 1 replay scheme on the REAL backend: `nccl` (= RCCL) all_to_all_single / all_reduce issued eagerly
+    between hipGraph segments on buffers of the graphs' private pool.  One rank is all a one-GPU test box offers (RCCL refuses
+    two ranks per device): the exchange goes to the rank itself, but the process group, the collective launches on RCCL's
+    stream, their ordering against the graph launches and the pool addressing are the ones of the 8-GPU run."""
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ANEMOI_REPO=repo, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL-ONE-RANK-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
