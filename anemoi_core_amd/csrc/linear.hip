@@ -1433,8 +1433,9 @@ static int launch_persistent(const LinArgs& a, hipStream_t st) {
   // is bound by the ~40 cycles a CU needs per 1-KiB LDS-DMA piece, i.e. by the tile's operand bytes, like the model says
   const double c1 = tile_cost_us(64, 128, a.n_rows, a.O, nk);
   if (c1 < 0.9 * (c3 < c4 ? c3 : c4)) {
-    if constexpr ((EPI & (EPI_STATS | EPI_LNFOLD)) == 0) {
-      // at most one round of 64 x 128 tiles: give every tile 8 waves (K split over wave groups) instead of 2
+    if constexpr ((EPI & EPI_LNFOLD) == 0) {
+      // at most one round of 64 x 128 tiles: give every tile 8 waves (K split over wave groups) instead of 2 (also with the
+      // row-statistics epilogue: the projection of a sharded mesh's block)
       static const bool sw = [] { const char* e = getenv("ANEMOI_GEMM_SPLITWAVE"); return !(e && e[0] == '0'); }();
       const int64_t t1 = (int64_t)((a.n_rows + SM - 1) / SM) * ((a.O + SN - 1) / SN);
       if (sw && t1 <= 256 && a.K2 == 0 && a.K1 % SK == 0 && a.splits == 1 && !a.f32_atomic) return launch_splitwave<T, EPI>(a, st);

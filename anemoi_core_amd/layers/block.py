@@ -28,11 +28,15 @@ from .utils import compute_mlp_hidden_dim
 from ..utils.tensors import version
 
 ANEMOI_DEBUG_SHARDING = os.environ.get("ANEMOI_DEBUG_SHARDING", "") != ""
-# LayerNorm folded into the neighbouring GEMMs (anemoi_linear_stats_fwd / anemoi_linear_lnfold_fwd): 32 of the 39 LayerNorm
-# launches of the O96 forward disappear.  On by default since both sides run on the fast interior-tile epilogue (-2.3 % forward
+# LayerNorm folded into the neighbouring GEMMs (anemoi_linear_stats_fwd / anemoi_linear_lnfold_fwd): 36 of the 39 LayerNorm
+# launches of the O96 forward disappear.  On by default since both sides run on the fast interior-tile epilogue (-3 % forward
 # time in same-box A/Bs; it was neutral with the generic epilogue: DESIGN.md section 5).  ANEMOI_LN_FOLD=0: LayerNorm + GEMM.
 _FUSED_EDGE_BWD = os.environ.get("ANEMOI_FUSED_EDGE_BWD", "1") == "1"  # 0: train through the materialised-E op (reference op boundary)
 _LN_FOLD = os.environ.get("ANEMOI_LN_FOLD", "1") == "1"
+# ... for tall operands only: the fold's consumer is the big-tile kernel (160 x 256 tiles), which leaves most of the chip idle
+# when there are few rows - measured per forward: 642 hidden nodes 1.72 ms without / 2.53 ms with the fold, 2 562 nodes 1.96 /
+# 2.05 ms, 10 242 nodes 3.09 / 3.00 ms.  Below this row count (one rank's rows of a sharded mesh, small meshes): LayerNorm + GEMM.
+_LN_FOLD_MIN_ROWS = int(os.environ.get("ANEMOI_LN_FOLD_MIN_ROWS", "4096"))
 
 
 class _FusedWeights:
@@ -264,7 +268,8 @@ class GraphTransformerBaseBlock(BaseBlock):
 
     def _ln_fold_ok(self, ln, x: Tensor) -> bool:
         """The LayerNorm-fold path: inference, 16-bit, plain affine LayerNorm (see include/anemoi_hip.h)."""
-        return (_LN_FOLD and type(ln).__name__ in ("LayerNorm", "AutocastLayerNorm") and x.dtype != torch.float32 and x.is_cuda
+        return (_LN_FOLD and x.shape[0] >= _LN_FOLD_MIN_ROWS and type(ln).__name__ in ("LayerNorm", "AutocastLayerNorm")
+                and x.dtype != torch.float32 and x.is_cuda
                 and not (torch.is_grad_enabled() and (x.requires_grad or ln.weight.requires_grad)))
 
     def _post_attention(self, attn_plus_self: Tensor, x_skip: Tensor, cond: Optional[Tensor] = None, chain: Optional[dict] = None) -> Tensor:

@@ -48,8 +48,8 @@ CONFIGS = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="o96", choices=sorted(CONFIGS), help="BASELINE.json configuration (default: the headline)")
     ap.add_argument("--data-grid", default=None)
     ap.add_argument("--hidden-res", type=int, default=None)

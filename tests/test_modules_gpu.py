@@ -272,3 +272,31 @@ def test_layer_kernels_plugins_run_standalone(dtype):
     assert float((xo.grad.float() - xr.grad).abs().max()) <= gtol * max(1.0, float(xr.grad.abs().max()))
     for (n, po), (_, pr) in zip(ours.named_parameters(), ref.named_parameters()):
         assert float((po.grad.float() - pr.grad).abs().max()) <= gtol * max(1.0, float(pr.grad.abs().max())), n
+
+
+def test_layernorm_fold_is_gated_by_row_count_and_equals_unfused(golden, monkeypatch):
+    """The LayerNorm fold (statistics from the producing GEMM, normalisation in the consuming big-tile GEMM) is taken for tall
+    operands only (layers/block.py: _LN_FOLD_MIN_ROWS; it is slower below a few thousand rows).  Forced on for the tiny
+    fixture model in bf16 it must agree with the unfused path at the bf16 rounding level, and by default it must not be
+    taken at this size (bit-equal to ANEMOI_LN_FOLD off)."""
+    from anemoi_core_amd.layers import block as B
+
+    case = golden("model_tiny.pt")["gt"]
+    model, g = build_model_from_fixture(case)
+    model.load_state_dict(case["params"], strict=True)
+    model = model.to(DEV).to(torch.bfloat16).eval()
+    x = {"data": case["x"].to(DEV).to(torch.bfloat16)}
+
+    def run():
+        with torch.inference_mode():
+            return model(x)["data"].float()
+
+    default = run()
+    monkeypatch.setattr(B, "_LN_FOLD", False)
+    unfused = run()
+    assert torch.equal(default, unfused)  # 642 hidden nodes: below the row threshold, the fold is not taken
+    monkeypatch.setattr(B, "_LN_FOLD", True)
+    monkeypatch.setattr(B, "_LN_FOLD_MIN_ROWS", 0)
+    folded = run()
+    s = max(1.0, float(unfused.abs().max()))
+    assert float((folded - unfused).abs().max()) <= 3e-2 * s and float((folded - unfused).abs().mean()) <= 5e-3
