@@ -39,6 +39,20 @@ _LN_FOLD = os.environ.get("ANEMOI_LN_FOLD", "1") == "1"
 _LN_FOLD_MIN_ROWS = int(os.environ.get("ANEMOI_LN_FOLD_MIN_ROWS", "4096"))
 
 
+_IDENTITY: dict = {}
+
+
+def _identity_index(x: Tensor) -> Tensor:
+    """int32 [0 .. rows) on x's device (cached per device and length)."""
+    key = (str(x.device), x.shape[0])
+    t = _IDENTITY.get(key)
+    if t is None:
+        if len(_IDENTITY) > 16:
+            _IDENTITY.clear()
+        t = _IDENTITY[key] = torch.arange(x.shape[0], dtype=torch.int32, device=x.device)
+    return t
+
+
 class _FusedWeights:
     """Concatenated projection weights ([Wq;Wk;Wv;Ws] ...) rebuilt only when a parameter changes."""
 
@@ -272,10 +286,14 @@ class GraphTransformerBaseBlock(BaseBlock):
                 and x.dtype != torch.float32 and x.is_cuda
                 and not (torch.is_grad_enabled() and (x.requires_grad or ln.weight.requires_grad)))
 
-    def _post_attention(self, attn_plus_self: Tensor, x_skip: Tensor, cond: Optional[Tensor] = None, chain: Optional[dict] = None) -> Tensor:
+    def _post_attention(self, attn_plus_self: Tensor, x_skip: Tensor, cond: Optional[Tensor] = None, chain: Optional[dict] = None,
+                        extra: Optional[Tensor] = None) -> Tensor:
         """projection + residual, LayerNorm, MLP + residual.  Inference: the projection GEMM also emits the row statistics of
         its output and the MLP's first GEMM applies the LayerNorm from them (no LayerNorm launch); with ``chain`` the last
-        GEMM does the same for the NEXT block's first LayerNorm."""
+        GEMM does the same for the NEXT block's first LayerNorm.  ``extra`` (last block of a processor): the model's latent
+        skip (encoder_processor_decoder.py:295-296), added by the last GEMM's epilogue as a second residual."""
+        if extra is not None and (ops._needs_grad(attn_plus_self, x_skip, extra, self.projection.weight) or extra.shape != x_skip.shape):
+            return self._post_attention(attn_plus_self, x_skip, cond, chain) + extra
         ln, mlp = self.layer_norm_mlp_dst, self.node_dst_mlp
         plain_mlp = mlp.mlp_implementation == "mlp" and len(mlp.mlp) == 3 and mlp.layer_norm is None
         if plain_mlp and self._ln_fold_ok(ln, attn_plus_self):
@@ -287,6 +305,8 @@ class GraphTransformerBaseBlock(BaseBlock):
                 h = ops.linear_ln_folded(out, ws, c, d, stats, ln.eps, act="gelu")
                 if h is None:
                     h = ops.linear(ops.layer_norm(out, ln.weight, ln.bias, ln.eps), lin1.weight, lin1.bias, act="gelu")
+                if extra is not None:  # second residual = the gather-add epilogue with the identity index
+                    return ops.linear(h, lin2.weight, lin2.bias, residual=out, g1=extra, idx1=_identity_index(extra))
                 r2 = ops.linear_with_row_stats(h, lin2.weight, lin2.bias, out) if chain is not None else None
                 if r2 is not None:
                     chain["x"], chain["stats"] = r2
@@ -294,7 +314,8 @@ class GraphTransformerBaseBlock(BaseBlock):
                 return ops.linear(h, lin2.weight, lin2.bias, residual=out)
         out = ops.linear(attn_plus_self, self.projection.weight, self.projection.bias, residual=x_skip)
         h = apply_layer_norm(ln, out, cond)
-        return self.node_dst_mlp(h, residual=out)
+        y = self.node_dst_mlp(h, residual=out)
+        return y if extra is None else y + extra
 
 
 class GraphTransformerMapperBlock(GraphTransformerBaseBlock):
@@ -424,7 +445,7 @@ class GraphTransformerProcessorBlock(GraphTransformerBaseBlock):
             q, k, v, x_r = qkvs[:, :A], qkvs[:, A:2 * A], qkvs[:, 2 * A:3 * A], qkvs[:, 3 * A:]
             csc = get_csc(edge_index, (x.shape[0], x.shape[0]), edges_are_dst_sorted)
             out = self._attention(q, k, v, x_r, edge_attr, csc)
-            return self._post_attention(out, x, cond, chain), edge_attr
+            return self._post_attention(out, x, cond, chain, kwargs.get("extra_residual")), edge_attr
         sharded = model_is_distributed(model_comm_group) and self.shard_strategy != "heads"
         x_plus_halo = None
         if (sharded and cond is None and not isinstance(ln, ConditionalLayerNorm) and not ops._needs_grad(x, ln.weight)):
@@ -437,7 +458,8 @@ class GraphTransformerProcessorBlock(GraphTransformerBaseBlock):
         else:
             xn = apply_layer_norm(ln, x, cond)
         if model_is_distributed(model_comm_group) and self.shard_strategy == "heads":
-            return self._forward_heads(x, xn, edge_attr, edge_index, shard_info, batch_size, model_comm_group, cond, halo_cache), edge_attr
+            return self._forward_heads(x, xn, edge_attr, edge_index, shard_info, batch_size, model_comm_group, cond, halo_cache,
+                                       extra=kwargs.get("extra_residual")), edge_attr
         if model_is_distributed(model_comm_group):
             plan = self._halo_plan(x, edge_index, shard_info, batch_size, model_comm_group, halo_cache)
             if x_plus_halo is None:
@@ -467,10 +489,10 @@ class GraphTransformerProcessorBlock(GraphTransformerBaseBlock):
             fused = dict(bufs=(qkvs,), q=(0, 0), k=(0, A), v=(0, 2 * A), s=(0, 3 * A))
             csc = get_csc(edge_index, (n, n), edges_are_dst_sorted)
         out = self._attention(q, k, v, x_r, edge_attr, csc, fused=fused, edge_prep=kwargs.get("edge_prep"))
-        return self._post_attention(out, x, cond), edge_attr
+        return self._post_attention(out, x, cond, extra=kwargs.get("extra_residual")), edge_attr
 
 
-    def _forward_heads(self, x, xn, edge_attr, edge_index, shard_info, batch_size, group, cond, cache: Optional[dict]):
+    def _forward_heads(self, x, xn, edge_attr, edge_index, shard_info, batch_size, group, cond, cache: Optional[dict], extra=None):
         """shard_strategy="heads" (see ``_heads_attention``): the fused q/k/v/self projection runs on the local rows."""
         if batch_size != 1:
             raise ValueError("shard_strategy='heads' requires batch_size=1 when model sharding is enabled.")
@@ -482,7 +504,7 @@ class GraphTransformerProcessorBlock(GraphTransformerBaseBlock):
         w, b = self._fused.get("qkvs", [self.lin_query, self.lin_key, self.lin_value, self.lin_self])
         qkvs = ops.linear(xn, w, b)
         out = self._heads_attention(qkvs[:, :A], qkvs[:, A:2 * A], qkvs[:, 2 * A:3 * A], ea_full, ei_full, sizes, sizes, group, train)
-        return self._post_attention(out + qkvs[:, 3 * A:], x, cond)
+        return self._post_attention(out + qkvs[:, 3 * A:], x, cond, extra=extra)
 
 
 class HaloPlan:

@@ -36,9 +36,10 @@ class BaseProcessor(nn.Module):
     def build_layers(self, layer_class, *layer_args, **layer_kwargs) -> None:
         self.proc = nn.ModuleList([layer_class(*layer_args, **layer_kwargs) for _ in range(self.num_layers)])
 
-    def run_layers(self, data: tuple, *args, **kwargs) -> tuple:
-        for layer in self.proc:
-            data = layer(*data, *args, **kwargs)
+    def run_layers(self, data: tuple, *args, last_layer_kwargs: Optional[dict] = None, **kwargs) -> tuple:
+        for i, layer in enumerate(self.proc):
+            extra = last_layer_kwargs if (last_layer_kwargs and i == len(self.proc) - 1) else {}
+            data = layer(*data, *args, **kwargs, **extra)
         return data
 
 
@@ -75,6 +76,7 @@ class GraphTransformerProcessor(BaseProcessor):
                 model_comm_group=None, edges_are_dst_sorted: bool = True, *args, **kwargs) -> Tensor:
         size = sum(shard_info.nodes) if shard_info.nodes_are_sharded() else x.shape[0]
         ln_chain = kwargs.pop("ln_chain", None)  # the encoder's last GEMM may have left the row statistics of x (model glue)
+        latent_skip = kwargs.pop("latent_skip", None)  # model glue: x_latent, added by the LAST block's last GEMM (returns x + skip)
         edge_attr, edge_index = ensure_edges_are_dst_sorted(
             edge_attr, edge_index, edges_are_sharded=shard_info.edges_are_sharded(), model_comm_group=model_comm_group,
             edges_are_dst_sorted=edges_are_dst_sorted,
@@ -90,6 +92,7 @@ class GraphTransformerProcessor(BaseProcessor):
             (x, edge_attr), edge_index=edge_index, shard_info=shard_info, batch_size=batch_size, size=size,
             model_comm_group=model_comm_group, edges_are_dst_sorted=True, halo_cache=self._halo_cache, edge_prep={},
             ln_chain={} if ln_chain is None else ln_chain,  # row statistics handed from a block's last GEMM to the next block's first (LayerNorm fold)
+            last_layer_kwargs=None if latent_skip is None else {"extra_residual": latent_skip},
             **kwargs,
         )
         return x

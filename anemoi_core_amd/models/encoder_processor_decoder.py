@@ -283,9 +283,12 @@ class AnemoiModelEncProcDec(nn.Module):
             data_latents[ds], latents[ds] = x_data_latent, x_latent
         x_latent = latents[names[0]] if len(names) == 1 else sum(latents.values())
         ea, ei, es = self.processor_graph_provider.get_edges(batch_size=batch_size, model_comm_group=model_comm_group)
+        # the latent skip (:295-296) rides in the last processor block's last GEMM (GraphTransformer processor), else one add
+        fuse_skip = self.latent_skip and isinstance(self.processor, GraphTransformerProcessor)
         x_latent_proc = self.processor(x=x_latent, batch_size=batch_size, shard_info=GraphShardInfo(nodes=shard_sizes_hidden, edges=es),
-                                       edge_attr=ea, edge_index=ei, model_comm_group=model_comm_group, **chain_kw)
-        if self.latent_skip:
+                                       edge_attr=ea, edge_index=ei, model_comm_group=model_comm_group, **chain_kw,
+                                       **({"latent_skip": x_latent} if fuse_skip else {}))
+        if self.latent_skip and not fuse_skip:
             x_latent_proc = x_latent_proc + x_latent
         out = {}
         for ds in names:
