@@ -20,7 +20,10 @@
 
 namespace anemoi {
 
-constexpr int kWavesPerBlock = 4;
+#ifndef ANEMOI_ATTN_WPB
+#define ANEMOI_ATTN_WPB 4
+#endif
+constexpr int kWavesPerBlock = ANEMOI_ATTN_WPB;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 
 template <int VEC>
@@ -137,7 +140,7 @@ struct WLayout {
 };
 
 template <typename T, int VEC, int LPH, int FE_PAD, bool KVADJ>
-__global__ __launch_bounds__(64 * kWavesPerBlock, 4) void gt_attn_fused_edge_fwd_kernel(
+__global__ __launch_bounds__(64 * kWavesPerBlock, 16 / kWavesPerBlock) void gt_attn_fused_edge_fwd_kernel(
     const T* __restrict__ q, int64_t ldq, const T* __restrict__ k, int64_t ldk, const T* __restrict__ v, int64_t ldv,
     const float* __restrict__ feat, const float* __restrict__ w_packed, const int32_t* __restrict__ row,
     const int32_t* __restrict__ colptr, const T* __restrict__ addend, int64_t ldadd, T* __restrict__ out, int64_t ldo,
