@@ -6,7 +6,8 @@ import json
 import sqlite3
 import sys
 
-FAMILIES = {"linear_mfma_*": "linear_mfma", "gt_attn_fused_edge_fwd_kernel": "gt_attn_fused_edge", "layernorm_fwd_kernel": "layernorm_fwd"}
+FAMILIES = {"linear_mfma_*": "linear_mfma", "gt_attn_fused_edge_fwd_kernel": "gt_attn_fused_edge", "layernorm_fwd_kernel": "layernorm_fwd",
+            "edge_ln_res_segsum_kernel": "edge_ln_res_segsum"}
 
 
 def per_kernel(db, counter):
