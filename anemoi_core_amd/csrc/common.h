@@ -1,8 +1,11 @@
 // Shared device/host helpers for libanemoi_hip.so (gfx950 / CDNA4 only: wave64, MFMA, DPP).
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <mutex>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "anemoi_hip.h"
 
@@ -145,15 +148,29 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
 
 // hipFuncSetAttribute (raised dynamic-LDS limit) is a per-DEVICE setting: one flag per device id, so that a second GPU
 // used from the same process gets the limit as well.
+// An integer tuning knob from the environment: unset, non-numeric or out-of-range values fall back to the default (a grid of
+// 0 workgroups from ANEMOI_ATTN_BLOCKS_PER_CU=0 used to fail with an opaque launch error).
+inline int env_int(const char* e, int dflt, int lo, int hi) {
+  if (e == nullptr || *e == 0) return dflt;
+  char* end = nullptr;
+  const long v = strtol(e, &end, 10);
+  if (end == e || *end != 0 || v < lo || v > hi) return dflt;
+  return (int)v;
+}
+
 struct PerDeviceOnce {
-  bool done[64] = {};
-  bool first() {
+  std::once_flag flag[64];
+  // Runs f once per device and returns only after it HAS run (a second thread waits instead of launching ahead of the
+  // raised LDS limit); device ids beyond the table simply run f every time (hipFuncSetAttribute is idempotent).
+  template <typename F>
+  void run(F&& f) {
     int d = 0;
     (void)hipGetDevice(&d);
-    d &= 63;
-    if (done[d]) return false;
-    done[d] = true;
-    return true;
+    if (d < 0 || d >= 64) {
+      f();
+      return;
+    }
+    std::call_once(flag[d], f);
   }
 };
 

@@ -463,7 +463,7 @@ static int launch_fast(const AttnArgs& a) {
     if (L::kFloats * sizeof(float) > 64 * 1024) return 1;  // beyond the default dynamic-LDS limit: generic path
     // persistent grid: at most ~6 workgroups per CU (LDS 25 KiB each, 5-6 waves/SIMD by registers); every wave walks
     // destinations d, d + total_waves, ... so the W' staging is paid once per workgroup
-    static const int per_cu = [] { const char* e = getenv("ANEMOI_ATTN_BLOCKS_PER_CU"); return e ? atoi(e) : 6; }();
+    static const int per_cu = [] { const char* e = getenv("ANEMOI_ATTN_BLOCKS_PER_CU"); return env_int(e, 6, 1, 32); }();
     const int max_blocks = 256 * per_cu;
     int blocks = (a.n_dst + kWavesPerBlock - 1) / kWavesPerBlock;
     blocks = blocks < max_blocks ? blocks : max_blocks;

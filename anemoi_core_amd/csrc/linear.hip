@@ -1325,10 +1325,10 @@ static int launch_persistent_wm(const LinArgs& a, hipStream_t st) {
   // (64*WM) x (64*WN) tile, WM*WN waves, ST-stage ring (3 stages = 144 KiB at 4 x 2: one workgroup per CU)
   constexpr int smem_bytes = ST * (64 * WM + 64 * WN) * BK * 2 + 1024;
   static PerDeviceOnce attr_once;
-  if (attr_once.first()) {
+  attr_once.run([&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_mfma_persistent_kernel<T, WM, WN, ST, EPI, PP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
-  }
+  });
   const int tm = (a.n_rows + 64 * WM - 1) / (64 * WM), tn = (a.O + 64 * WN - 1) / (64 * WN);
   const int nt = tm * tn * a.splits;
   const int per_cu = (160 * 1024) / smem_bytes < 1 ? 1 : (160 * 1024) / smem_bytes;  // small tiles: several workgroups per CU
@@ -1346,10 +1346,10 @@ static int launch_splitwave(const LinArgs& a, hipStream_t st) {
   constexpr int smem_bytes = ring > fin ? ring : fin;
   static_assert(smem_bytes <= 160 * 1024, "LDS");
   static PerDeviceOnce attr_once;
-  if (attr_once.first()) {
+  attr_once.run([&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_mfma_splitwave_kernel<T, EPI, MI, WR, KG, STAGES, SKW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
-  }
+  });
   const int tm = (a.n_rows + TM - 1) / TM, tn = (a.O + SN - 1) / SN;
   hipLaunchKernelGGL((linear_mfma_splitwave_kernel<T, EPI, MI, WR, KG, STAGES, SKW>), dim3(tm * tn), dim3(512), smem_bytes, st, a, tn, tm * tn);
   return check_launch("linear_mfma_splitwave_kernel");
@@ -1360,10 +1360,10 @@ static int launch_bigtile(const LinArgs& a, hipStream_t st) {
   constexpr int TBM = 32 * MI, TBN = 256;
   constexpr int smem_bytes = 2 * (TBM + TBN) * BK * 2 + 1024 + ((EPI & EPI_LNFOLD) ? 2 * TBM * 2 * 4 : 0);
   static PerDeviceOnce attr_once;
-  if (attr_once.first()) {
+  attr_once.run([&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_mfma_bigtile_kernel<T, MI, EPI>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
-  }
+  });
   const int tm = (a.n_rows + TBM - 1) / TBM, tn = (a.O + TBN - 1) / TBN;
   const int nt = tm * tn;
   const int grid = nt < 256 ? nt : 256;
@@ -1402,11 +1402,11 @@ static int launch_persistent(const LinArgs& a, hipStream_t st) {
     // (tools/gemm_phase_timing.py).  160 x 256 tiles instead: two per CU, the first tile's output drains under the second
     // tile's K-loop, whose rate is set by the MFMAs (power-limited clock: 1.9 us per 320-row K-step on random data against
     // 0.7 us for its DMA, tools/dma_rate_probe.hip), not by the 44 % extra operand bytes.
-    static const int half_mi = [] { const char* e = getenv("ANEMOI_GEMM_BIG_MI"); return e ? atoi(e) : 5; }();
+    static const int half_mi = [] { const char* e = getenv("ANEMOI_GEMM_BIG_MI"); return env_int(e, 5, 5, 10); }();
     const int64_t t320 = (int64_t)((main_rows + 319) / 320) * ((a.O + 255) / 256);
     // ... and up to two rounds of them (GraphConv's [81840 x 512] -> 512 edge GEMMs: 8.66 -> 8.36 ms per GNN forward); beyond
     // that the drain is hidden anyway and the 320-row tile's lower operand traffic wins (N320: 15.5 against 15.85 ms)
-    static const int max_t320 = [] { const char* e = getenv("ANEMOI_GEMM_BIG_MI5_T320"); return e ? atoi(e) : 512; }();
+    static const int max_t320 = [] { const char* e = getenv("ANEMOI_GEMM_BIG_MI5_T320"); return env_int(e, 512, 0, 1 << 30); }();
     if (half_mi == 5 && t320 <= max_t320) return launch_bigtile<T, EPI, 5>(m, st);
     return launch_bigtile<T, EPI, 10>(m, st);
   }
@@ -1477,9 +1477,9 @@ static int launch_mfma(const LinArgs& a, hipStream_t st) {
   const int tiles_m = (a.n_rows + BM - 1) / BM, tiles_n = (a.O + BN - 1) / BN;
   const int num_tiles = tiles_m * tiles_n;
   static PerDeviceOnce attr_once;
-  if (attr_once.first()) {
+  attr_once.run([&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_mfma_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kTileBytes);
-  }
+  });
   hipLaunchKernelGGL((linear_mfma_kernel<T>), dim3(num_tiles), dim3(256), 4 * kTileBytes, st, a, tiles_n, num_tiles);
   return check_launch("linear_mfma_kernel");
 }
@@ -1493,9 +1493,14 @@ static int launch_stats_producer(const LinArgs& a, hipStream_t st) {
   constexpr int EPI = (RES ? EPI_RES : 0) | EPI_STATS;  // without a residual: the embedding in front of a mapper's LayerNorm
   {
     constexpr int TM = 160;
-    const int rem160 = a.n_rows % TM;
-    const bool split160 = rem160 > 0 && rem160 <= 32 && a.n_rows > TM;
-    const int rows160 = split160 ? a.n_rows - rem160 : a.n_rows;
+    // ONE tail rule on both sides of the fold: the consumer (launch_lnfold_consumer) recomputes the statistics of a row
+    // from the row itself only for the rows beyond a multiple of 320 (at most 32 of them) - so only those may be peeled
+    // here without strip sums.  A remainder of 161..192 mod 320 (<= 32 mod 160) goes through a ragged last tile, which
+    // writes the strip sums of every valid row.
+    const int rem320 = a.n_rows % 320;
+    const bool split160 = rem320 > 0 && rem320 <= 32 && a.n_rows > 320;
+    const int rem160 = split160 ? rem320 : 0;
+    const int rows160 = a.n_rows - rem160;
     const int64_t t160 = (int64_t)((rows160 + TM - 1) / TM) * ((a.O + SN - 1) / SN);
     static const bool narrow = [] { const char* e = getenv("ANEMOI_GEMM_NARROW"); return !(e && e[0] == '0'); }();
     if (narrow && t160 > 128 && t160 <= 256 && a.K2 == 0 && a.K1 >= 1024 && a.K1 % SK == 0) {
@@ -1506,7 +1511,7 @@ static int launch_stats_producer(const LinArgs& a, hipStream_t st) {
       if (n64) return launch_splitwave<T, EPI, 5, 2, 2, 4, 64>(m, st);
       return launch_splitwave<T, EPI, 5, 2, 2, 2>(m, st);
     }
-  }
+  });
   (void)c3;
   (void)c4;
   return launch_persistent<T, EPI>(a, st);  // the kernel choice of the same shape without statistics (big tiles at 40 320 rows)

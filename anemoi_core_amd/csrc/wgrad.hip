@@ -266,8 +266,7 @@ template <typename T, bool BIAS, int TKS, int STAGES>
 int launch_wgrad_cfg(const WgradArgs& a, hipStream_t st) {
   constexpr int lds = STAGES * 2 * TKS * TM * 2;
   static PerDeviceOnce attr_once;
-  if (attr_once.first())
-    (void)hipFuncSetAttribute((const void*)wgrad_tn_kernel<T, BIAS, TKS, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  attr_once.run([&] { (void)hipFuncSetAttribute((const void*)wgrad_tn_kernel<T, BIAS, TKS, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
   hipLaunchKernelGGL((wgrad_tn_kernel<T, BIAS, TKS, STAGES>), dim3(a.tiles_m * a.tiles_n * a.splits), dim3(256), lds, st, a);
   return check_launch("wgrad_tn_kernel");
 }

@@ -214,9 +214,10 @@ class AnemoiModelEncProcDec(nn.Module):
         col_map = getattr(self, f"_col_map_{ds}")
         fusable = (col_map is not None and batch_size == 1 and ensemble_size == 1 and self.n_step_output == 1 and x_out.is_cuda
                    and not (torch.is_grad_enabled() and (x_out.requires_grad or x_skip.requires_grad)))
-        if skip_is_raw and not fusable:
+        fused_norm = fusable and skip_is_raw and x_skip.dtype == dtype and dtype in (x_out.dtype, torch.float32)
+        if skip_is_raw and not fused_norm:  # every path but the fused-normalisation kernel takes a NORMALISED skip
             x_skip, skip_is_raw = norm.transform(x_skip, in_place=False), False
-        if fusable and skip_is_raw and x_skip.dtype == dtype and dtype in (x_out.dtype, torch.float32):
+        if fused_norm:
             mul, add = norm.column_program(x_skip.shape[-1])
             x_out = ops.assemble_output(x_out, x_skip.reshape(N, -1), col_map, mul, add).view(1, 1, 1, N, -1)
         elif fusable and x_out.dtype == dtype and x_skip.dtype == dtype:
@@ -338,6 +339,9 @@ class AnemoiModelEncProcDec(nn.Module):
                 pre, post = self._sole_normalizer(pre_processors[ds], False), self._sole_normalizer(post_processors[ds], True)
                 if pre is not None and post is not None and x[ds].is_cuda:
                     fused[ds] = (pre, post)
+                    check = getattr(pre_processors[ds], "check_first_batch", None)
+                    if check is not None and getattr(pre_processors[ds], "_awaiting_first_batch", False):
+                        check(pre.transform(x[ds], in_place=False))  # the chain's one-off NaN check survives the fusion
                 else:
                     x[ds] = pre_processors[ds](x[ds], in_place=False)
             y_hat = self.forward(x, model_comm_group=model_comm_group, grid_shard_sizes=grid_shard_sizes, _fused_norm=fused, **kwargs)

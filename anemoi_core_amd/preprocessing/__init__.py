@@ -1,91 +1,134 @@
-"""Pre- / post-processors at the model edge — mirror of the reference's ``anemoi.models.preprocessing`` package for the one
-processor that sits on the hot path, the input normaliser (preprocessing/__init__.py:22-206, normalizer.py:24-252).
+"""Pre- / post-processors at the model edge (scope row f4) for the one processor on the hot path, the input normaliser.
 
-``BasePreprocessor`` parses the reference's processor config (default / remap / method lists), ``Processors`` chains
-processors (reversed when ``inverse``) exactly like the reference.  ``InputNormalizer`` keeps the reference's buffers and
-state_dict keys; its arithmetic is a per-variable affine map that the model fuses into its input / output assembly kernels
-(``AnemoiModelEncProcDec.predict_step``)."""
+Written from the documented behaviour of the reference's ``anemoi.models.preprocessing`` package, not from its text:
+
+* a processor is configured by a mapping whose reserved entries are ``default`` (method for unlisted variables, "none"
+  when absent), ``remap`` ({variable: variable whose statistics it borrows}), ``normalizer`` and ``method_kwargs``; every
+  other entry reads ``<method>: <variable> | [<variables>]``; entries that are ``None`` or the string "none" do not count
+  (reference preprocessing/__init__.py:63-88 states the same schema);
+* a processor is called as ``p(x, in_place=True, inverse=False, **kw)`` and is the identity unless a subclass says otherwise;
+* ``Processors([[name, module], ...], inverse=False)`` applies its members first to last, or last to first with
+  ``inverse=True``; the first tensor that leaves a forward (non-inverse) chain must be free of NaNs.
+
+State_dict keys (``processors.<name>.<buffer>``) are those of the reference, so its checkpoints load strictly.  On the HIP
+path ``AnemoiModelEncProcDec.predict_step`` does not call these modules at all when the chain is a lone ``InputNormalizer``:
+the affine map becomes a column program of the assembly kernels; ``Processors.check_first_batch`` keeps the NaN check there."""
 from __future__ import annotations
 
 import logging
-from typing import Optional
+from dataclasses import dataclass, field
+from typing import Mapping, Optional
 
 import torch
 from torch import Tensor, nn
 
 LOGGER = logging.getLogger(__name__)
 
+_RESERVED = ("default", "remap", "normalizer", "method_kwargs")
+
+
+@dataclass(frozen=True)
+class ProcessorSpec:
+    """A processor's configuration in normal form: ``variables[method]`` is the tuple of variable names a method was
+    listed for, ``method_of[variable]`` the inverse lookup."""
+
+    default: str = "none"
+    remap: Mapping = field(default_factory=dict)
+    normalizer: str = "none"
+    method_kwargs: Mapping = field(default_factory=dict)
+    variables: Mapping = field(default_factory=dict)
+
+    @property
+    def method_of(self) -> dict:
+        out: dict = {}
+        for method, names in self.variables.items():
+            out.update(dict.fromkeys(names, method))
+        return out
+
+    @staticmethod
+    def parse(config: Optional[Mapping], owner: str = "processor") -> "ProcessorSpec":
+        config = {} if config is None else config
+        listed = {}
+        for key in config.keys():
+            value = config[key]
+            if key in _RESERVED or value is None or (isinstance(value, str) and value == "none"):
+                continue
+            listed[str(key)] = (value,) if isinstance(value, str) else tuple(value)
+        if not listed:
+            LOGGER.warning("%s: no variable is listed under any method; '%s' applies to all of them.", owner, config.get("default", "none"))
+        reserved = {k: config.get(k) for k in _RESERVED if config.get(k) is not None}
+        return ProcessorSpec(variables=listed, **reserved)
+
 
 class BasePreprocessor(nn.Module):
-    """Base class for data pre- and post-processors (reference preprocessing/__init__.py:22-149)."""
+    """Base of the data pre- / post-processors.  Subclasses override ``transform`` / ``inverse_transform``; they read
+    ``self.methods`` (variable -> method), ``self.default`` and ``self.remap`` like the reference's subclasses do."""
+
+    supports_skip_imputation = False
 
     def __init__(self, config=None, data_indices=None, statistics: Optional[dict] = None) -> None:
         super().__init__()
-        self.default, self.remap, self.normalizer, self.method_config, self.method_kwargs = self._process_config(config)
-        self.methods = self._invert_key_value_list(self.method_config)
+        self.spec = ProcessorSpec.parse(config, type(self).__name__)
         self.data_indices = data_indices
 
-    @classmethod
-    def _process_config(cls, config):
-        special = ["default", "remap", "normalizer", "method_kwargs"]  # keys that do not hold a list of variables
-        default = config.get("default", "none")
-        remap = config.get("remap", {})
-        normalizer = config.get("normalizer", "none")
-        method_kwargs = config.get("method_kwargs", {})
-        method_config = {k: v for k, v in config.items() if k not in special and v is not None and v != "none"}
-        if not method_config:
-            LOGGER.warning("%s: Using default method %s for all variables not specified in the config.", cls.__name__, default)
-        for m in method_config:
-            if isinstance(method_config[m], str):
-                method_config[m] = {method_config[m]: f"{m}_{method_config[m]}"}
-            elif isinstance(method_config[m], list):
-                method_config[m] = {method: f"{m}_{method}" for method in method_config[m]}
-        return default, remap, normalizer, method_config, method_kwargs
+    # the reference's attribute names, derived from the one normal form
+    default = property(lambda self: self.spec.default)
+    remap = property(lambda self: self.spec.remap)
+    normalizer = property(lambda self: self.spec.normalizer)
+    method_kwargs = property(lambda self: self.spec.method_kwargs)
+    methods = property(lambda self: self.spec.method_of)
 
-    @staticmethod
-    def _invert_key_value_list(method_config: dict) -> dict:
-        return {variable: method for method, variables in method_config.items() if not isinstance(variables, str) for variable in variables}
+    @property
+    def method_config(self) -> dict:
+        return {m: {v: f"{m}_{v}" for v in names} for m, names in self.spec.variables.items()}
 
     def forward(self, x, in_place: bool = True, inverse: bool = False, **kwargs) -> Tensor:
-        if "skip_imputation" in kwargs and not getattr(self, "supports_skip_imputation", False):
-            kwargs = {k: v for k, v in kwargs.items() if k != "skip_imputation"}
-        if inverse:
-            return self.inverse_transform(x, in_place=in_place, **kwargs)
-        return self.transform(x, in_place=in_place, **kwargs)
+        if not self.supports_skip_imputation:
+            kwargs.pop("skip_imputation", None)
+        step = self.inverse_transform if inverse else self.transform
+        return step(x, in_place=in_place, **kwargs)
 
     def transform(self, x, in_place: bool = True, **kwargs) -> Tensor:
         return x if in_place else x.clone()
 
-    def inverse_transform(self, x, in_place: bool = True, **kwargs) -> Tensor:
-        return x if in_place else x.clone()
+    inverse_transform = transform
 
 
 class Processors(nn.Module):
-    """A collection of processors (reference preprocessing/__init__.py:152-206): ``processors`` is a list of
-    ``[name, module]`` pairs; with ``inverse`` they run in reverse order with ``inverse=True``."""
+    """An ordered chain of named processors; ``inverse=True`` runs the members last to first as inverse transforms."""
 
     def __init__(self, processors: list, inverse: bool = False) -> None:
         super().__init__()
-        self.inverse = inverse
-        self.first_run = True
-        if inverse:
-            processors = processors[::-1]
-        self.processors = nn.ModuleDict(processors)
+        self.inverse = bool(inverse)
+        self.processors = nn.ModuleDict()
+        for name, module in processors:
+            self.processors[name] = module
+        self._awaiting_first_batch = True
 
-    def __repr__(self) -> str:
-        return f"{self.__class__.__name__} [{'inverse' if self.inverse else 'forward'}]({self.processors})"
+    def chain(self) -> list:
+        """The members in the order they are applied."""
+        members = list(self.processors.values())
+        return members[::-1] if self.inverse else members
+
+    def extra_repr(self) -> str:
+        return "direction=" + ("inverse" if self.inverse else "forward")
 
     def forward(self, x, in_place: bool = True, **kwargs) -> Tensor:
-        for processor in self.processors.values():
-            x = processor(x, in_place=in_place, inverse=self.inverse, **kwargs)
-        if self.first_run:
-            self.first_run = False
-            self._run_checks(x)
+        for member in self.chain():
+            x = member(x, in_place=in_place, inverse=self.inverse, **kwargs)
+        self.check_first_batch(x)
         return x
 
-    def _run_checks(self, x):
-        if not self.inverse:
-            assert not torch.isnan(x).any(), f"NaNs ({torch.isnan(x).sum()}) found in processed tensor after {self.__class__.__name__}."
+    def check_first_batch(self, x: Tensor) -> None:
+        """One-off sanity check of the first processed batch (forward direction only): NaNs that survive the
+        pre-processors would poison the model silently.  Also called by the fused model edge, which bypasses ``forward``."""
+        if not self._awaiting_first_batch:
+            return
+        self._awaiting_first_batch = False
+        if self.inverse:
+            return
+        bad = int(torch.isnan(x).sum())
+        assert bad == 0, f"{type(self).__name__}: {bad} NaNs in the first pre-processed batch."
 
 
 from .normalizer import InputNormalizer  # noqa: E402,F401

@@ -1,5 +1,5 @@
 """InputNormalizer — mirror of the reference's ``anemoi.models.preprocessing.normalizer.InputNormalizer``
-(preprocessing/normalizer.py:24-252): same constructor (processor config, data indices, statistics), same persistent
+(preprocessing/normalizer.py:24-252): same constructor arguments (processor config, data indices, statistics), same persistent
 buffers (``_norm_mul``, ``_norm_add``, ``_input_idx``, ``_output_idx``, ``_model_output_idx``), same ``transform`` /
 ``inverse_transform`` semantics (which statistics a tensor of a given width takes).
 
@@ -20,84 +20,84 @@ from . import BasePreprocessor
 _METHODS = ("mean-std", "std", "min-max", "max", "none")
 
 
+def _affine_table(minimum: np.ndarray, maximum: np.ndarray, mean: np.ndarray, stdev: np.ndarray) -> dict:
+    """method -> (mul, add) over ALL variables at once (float64): x_normalised = x * mul + add.
+
+    mean-std: (x - mean) / stdev;  std: x / stdev;  min-max: (x - minimum) / (maximum - minimum);  max: x / maximum;
+    none: x (the documented normalisation methods of anemoi's ``normalizer`` processor)."""
+    one, zero = np.ones_like(mean), np.zeros_like(mean)
+    span = maximum - minimum
+    with np.errstate(divide="ignore", invalid="ignore"):  # degenerate fields are reported below, only where they are used
+        return {
+            "mean-std": (one / stdev, -mean / stdev),
+            "std": (one / stdev, zero),
+            "min-max": (one / span, -minimum / span),
+            "max": (one / maximum, zero),
+            "none": (one, zero),
+        }
+
+
 def _as_index(v) -> Tensor:
     return torch.as_tensor(v).to(torch.int32).reshape(-1).clone()
 
 
 class InputNormalizer(BasePreprocessor):
-    """Normalizes input data with a configurable method per variable."""
+    """Per-variable affine normalisation of the dataset's variables, method chosen per variable by the config."""
 
     def __init__(self, config=None, data_indices=None, statistics: Optional[dict] = None) -> None:
         super().__init__(config, data_indices, statistics)
-        name_to_index = self.data_indices.data.input.name_to_index
-        minimum, maximum = np.array(statistics["minimum"], dtype=np.float64), np.array(statistics["maximum"], dtype=np.float64)
-        mean, stdev = np.array(statistics["mean"], dtype=np.float64), np.array(statistics["stdev"], dtype=np.float64)
+        position = self.data_indices.data.input.name_to_index  # variable name -> column of the statistics vectors
+        names = np.array(list(position.keys()), dtype=object)
+        cols = np.fromiter(position.values(), dtype=np.int64, count=len(position))
 
-        # optionally reuse the statistics of one variable for another one (two steps: independent of the order)
-        remapped = {}
-        for remap, source in self.remap.items():
-            s, r = name_to_index[source], name_to_index[remap]
-            remapped[r] = (minimum[s], maximum[s], mean[s], stdev[s])
-        for idx, st in remapped.items():
-            minimum[idx], maximum[idx], mean[idx], stdev[idx] = st
-        self._validate_normalization_inputs(name_to_index, minimum, maximum, mean, stdev)
+        rows = [np.asarray(statistics[k], dtype=np.float64).reshape(-1) for k in ("minimum", "maximum", "mean", "stdev")]
+        assert len({r.size for r in rows}) == 1, f"InputNormalizer: statistics of different lengths {[r.size for r in rows]}"
+        stats = np.stack(rows)
+        # "remap": a variable borrows the statistics of another one; all sources are read before any column is
+        # overwritten (one fancy-indexed gather then one scatter), so chains such as {a: b, b: c} do not depend on order
+        if self.remap:
+            takers = np.array([position[t] for t in self.remap.keys()], dtype=np.int64)
+            givers = np.array([position[g] for g in self.remap.values()], dtype=np.int64)
+            stats[:, takers] = stats[:, givers].copy()
 
-        mul = np.ones((minimum.size,), dtype=np.float32)
-        add = np.zeros((minimum.size,), dtype=np.float32)
-        for name, i in name_to_index.items():
-            method = self.methods.get(name, self.default)
-            if method == "mean-std":
-                if stdev[i] < (mean[i] * 1e-6):
-                    warnings.warn(f"Normalizing: the field seems to have only one value {mean[i]}")
-                mul[i] = 1 / stdev[i]
-                add[i] = -mean[i] / stdev[i]
-            elif method == "std":
-                if stdev[i] < (mean[i] * 1e-6):
-                    warnings.warn(f"Normalizing: the field seems to have only one value {mean[i]}")
-                mul[i] = 1 / stdev[i]
-                add[i] = 0
-            elif method == "min-max":
-                x = maximum[i] - minimum[i]
-                if x < 1e-9:
-                    warnings.warn(f"Normalizing: the field {name} seems to have only one value {maximum[i]}.")
-                mul[i] = 1 / x
-                add[i] = -minimum[i] / x
-            elif method == "max":
-                mul[i] = 1 / maximum[i]
-            elif method == "none":
-                pass
-            else:
-                raise ValueError(f"Unknown normalisation method for {name}: {method}")
+        method_of = self.methods
+        unknown = sorted(set(method_of) - set(position))
+        assert not unknown, f"{unknown[0]} is not a valid variable name"
+        invalid = sorted(set(method_of.values()) - set(_METHODS))
+        assert not invalid, f"{invalid[0]} is not a valid normalisation method"
+        assert self.default in _METHODS, f"{self.default} is not a valid normalisation method"
+        listed = sum(len(v) for v in self.spec.variables.values())
+        assert len(method_of) == listed, f"InputNormalizer: {listed - len(method_of)} variable(s) are listed under more than one method"
+
+        table = _affine_table(*stats)
+        chosen = np.array([_METHODS.index(method_of.get(n, self.default)) for n in names], dtype=np.int64)
+        self._report_degenerate(names, cols, chosen, *stats)
+        mul = np.ones(stats.shape[1], dtype=np.float32)
+        add = np.zeros(stats.shape[1], dtype=np.float32)
+        mul[cols] = np.stack([table[m][0] for m in _METHODS])[chosen, cols]
+        add[cols] = np.stack([table[m][1] for m in _METHODS])[chosen, cols]
 
         self.register_buffer("_norm_mul", torch.from_numpy(mul), persistent=True)
         self.register_buffer("_norm_add", torch.from_numpy(add), persistent=True)
         self.register_buffer("_input_idx", _as_index(self.data_indices.data.input.full), persistent=True)
         self.register_buffer("_output_idx", _as_index(self.data_indices.data.output.full), persistent=True)
-
-        # variables the MODEL predicts, as positions of the data-output index (normalizer.py:126-146)
-        model_output_names = list(self.data_indices.model.output.name_to_index.keys())
-        data_output = self.data_indices.data.output.name_to_index
-        mask = torch.zeros(len(self._output_idx), dtype=torch.bool)
-        for var_name in list(data_output.keys()):
-            if var_name in model_output_names:
-                pos = (self._output_idx == data_output[var_name]).nonzero(as_tuple=True)[0].item()
-                mask[pos] = True
-        self.register_buffer("_model_output_idx", self._output_idx[mask], persistent=True)
+        # the variables the MODEL predicts, as the sub-sequence of the data-output index: a dataset may carry target-only
+        # variables that appear in data.output but not in model.output
+        predicted = self.data_indices.model.output.name_to_index
+        keep = [i for n, i in self.data_indices.data.output.name_to_index.items() if n in predicted]
+        sel = torch.isin(self._output_idx, torch.as_tensor(keep, dtype=torch.int32))
+        assert int(sel.sum()) == len(keep), "InputNormalizer: a predicted variable is missing from the data-output index"
+        self.register_buffer("_model_output_idx", self._output_idx[sel], persistent=True)
         self._gathered: dict = {}
 
-    def _validate_normalization_inputs(self, name_to_index: dict, minimum, maximum, mean, stdev) -> None:
-        assert len(self.methods) == sum(len(v) for v in self.method_config.values()), (
-            f"Error parsing methods in InputNormalizer methods ({len(self.methods)}) "
-            f"and entries in config ({sum(len(v) for v in self.method_config)}) do not match."
-        )
-        n = minimum.size
-        assert maximum.size == n, (maximum.size, n)
-        assert mean.size == n, (mean.size, n)
-        assert stdev.size == n, (stdev.size, n)
-        assert isinstance(self.methods, dict)
-        for name, method in self.methods.items():
-            assert name in name_to_index, f"{name} is not a valid variable name"
-            assert method in _METHODS, f"{method} is not a valid normalisation method"
+    @staticmethod
+    def _report_degenerate(names, cols, chosen, minimum, maximum, mean, stdev) -> None:
+        """Warn about constant fields, per method family, without a Python loop over the variables."""
+        m = np.array(_METHODS, dtype=object)[chosen]
+        flat = np.isin(m, ("mean-std", "std")) & (stdev[cols] < mean[cols] * 1e-6)
+        narrow = (m == "min-max") & ((maximum - minimum)[cols] < 1e-9)
+        for n in names[flat | narrow]:
+            warnings.warn(f"Normalizing: the field {n} seems to have only one value.")
 
     # ---------------------------------------------------------------------------------- which statistics for which tensor
     def _select(self, width: int, inverse: bool, data_index=None) -> tuple[Tensor, Tensor]:
