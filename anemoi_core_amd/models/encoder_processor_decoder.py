@@ -255,6 +255,10 @@ class AnemoiModelEncProcDec(nn.Module):
         names = list(x.keys())
         batch_size = x[names[0]].shape[0]
         ensemble_size = x[names[0]].shape[2]
+        if ensemble_size != 1:
+            # the reference's class fails on it as well (node attributes are repeated batch_size times against batch * ensemble *
+            # grid input rows: torch.cat mismatch at encoder_processor_decoder.py:121); its ensemble model folds members into the batch
+            raise ValueError(f"AnemoiModelEncProcDec: ensemble dimension {ensemble_size} != 1; fold the members into the batch dimension")
         in_out_sharded = {ds: grid_shard_sizes is not None and grid_shard_sizes.get(ds) is not None for ds in names}
         if model_comm_group is not None and comm_size(model_comm_group) > 1:
             assert batch_size == 1, "Only batch size of 1 is supported when model is sharded across GPUs"

@@ -182,10 +182,10 @@ int anemoi_gelu_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, int32_t n_
  *    no atomics, no zeroing, deterministic.  O and K multiples of 64.
  *  - anemoi_linear_lnfold_fwd: y = act(LN(x) W^T + b) from raw x [n_rows, K], w_scaled = W diag(gamma) [O, K], fp32 c, d [O]
  *    and stats_in = the producer's statistics of x (strips * 64 == K).  Partials are added in a fixed order.
- *  The pair is a two-kernel protocol: when n_rows exceeds a multiple of 160 by at most 32 (the "+ 2" of an icosphere's
- *  10 * 4^r + 2 nodes) the producer may compute those trailing rows outside its tiles and leaves their stats_out entries
- *  UNWRITTEN; the consumer never reads them - it takes the statistics of its own trailing rows (n_rows % 320 <= 32) from the
- *  rows themselves.
+ *  The pair is a two-kernel protocol with ONE tail rule on both sides: when n_rows exceeds a multiple of 320 by at most 32
+ *  (the "+ 2" of an icosphere's 10 * 4^r + 2 nodes) the producer may compute those trailing rows outside its tiles and
+ *  leaves their stats_out entries UNWRITTEN; the consumer never reads them - it takes the statistics of exactly those rows
+ *  (n_rows % 320 <= 32) from the rows themselves.  Every other row has its strip sums written (ragged last tiles included).
  * Replaces the two LayerNorm launches of a GraphTransformerProcessorBlock (layer_norm_attention / layer_norm_mlp_dst,
  * layers/block.py:1237, 1271) and layer_norm_attention_src / _dest of a GraphTransformerMapperBlock (layers/block.py:979-984)
  * in the unsharded inference path.  Returns ANEMOI_E_UNSUPPORTED for shapes / alignments the

@@ -284,21 +284,33 @@ def provider_edge_attr(p: Params, prefix: str, edge_attr_sorted: Tensor) -> Tens
 
 
 def enc_proc_dec_forward(p: Params, cfg: dict, graph, x: Tensor) -> Tensor:
-    """AnemoiModelEncProcDec.forward for one dataset "data", batch 1, ensemble 1
-    (models/encoder_processor_decoder.py:185-330); SkipConnection(step=-1) residual
-    (layers/residual.py:60-81), no boundings.  ``graph``: object with enc/proc/dec edge_index (dst-sorted
-    numpy/tensor [2,M]) and edge_attr [M,3].  x: [1, T, 1, N_data, V] -> [1, 1, 1, N_data, V_out]."""
+    """AnemoiModelEncProcDec.forward for one dataset "data", ensemble 1, any batch size and number of output steps
+    (models/encoder_processor_decoder.py:185-330); SkipConnection(step=-1) residual repeated over the output steps
+    (layers/residual.py:53-81), no boundings.  ``graph``: object with enc/proc/dec edge_index (dst-sorted
+    numpy/tensor [2,M]) and edge_attr [M,3].  x: [B, T, 1, N_data, V] -> [B, T_out, 1, N_data, V_out].
+
+    Batch > 1 as in the reference: ONE graph of B disjoint copies - node attributes and edge attributes repeated B times
+    (layers/graph.py:95-118, TrainableTensor: "e f -> (repeat e) f"), edge_index copy i shifted by i * (N_src, N_dst)
+    (layers/graph_provider.py:210-231)."""
     t = lambda a: a if isinstance(a, Tensor) else torch.from_numpy(a)  # noqa: E731
     B, T, E, N, V = x.shape
-    assert B == 1 and E == 1
+    assert E == 1, "ensemble members go through AnemoiEnsModelEncProcDec in the reference (out of scope)"
     kind, H, L = cfg["kind"], cfg["num_heads"], cfg["num_layers"]
-    x_skip = x[:, -1, ...]  # SkipConnection step=-1, n_step_output=1 -> [B,E,N,V] then unsqueeze time
-    x_data_latent = torch.cat([x[0, :, 0].permute(1, 0, 2).reshape(N, T * V), node_attributes(p, "data")], dim=-1)
-    x_hidden_latent = node_attributes(p, "hidden")
-    enc_ea = provider_edge_attr(p, "encoder_graph_provider.data", t(graph.enc_edge_attr))
-    proc_ea = provider_edge_attr(p, "processor_graph_provider", t(graph.proc_edge_attr))
-    dec_ea = provider_edge_attr(p, "decoder_graph_provider.data", t(graph.dec_edge_attr))
-    enc_ei, proc_ei, dec_ei = t(graph.enc_edge_index), t(graph.proc_edge_index), t(graph.dec_edge_index)
+    T_out = int(cfg.get("n_step_output", 1))
+    x_skip = x[:, -1, ...]  # SkipConnection step=-1 -> [B,E,N,V]
+    x_data_latent = torch.cat([x.permute(0, 2, 3, 1, 4).reshape(B * E * N, T * V), node_attributes(p, "data").repeat(B, 1)], dim=-1)
+    x_hidden_latent = node_attributes(p, "hidden").repeat(B, 1)
+    n_hidden = x_hidden_latent.shape[0] // B
+
+    def batched(edge_index, n_src, n_dst):
+        ei = t(edge_index).long()
+        inc = torch.tensor([[n_src], [n_dst]], dtype=torch.long)
+        return torch.cat([ei + b * inc for b in range(B)], dim=1)
+
+    enc_ea = provider_edge_attr(p, "encoder_graph_provider.data", t(graph.enc_edge_attr)).repeat(B, 1)
+    proc_ea = provider_edge_attr(p, "processor_graph_provider", t(graph.proc_edge_attr)).repeat(B, 1)
+    dec_ea = provider_edge_attr(p, "decoder_graph_provider.data", t(graph.dec_edge_attr)).repeat(B, 1)
+    enc_ei, proc_ei, dec_ei = batched(graph.enc_edge_index, N, n_hidden), batched(graph.proc_edge_index, n_hidden, n_hidden), batched(graph.dec_edge_index, n_hidden, N)
     if kind == "gt":
         x_latent = gt_forward_mapper(p, "encoder.data", x_data_latent, x_hidden_latent, enc_ea, enc_ei, H)
         x_data_for_dec = x_data_latent  # forward mapper returns x[0] untouched (mapper.py:597)
@@ -311,9 +323,9 @@ def enc_proc_dec_forward(p: Params, cfg: dict, graph, x: Tensor) -> Tensor:
         x_out = gt_backward_mapper(p, "decoder.data", x_proc, x_data_for_dec, dec_ea, dec_ei, H)
     else:
         x_out = gnn_backward_mapper(p, "decoder.data", x_proc, x_data_for_dec, dec_ea, dec_ei)
-    x_out = x_out.view(1, 1, N, 1, -1).permute(0, 3, 1, 2, 4).clone()  # "(b e g) (t v) -> b t e g v", time=1
+    x_out = x_out.view(B, E, N, T_out, -1).permute(0, 3, 1, 2, 4).clone()  # "(b e g) (t v) -> b t e g v"
     n_prog = x_out.shape[-1]
-    x_out[..., :n_prog] += x_skip.unsqueeze(1)[..., :n_prog]  # prognostic idx = first n_prog inputs in the fixtures
+    x_out[..., :n_prog] += x_skip.unsqueeze(1)[..., :n_prog]  # prognostic idx = first n_prog inputs in the fixtures; broadcast over T_out
     return x_out
 
 

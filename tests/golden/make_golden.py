@@ -338,6 +338,48 @@ def gen_model():
     save("model_tiny.pt", out)
 
 
+def gen_model_batch():
+    """Batch > 1 and n_step_output > 1 through the REFERENCE's AnemoiModelEncProcDec:
+    graph_provider.py:210-231 (edge_inc batch expansion), layers/residual.py:53-57 (skip repeated over the output steps),
+    encoder_processor_decoder.py:131-163 ((batch ensemble grid) (time vars) rearrangements).  Small models (32 channels, one
+    processor layer) so that the fixture stays small; one set of parameters per n_step_output (the decoder's width changes)."""
+    from anemoi.models.models import AnemoiModelEncProcDec
+
+    g = build_synthetic_graph("o8", 3)
+    out = {}
+    for kind in ("gt", "gnn"):
+        for t_out in (1, 2):
+            torch.manual_seed(41 + t_out)
+            gen = torch.Generator().manual_seed(77 + t_out)
+            n_vars, n_prog, n_step = 4, 3, 2  # one diagnostic-free forcing variable: input width 4, output width 3
+            cfg = dict(kind=kind, num_channels=32, num_layers=1, num_heads=4, trainable=4, n_vars=n_vars, n_prog=n_prog, n_step_input=n_step,
+                       n_step_output=t_out, data_grid="o8", hidden_resolution=3)
+            model = AnemoiModelEncProcDec(
+                model_config=model_config(kind, 32, 1, 4, 4),
+                data_indices=make_data_indices(n_vars, n_prog),
+                statistics={"data": None},
+                n_step_input=n_step,
+                n_step_output=t_out,
+                graph_data=make_hetero(g),
+            ).eval()
+            _randomise(model, gen, scale=0.3)
+            cases = []
+            for B, E in ((2, 1), (3, 1)) if t_out == 1 else ((1, 1), (2, 1)):
+                x = torch.randn(B, n_step, E, g.num_data, n_vars, generator=gen)
+                with torch.no_grad():
+                    y = model({"data": x})["data"]
+                assert y.shape == (B, t_out, E, g.num_data, n_prog), y.shape
+                cases.append(dict(x=x, out=y))
+                print(kind, "t_out", t_out, "B", B, "E", E, "out", tuple(y.shape), float(y.abs().mean()))
+            try:
+                model({"data": torch.randn(1, n_step, 2, g.num_data, n_vars, generator=gen)})
+                ens_err = None
+            except Exception as e:  # noqa: BLE001
+                ens_err = type(e).__name__
+            out[f"{kind}_t{t_out}"] = dict(cfg=cfg, params=_sd(model), cases=cases, ensemble_error=ens_err)
+    save("model_batch.pt", out)
+
+
 def gen_model_grads():
     """Gradients of the REFERENCE's tiny models (same parameters / input as model_tiny.pt): loss = sum(out * w) with the seeded w the
     gradient tests use; pins the backward (scope row f1) to the reference's own autograd instead of the oracle's."""
@@ -595,7 +637,7 @@ def gen_edges():
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ["conv", "blocks", "proc", "model", "grads", "sharding", "variants", "edges"]
+    which = sys.argv[1:] or ["conv", "blocks", "proc", "model", "batch", "grads", "sharding", "variants", "edges"]
     if "conv" in which:
         gen_conv()
     if "blocks" in which:
@@ -604,6 +646,8 @@ if __name__ == "__main__":
         gen_proc_mappers()
     if "model" in which:
         gen_model()
+    if "batch" in which:
+        gen_model_batch()
     if "grads" in which:
         gen_model_grads()
     if "sharding" in which:

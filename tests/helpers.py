@@ -15,8 +15,8 @@ def build_model_from_fixture(case):
     g = build_synthetic_graph(cfg["data_grid"], cfg["hidden_resolution"])
     model = AnemoiModelEncProcDec(
         model_config=model_config(cfg["kind"], cfg["num_channels"], cfg["num_layers"], cfg["num_heads"], cfg["trainable"]),
-        data_indices=make_data_indices(cfg["n_vars"], cfg["n_vars"]), statistics={"data": None},
-        n_step_input=cfg["n_step_input"], n_step_output=1, graph_data=g,
+        data_indices=make_data_indices(cfg["n_vars"], cfg.get("n_prog", cfg["n_vars"])), statistics={"data": None},
+        n_step_input=cfg["n_step_input"], n_step_output=cfg.get("n_step_output", 1), graph_data=g,
     ).eval()
     return model, g
 

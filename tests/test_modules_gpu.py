@@ -149,6 +149,30 @@ def test_full_model_tiny_fp32(golden, kind):
     assert torch.equal(y, y2)
 
 
+@pytest.mark.parametrize("key", ["gt_t1", "gt_t2", "gnn_t1", "gnn_t2"])
+def test_full_model_batch_and_output_steps_match_reference(golden, key):
+    """Batch 2 / 3 (graph_provider.py:210-231: one graph of B disjoint copies) and n_step_output 2 (layers/residual.py:53-57:
+    skip repeated over the output steps) on the HIP path against the REFERENCE's own outputs (fixture model_batch.pt); fp32
+    atol 2e-4 like the batch-1 model test, and bf16 against the same outputs at the 16-bit model tolerance."""
+    c = golden("model_batch.pt")[key]
+    model, _ = build_model_from_fixture(c)
+    model.load_state_dict(c["params"], strict=True)
+    model = model.to(DEV)
+    for case in c["cases"]:
+        with torch.no_grad():
+            y = model({"data": case["x"].to(DEV)})["data"]
+        assert y.shape == case["out"].shape
+        close(y, case["out"], 2e-4, what=f"model {key} B={case['x'].shape[0]}")
+    m16 = model.to(torch.bfloat16)
+    case = c["cases"][-1]
+    with torch.no_grad():
+        y = m16({"data": case["x"].to(DEV).to(torch.bfloat16)})["data"]
+    err = (y.float().cpu() - case["out"]).abs()
+    assert float(err.max()) < 6e-2 * max(1.0, float(case["out"].abs().max())) and float(err.mean()) < 1e-2
+    with pytest.raises((ValueError, RuntimeError)):  # the reference's class cannot take ensemble > 1 either (fixture: ensemble_error)
+        model({"data": torch.randn(1, 2, 2, case["x"].shape[3], case["x"].shape[4], device=DEV, dtype=torch.bfloat16)})
+
+
 @pytest.mark.parametrize("dtype,tol_max,tol_mean", [(torch.bfloat16, 6e-2, 1e-2), (torch.float16, 1e-2, 2e-3)])
 def test_full_model_tiny_16bit_vs_fp32_oracle(golden, dtype, tol_max, tol_mean):
     """16-bit policy (16-bit storage, fp32 accumulation) against the fp32 oracle: stated tolerance 6e-2 abs on O(1) outputs
