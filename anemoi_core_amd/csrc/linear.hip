@@ -1511,7 +1511,7 @@ static int launch_stats_producer(const LinArgs& a, hipStream_t st) {
       if (n64) return launch_splitwave<T, EPI, 5, 2, 2, 4, 64>(m, st);
       return launch_splitwave<T, EPI, 5, 2, 2, 2>(m, st);
     }
-  });
+  }
   (void)c3;
   (void)c4;
   return launch_persistent<T, EPI>(a, st);  // the kernel choice of the same shape without statistics (big tiles at 40 320 rows)
