@@ -18,7 +18,7 @@ LIBDIR = os.path.join(PKG, "lib")
 LIBPATH = os.path.join(LIBDIR, "libanemoi_hip.so")
 INCLUDE = os.path.join(REPO, "include")
 
-SOURCES = ["lib.cpp", "gt_attention.hip", "gt_attention_bwd.hip", "rowwise.hip", "rowwise_bwd.hip", "linear.hip", "wgrad.hip"]
+SOURCES = ["lib.cpp", "gt_attention.hip", "gt_attention_bwd.hip", "rowwise.hip", "rowwise_bwd.hip", "linear.hip", "wgrad.hip", "peer.hip"]
 ARCH = "gfx950"
 
 

@@ -36,6 +36,48 @@ def _all_reduce_sum(x: Tensor, group) -> None:
     collective(lambda: dist.all_reduce(x, op=dist.ReduceOp.SUM, group=group))
 
 
+def _push_rows_default(recv: Tensor, src: Tensor, send_index: Optional[Tensor], recv_counts, send_counts, group, gather_fn) -> None:
+    packed = src if send_index is None else (gather_fn(src, send_index) if gather_fn is not None else src.index_select(0, send_index.long()))
+    _all_to_all_single(recv, packed.contiguous(), list(recv_counts), list(send_counts), group)
+
+
+# Indexed variant of the all-to-all (inference): recv <- the peers' rows, this rank's packed send order being src[send_index].
+# Default: one pack kernel + the collective; the device-initiated wire (distributed/peer.py) does both in ONE kernel.
+_push_rows = _push_rows_default
+
+
+def recv_buffer(head_rows: int, send_counts, recv_counts, width: int, dtype, device, group) -> Tensor:
+    """[head_rows + sum(recv_counts), width]: the caller fills the head (its local rows), the exchange that follows receives
+    into the tail.  The device-initiated wire hands out memory its peers can store into; by default plain device memory."""
+    return torch.empty((head_rows + sum(recv_counts), width), dtype=dtype, device=device)
+
+
+def forward_scope(group):
+    """Marks one forward of a model-parallel module (outermost scope wins).  A no-op for host-issued collectives; the
+    device-initiated wire restarts its exchange sequence and lets all ranks meet on the device."""
+    import contextlib
+
+    return contextlib.nullcontext()
+
+
+def scoped_forward(fn):
+    """Decorator for the ``forward`` of a model-parallel module: runs it inside ``forward_scope(model_comm_group)``."""
+    import functools
+    import inspect
+
+    pos = list(inspect.signature(fn).parameters).index("model_comm_group")
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        group = kwargs.get("model_comm_group") if "model_comm_group" in kwargs else (args[pos] if len(args) > pos else None)
+        if group is None:
+            return fn(*args, **kwargs)
+        with forward_scope(group):
+            return fn(*args, **kwargs)
+
+    return wrapper
+
+
 def _needs_grad(*tensors) -> bool:
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
@@ -175,8 +217,7 @@ def halo_exchange_into(buf: Tensor, n_local: int, send_index: Tensor, send_count
                        gather_fn) -> Tensor:
     """Inference variant of ``halo_exchange`` without the concatenation: ``buf`` [n_local + n_halo, D] already holds the local
     rows in its head; the halo rows are received straight into its tail."""
-    packed = gather_fn(buf[:n_local], send_index)
-    _all_to_all_single(buf[n_local:], packed.contiguous(), list(recv_counts), list(send_counts), group)
+    _push_rows(buf[n_local:], buf[:n_local], send_index, list(recv_counts), list(send_counts), group, gather_fn)
     return buf
 
 
@@ -204,6 +245,11 @@ def exchange_rows(x_local: Tensor, want_global_ids: Tensor, shard_sizes: Sequenc
         asked = req_local.new_empty(sum(send_counts_l))
         dist.all_to_all_single(asked, req_local.contiguous(), output_split_sizes=send_counts_l, input_split_sizes=recv_counts_l, group=group)
         plan = dict(send_index=asked.to(torch.int32).contiguous(), send_counts=send_counts_l, recv_counts=recv_counts_l)
+    if not _needs_grad(x_local) and x_local.dim() == 2:
+        # inference: pack + exchange as one indexed push (one kernel on the device-initiated wire), received in place
+        rows = recv_buffer(0, plan["send_counts"], plan["recv_counts"], x_local.shape[1], x_local.dtype, x_local.device, group)
+        _push_rows(rows, x_local, plan["send_index"], plan["recv_counts"], plan["send_counts"], group, gather_fn)
+        return rows, plan
     packed = gather_fn(x_local, plan["send_index"]) if gather_fn is not None else x_local.index_select(0, plan["send_index"].long())
     rows = all_to_all_rows(packed, plan["send_counts"], plan["recv_counts"], group)
     return rows, plan

@@ -452,7 +452,7 @@ class GraphTransformerProcessorBlock(GraphTransformerBaseBlock):
             # inference on a shard: LayerNorm writes the head of the [local + halo] buffer, the all-to-all receives into its tail
             plan = self._halo_plan(x, edge_index, shard_info, batch_size, model_comm_group, halo_cache)
             nl = x.shape[0]
-            x_plus_halo = torch.empty((nl + sum(plan.recv_counts), x.shape[1]), dtype=x.dtype, device=x.device)
+            x_plus_halo = comm.recv_buffer(nl, plan.send_counts, plan.recv_counts, x.shape[1], x.dtype, x.device, model_comm_group)
             xn = ops.layer_norm(x, ln.weight, ln.bias, ln.eps, out=x_plus_halo[:nl])
             comm.halo_exchange_into(x_plus_halo, nl, plan.send_index, plan.send_counts, plan.recv_counts, model_comm_group, ops.gather_rows)
         else:

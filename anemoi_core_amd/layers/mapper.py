@@ -132,6 +132,7 @@ class GraphTransformerBaseMapper(BaseMapper):
         return padded(x, lin)
 
     # subclasses: pre_process(x_src_compact, x_dst) -> embedded pair, post_process(x_dst)
+    @comm.scoped_forward
     def forward(self, x, batch_size: int, shard_info: BipartiteGraphShardInfo, edge_attr: Tensor, edge_index: Tensor,
                 model_comm_group=None, keep_x_dst_sharded: bool = False, edges_are_dst_sorted: bool = True, cond=None, **kwargs):
         if self.shard_strategy == "heads" and model_is_distributed(model_comm_group):
@@ -321,6 +322,7 @@ class GNNBaseMapper(BaseMapper):
             xs_new = comm.gather_tensor(xs_new, 0, src_sizes, group, reduce_in_backward=True)  # consumers slice it by THEIR partition
         return xs_new, out_dst
 
+    @comm.scoped_forward
     def forward(self, x, batch_size: int, shard_info: BipartiteGraphShardInfo, edge_attr: Tensor, edge_index: Tensor,
                 model_comm_group=None, keep_x_dst_sharded: bool = False, edges_are_dst_sorted: bool = True, **kwargs):
         return self.mapper_forward(x, batch_size, shard_info, edge_attr, edge_index, model_comm_group, keep_x_dst_sharded,

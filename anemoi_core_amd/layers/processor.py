@@ -10,7 +10,7 @@ from typing import Optional
 from torch import Tensor, nn
 
 from ..distributed.partition import edge_shard_plan, ensure_edges_are_dst_sorted, sort_edge_index_by_dst, take_edge_rows
-from ..distributed.primitives import gather_tensor
+from ..distributed.primitives import gather_tensor, scoped_forward
 from ..distributed.shapes import GraphShardInfo
 from .block import GraphConvProcessorBlock, GraphTransformerProcessorBlock
 from .utils import compute_mlp_hidden_dim, load_layer_kernels
@@ -72,6 +72,7 @@ class GraphTransformerProcessor(BaseProcessor):
         self._halo_cache: dict = {}
         self._shard_cache = None
 
+    @scoped_forward
     def forward(self, x: Tensor, batch_size: int, shard_info: GraphShardInfo, edge_attr: Tensor, edge_index: Tensor,
                 model_comm_group=None, edges_are_dst_sorted: bool = True, *args, **kwargs) -> Tensor:
         size = sum(shard_info.nodes) if shard_info.nodes_are_sharded() else x.shape[0]
@@ -112,6 +113,7 @@ class GNNProcessor(BaseProcessor):
         self._shard_cache = None
         self._local_edge_cache: dict = {}
 
+    @scoped_forward
     def forward(self, x: Tensor, batch_size: int, shard_info: GraphShardInfo, edge_attr: Tensor, edge_index: Tensor,
                 model_comm_group=None, edges_are_dst_sorted: bool = True, *args, **kwargs) -> Tensor:
         if not shard_info.edges_are_sharded():  # local slice of the dst-sorted edges (no communication), cached: static graph

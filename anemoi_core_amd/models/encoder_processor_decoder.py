@@ -17,7 +17,7 @@ import torch
 from torch import Tensor, nn
 
 from .. import ops
-from ..distributed.primitives import shard_tensor
+from ..distributed.primitives import scoped_forward, shard_tensor
 from ..distributed.shapes import BipartiteGraphShardInfo, GraphShardInfo, comm_size, get_shard_sizes
 from ..layers.graph import NamedNodesAttributes
 from ..layers.graph_provider import create_graph_provider
@@ -248,6 +248,7 @@ class AnemoiModelEncProcDec(nn.Module):
                 ops.bound_columns_(x_out, *self._bound_tables[key])
         return x_out
 
+    @scoped_forward
     def forward(self, x: dict, *, model_comm_group=None, grid_shard_sizes: Optional[dict] = None, _fused_norm: Optional[dict] = None,
                 **kwargs) -> dict:
         """``_fused_norm`` (set by ``predict_step`` only): {dataset: (input normaliser, output normaliser)} - x is then the RAW

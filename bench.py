@@ -471,14 +471,22 @@ def main():
                          "report a number measured on another rank count")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (ROCm) device; there is no CPU fallback for the product path")
-    # Developer hook (never set by the driver): ANEMOI_BENCH_TRANSPORT=host runs the N > 1 code path with all ranks on ONE
-    # GPU over gloo + the debug host transport, to exercise sharding and segmented capture on a 1-GPU box.
-    host_transport = os.environ.get("ANEMOI_BENCH_TRANSPORT") == "host"
+    # Wire of the N > 1 run (ANEMOI_BENCH_TRANSPORT):
+    #   unset  = the product: RCCL process group (backend "nccl") for set-up and as the fallback, the device-initiated hipIpc
+    #            exchange (anemoi_core_amd/distributed/peer.py) as the data path - one hipGraph per rank; verified against
+    #            rank 0's own unsharded forward before anything is timed, else all ranks fall back to the RCCL chain;
+    #   rccl   = the RCCL chain only (host-issued all-to-alls between hipGraph segments);
+    #   ipc / host = developer hooks (never set by the driver): all ranks on ONE GPU over a gloo group, with the hipIpc exchange
+    #            resp. the host-staged debug transport - the N > 1 code path on a 1-GPU box, not a scaling number.
+    transport = os.environ.get("ANEMOI_BENCH_TRANSPORT", "")
+    if transport not in ("", "rccl", "ipc", "host"):
+        raise SystemExit(f"bench.py: unknown ANEMOI_BENCH_TRANSPORT={transport!r}")
+    host_transport = transport in ("host", "ipc")  # all ranks share device 0, control plane on gloo
     if host_transport:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    group = None
+    group, wire, wire_note = None, None, None
     if world > 1:
         import torch.distributed as dist
 
@@ -490,6 +498,15 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=device)
         group = dist.group.WORLD
+        if transport in ("", "ipc"):
+            from anemoi_core_amd.distributed import peer
+
+            try:
+                wire = peer.install(group)
+            except Exception as e:  # noqa: BLE001  (PeerWire set-up fails on all ranks together)
+                if transport == "ipc":
+                    raise
+                wire_note = f"hipIpc wire unavailable ({type(e).__name__}: {str(e)[:200]}); RCCL chain"
     dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
 
     g, model, x = build(args, device)
@@ -518,6 +535,35 @@ def main():
         for _ in range(max(2, args.warmup // 2)):  # builds the static caches, sizes the allocator
             out = step()
         sync_all()
+        if wire is not None:
+            # the device-initiated wire has to EARN its place: every rank's sharded output must match rank 0's unsharded forward
+            # (bf16: 2e-2 of the output scale, the bound of the sharded parity tests) and no wait may have timed out
+            ok, why = 1, ""
+            try:
+                wire.check()
+                ref = model(inp)["data"] if rank == 0 else torch.empty_like(out)
+                holder = [ref.float().cpu() if rank == 0 else None]
+                torch.distributed.broadcast_object_list(holder, src=0)
+                err = float((out.float().cpu() - holder[0]).abs().max())
+                scale = max(1.0, float(holder[0].abs().max()))
+                if not err <= (2e-5 if dtype == torch.float32 else 2e-2) * scale:
+                    ok, why = 0, f"sharded output differs from the unsharded forward by {err:.3e} (scale {scale:.2f})"
+                del ref, holder
+            except Exception as e:  # noqa: BLE001
+                ok, why = 0, f"{type(e).__name__}: {str(e)[:200]}"
+            flag = torch.tensor([ok], device="cpu" if host_transport else device, dtype=torch.int32)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                if transport == "ipc":
+                    raise SystemExit(f"bench.py: rank {rank}: hipIpc wire failed its check: {why or 'another rank failed'}")
+                from anemoi_core_amd.distributed import peer
+
+                peer.uninstall()
+                wire, wire_note = None, f"hipIpc wire failed its check on some rank ({why or 'see other ranks'}); RCCL chain"
+                for _ in range(2):
+                    out = step()
+                sync_all()
+            torch.cuda.empty_cache()
         # N = 1: the whole forward is ONE hipGraph.  N > 1: RCCL collectives cannot be captured on this stack (the capture
         # aborts through the ProcessGroupNCCL watchdog or hangs; tools/nccl_capture_probe.py), so the forward becomes a
         # chain of hipGraphs with the collectives re-issued eagerly in between (anemoi_core_amd/utils/segments.py).
@@ -596,14 +642,20 @@ def main():
                                    f"icosphere res {args.hidden_res} hidden mesh ({g.num_hidden} nodes, {g.proc_edge_index.shape[1]} edges), "
                                    f"{kind_name} processor {args.layers} layers x {args.channels} ch" + (f" x {args.heads} heads" if args.kind == "gt" else "") +
                                    f", enc {g.enc_edge_index.shape[1]} / dec {g.dec_edge_index.shape[1]} edges, batch 1",
-                       "parallelism": f"hidden mesh sharded over {world} GPU(s), halo all-to-all per layer" if world > 1 else "single GPU",
+                       "parallelism": f"hidden mesh sharded over {world} GPU(s), halo exchange per layer" if world > 1 else "single GPU",
                        "hip_graph": graph is not None, "graph_equals_eager": graph_checked,
                        "graph_segments": getattr(graph, "num_graphs", 1) if graph is not None else 0},
         }
         if world > 1:
             res["rccl"] = rccl_block(model, group, world, graph)
+            res["rccl"]["wire"] = ("hipIpc device-initiated exchange (peer stores + epoch flags inside the rank's hipGraph)" if wire is not None
+                                   else "RCCL all_to_all_single between hipGraph segments")
+            if wire is not None:
+                res["rccl"]["peer_channels"] = len(wire._channels)
+            if wire_note:
+                res["rccl"]["wire_note"] = wire_note
             if host_transport:
-                res["rccl"]["note"] = "ANEMOI_BENCH_TRANSPORT=host: all ranks on ONE GPU over the gloo debug transport - a code-path check, not a scaling number"
+                res["rccl"]["note"] = f"ANEMOI_BENCH_TRANSPORT={transport}: all ranks on ONE GPU (gloo control plane) - a code-path check, not a scaling number"
         if world == 1 and not args.no_kernel_timing:
             host_ms = max(12.0, 4.0 * ms)
             with torch.inference_mode():
@@ -654,6 +706,11 @@ def main():
             res["cpu_baseline"] = cpu_baseline(params_fp32, cfg, g, x)
         print(json.dumps(res), flush=True)
     if world > 1:
+        if wire is not None:
+            wire.check()
+            from anemoi_core_amd.distributed import peer
+
+            peer.uninstall()
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

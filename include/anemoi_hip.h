@@ -16,7 +16,9 @@
  *    the host wrapper converts once because the graph is static; N, M < 2^31);
  *  - ``stream`` is a hipStream_t passed as void*; kernels are enqueued, never synchronised;
  *  - return value 0 = success, otherwise a negative ANEMOI_E_* code; anemoi_hip_last_error()
- *    returns a thread-local message.  Nothing is allocated or freed by the library.
+ *    returns a thread-local message.  Nothing is allocated or freed by the library, except the
+ *    peer-exchange arenas of anemoi_peer_alloc / anemoi_peer_free (memory other PROCESSES map
+ *    through hipIpc cannot come from the caller's caching allocator).
  */
 #ifndef ANEMOI_HIP_H
 #define ANEMOI_HIP_H
@@ -27,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ANEMOI_HIP_ABI_VERSION 7
+#define ANEMOI_HIP_ABI_VERSION 8
 
 typedef enum { ANEMOI_F32 = 0, ANEMOI_BF16 = 1, ANEMOI_F16 = 2 } anemoi_dtype_t;
 typedef enum { ANEMOI_ACT_NONE = 0, ANEMOI_ACT_GELU = 1 } anemoi_act_t;
@@ -294,6 +296,41 @@ int anemoi_assemble_output_norm(const void* x_out, int64_t ldx, anemoi_dtype_t m
  * y = (x - add[c]) / mul[c]) over the last dimension of a [n_rows, V] view; y may alias x (in_place). */
 int anemoi_affine_columns(const void* x, int64_t ldx, void* y, int64_t ldy, const float* col_mul, const float* col_add,
                           int32_t inverse, int32_t n_rows, int32_t V, anemoi_dtype_t dtype, void* stream);
+
+/* ---- device-initiated row exchange between the ranks of a model-parallel group (scope row e) ----------------------------
+ * The reference exchanges node rows with host-issued NCCL collectives: the per-layer halo all-to-all
+ * (`_halo_exchange` = dist.all_to_all_single with per-peer splits, distributed/primitives.py:422-460, called from
+ * GraphTransformerProcessorBlock.forward, layers/block.py:1159-1172), the all-gather of shards (`_gather`,
+ * primitives.py:60-183) and the source-row sync of the mappers (distributed/khop_edges.py:386-392).  On one MI355X node
+ * the same data movement is ONE kernel of the rank's own stream per exchange: it stores the rows straight into the peers'
+ * receive buffers (peer memory mapped with hipIpc; xGMI is point to point, every link carries only its own rows), publishes
+ * them with a system-scope release + an epoch flag, and waits for the flags of the peers it receives from.  Being a plain
+ * kernel node it is captured with the rest of the forward: one hipGraph per rank, no host in the loop
+ * (anemoi_core_amd/distributed/peer.py holds the host side; RCCL stays available as the fallback wire).
+ *
+ * Memory.  anemoi_peer_alloc returns zeroed device memory of one of three kinds; anemoi_peer_export writes the
+ * ANEMOI_PEER_HANDLE_BYTES-byte hipIpc handle other processes pass to anemoi_peer_open (never the exporting process itself);
+ * anemoi_peer_close unmaps.  Handles travel over the caller's control plane (torch.distributed object collectives). */
+#define ANEMOI_PEER_MEM_DEFAULT 0     /* hipMalloc: receive buffers, read by later kernels of the receiving stream */
+#define ANEMOI_PEER_MEM_FINEGRAINED 1 /* hipExtMallocWithFlags(hipDeviceMallocFinegrained) */
+#define ANEMOI_PEER_MEM_UNCACHED 2    /* hipExtMallocWithFlags(hipDeviceMallocUncached): flag words polled while a peer writes */
+#define ANEMOI_PEER_HANDLE_BYTES 64
+int anemoi_peer_alloc(void** ptr, int64_t bytes, int32_t kind);
+int anemoi_peer_free(void* ptr);
+int anemoi_peer_export(void* ptr, void* handle_out /* host, 64 bytes */);
+int anemoi_peer_open(const void* handle /* host, 64 bytes */, void** ptr_out);
+int anemoi_peer_close(void* ptr);
+
+/* One exchange of one channel.  Packed row i of the send order is src[(send_index ? send_index[i] : i)] (row_bytes bytes, a
+ * multiple of 16, ld_src_bytes apart); `table` is int64 [6][n_peers] in device memory: remote_base (address of this rank's
+ * first row in peer p's receive buffer), remote_flag (address of the word peer p polls for this rank), send_begin,
+ * send_count (rows of the packed order for peer p), signal (1: publish the epoch to p), expect (1: wait for p's epoch).
+ * local_flags = this rank's words of the channel: [n_peers flags | seq | ticket] (uint32, ANEMOI_PEER_MEM_UNCACHED).  total_rows
+ * may be 0 (signal / expect only: the forward-level barrier).  A peer that does not show up within timeout_ticks (100 MHz
+ * wall clock) sets *status = 0x80000000 | peer instead of hanging the device. */
+int anemoi_peer_exchange_rows(const void* src, int64_t ld_src_bytes, const int32_t* send_index, const int64_t* table,
+                              int32_t n_peers, int32_t row_bytes, int32_t total_rows, uint32_t* local_flags, uint32_t* status,
+                              int64_t timeout_ticks, void* stream);
 
 #ifdef __cplusplus
 }

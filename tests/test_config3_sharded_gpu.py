@@ -27,7 +27,7 @@ from tests.test_distributed_gpu import _spawn
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 SURVEY_HALO = {(5, 2): (277, 277), (5, 4): (260, 501), (5, 8): (188, 517), (6, 8): (338, 1066)}
-WIRES = ["host"]
+WIRES = ["host", "ipc"]
 
 
 def _args(hidden_res, layers):

@@ -279,3 +279,107 @@ def test_rccl_collectives_between_graph_segments_one_rank():
         env.pop(k, None)
     r = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL-ONE-RANK-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+# ---------------------------------------------------------------------------------------------- device-initiated wire
+def _peer_inputs(q, it, n_rows, D, dev):
+    """Rank q's rows of iteration it and its (static) send plan - reproducible on every rank."""
+    gen = torch.Generator().manual_seed(1000 * q + it)
+    return torch.randn(n_rows, D, generator=gen).to(torch.bfloat16).to(dev)
+
+
+def _peer_plan(q, world, n_rows):
+    """send_counts[q][p] and the packed send index of rank q (a function of q only)."""
+    counts = [0 if p == q else (17 * q + 5 * p) % 41 + (0 if (q + p) % 4 == 0 else 3) for p in range(world)]
+    if world > 2:
+        counts[(q + 1) % world] = 0  # a peer that gets nothing from q (and one-way pairs: p sends to q, q not to p)
+    gen = torch.Generator().manual_seed(77 + q)
+    idx = torch.randint(0, n_rows, (sum(counts),), generator=gen).to(torch.int32)
+    return counts, idx
+
+
+def _peer_wire_worker(rank, world, group):
+    from anemoi_core_amd import ops
+    from anemoi_core_amd.distributed import peer, primitives as P
+
+    dev = torch.device("cuda", 0)
+    wire = peer.install(group, arena_mb=64, timeout_s=30)
+    D = 512
+    rows = [900 + 37 * q for q in range(world)]
+    plans = [_peer_plan(q, world, rows[q]) for q in range(world)]
+    send_counts, send_index = plans[rank][0], plans[rank][1].to(dev)
+    recv_counts = [plans[q][0][rank] for q in range(world)]
+    nl = rows[rank]
+    heavy = torch.randn(4096, 4096, device=dev)
+    bad = []
+
+    def expected(it):
+        parts = []
+        for q in range(world):
+            if recv_counts[q]:
+                b = sum(plans[q][0][:rank])
+                parts.append(_peer_inputs(q, it, rows[q], D, dev)[plans[q][1][b:b + recv_counts[q]].long().to(dev)])
+        return torch.cat(parts) if parts else torch.empty(0, D, dtype=torch.bfloat16, device=dev)
+
+    def one_forward(x, small):
+        with P.forward_scope(group):
+            buf = P.recv_buffer(nl, send_counts, recv_counts, D, x.dtype, dev, group)  # in place: peers fill the tail
+            buf[:nl].copy_(x)
+            P.halo_exchange_into(buf, nl, send_index, send_counts, recv_counts, group, ops.gather_rows)
+            staged = torch.empty(sum(recv_counts), D, dtype=x.dtype, device=dev)  # any tensor: through the region + one copy
+            P._push_rows(staged, x, send_index, recv_counts, send_counts, group, ops.gather_rows)
+            gathered = P.gather_tensor(small, 0, [small.shape[0]] * world, group)  # 84 columns: 168-byte rows
+        return buf, staged, gathered
+
+    with torch.inference_mode():
+        for it in range(40):
+            if it % world == rank:  # uneven load: one rank is late, another one every iteration
+                for _ in range(3):
+                    heavy @ heavy
+            x = _peer_inputs(rank, it, nl, D, dev)
+            small = x[:40, :84].contiguous()
+            buf, staged, gathered = one_forward(x, small)
+            want = expected(it)
+            want_g = torch.cat([_peer_inputs(q, it, rows[q], D, dev)[:40, :84] for q in range(world)])
+            if not (torch.equal(buf[nl:], want) and torch.equal(staged, want) and torch.equal(buf[:nl], x) and torch.equal(gathered, want_g)):
+                bad.append(it)
+        wire.check()
+        # the same forward as ONE hipGraph, replayed on changing inputs, peers free-running
+        x_static = _peer_inputs(rank, 100, nl, D, dev)
+        small_static = x_static[:40, :84].contiguous()
+        one_forward(x_static, small_static)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            one_forward(x_static, small_static)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g):
+            buf, staged, gathered = one_forward(x_static, small_static)
+        for it in range(101, 131):
+            if it % world == rank:
+                heavy @ heavy
+            x_static.copy_(_peer_inputs(rank, it, nl, D, dev))
+            small_static.copy_(x_static[:40, :84])
+            g.replay()
+            want = expected(it)
+            if not (torch.equal(buf[nl:], want) and torch.equal(staged, want)):
+                bad.append(it)
+        wire.check()
+    n_channels = len(wire._channels)
+    torch.cuda.synchronize()
+    dist.barrier(group=group)
+    peer.uninstall()
+    return dict(bad=bad, channels=n_channels)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_peer_wire_rows_flags_and_graph_replay_under_uneven_load(world):
+    """csrc/peer.hip + distributed/peer.py with `world` processes on the one GPU (hipIpc works where RCCL refuses): in-place and
+    staged variable-count row exchanges with one-way pairs and empty peers, an all-gather of 168-byte rows, 40 eager forwards
+    and 30 replays of ONE captured hipGraph with a different late rank every iteration - every word of every received row is
+    compared with what the sender's seeded generator says it sent."""
+    for o in _spawn(_peer_wire_worker, world):
+        assert o["bad"] == [] and o["channels"] == 1 + 3  # barrier + the three exchanges of the forward
