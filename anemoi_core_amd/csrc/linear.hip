@@ -49,6 +49,7 @@ struct LinArgs {
   // normalisation of its INPUT rows in the epilogue:  LN(x) W^T = rstd (x (W gamma)^T - mean c) + d
   float* stats_out = nullptr;       // [n_rows][O / 64][2] fp32: sum and sum of squares of every 64-column strip (EPI_STATS)
   const float* stats_in = nullptr;  // [n_rows][ln_strips][2] of the input rows (EPI_LNFOLD)
+  int ln_tail_begin = 0x7fffffff;   // rows >= this carry NO strip sums (the one tail rule: n_rows % 320 <= 32): statistics from the row
   const float* ln_c = nullptr;      // [O] row sums of the gamma-scaled weight
   const float* ln_d = nullptr;      // [O] W beta + bias
   int ln_strips = 0, ln_D = 0;
@@ -350,6 +351,47 @@ enum : int { EPI_RES = 1, EPI_GATHER = 2, EPI_GELU = 4, EPI_STATS = 8, EPI_LNFOL
 // (guide T21).  Interior tiles issue exactly kEpiStores = 8 stores per wave.
 constexpr int kEpiStores = 8;
 
+// LayerNorm fold, small-tile kernels: mean / rstd of one row straight from the producer's strip sums (the big-tile kernel
+// stages them in LDS once per tile; with 64-row tiles on a few thousand rows the 8 lanes that share a row re-read its 64
+// bytes from L1 instead).  Same summation order as the LDS variant: bit-identical statistics.
+template <typename T>
+__device__ __forceinline__ void ln_row_stats(const LinArgs& a, int m, float& mu, float& rs) {
+  m = min(m, a.n_rows + a.tail_rows - 1);
+  const float* st = a.stats_in + (int64_t)m * a.ln_strips * 2;
+  float s1 = 0.f, s2 = 0.f;
+  if (m >= a.ln_tail_begin) {  // a producer's peeled tail row: sums of the stored row itself (strip by strip, like the producer)
+    const T* xr = (const T*)a.x + (int64_t)m * a.ldx;
+    for (int k = 0; k < a.ln_D; k += 8) {
+      float xv[8];
+      load_vec<T, 8>(xr + k, xv);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        s1 += xv[i];
+        s2 = fmaf(xv[i], xv[i], s2);
+      }
+    }
+  } else if (a.ln_strips == 8) {
+    f32x4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = reinterpret_cast<const f32x4*>(st)[q];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      s1 += v[q][0];
+      s2 += v[q][1];
+      s1 += v[q][2];
+      s2 += v[q][3];
+    }
+  } else {
+    for (int q = 0; q < a.ln_strips; ++q) {
+      s1 += st[2 * q];
+      s2 += st[2 * q + 1];
+    }
+  }
+  const float inv = 1.0f / (float)a.ln_D;
+  mu = s1 * inv;
+  rs = rsqrtf(fmaxf(s2 * inv - mu * mu, 0.f) + a.ln_eps);
+}
+
 // Fast path of the epilogue below for INTERIOR tiles (every row and column of the tile exists) with bias / residual / gather /
 // GELU only - the hot case.  The generic epilogue carries, per 16-byte store, the predicates of ragged tiles, the 4-column tail
 // of O % 8 == 4, the fp32-atomic split-K branch and 64-bit address products: measured on MI355X its on-chip work (stores
@@ -442,7 +484,14 @@ __device__ __forceinline__ void mfma_epilogue_fast(const LinArgs& a, f32x4 (&acc
     for (int it = 0; it < 2; ++it) {
       float vv[8];
       if constexpr ((EPI & EPI_LNFOLD) != 0) {  // mean / rstd of the tile's rows sit in LDS (written at the start of the tile)
-        const f32x2 mr = *reinterpret_cast<const f32x2*>(ln_rows + 2 * (wr * (16 * MI) + (lane >> 3) + mi * 16 + it * 8));
+        f32x2 mr;
+        if (ln_rows != nullptr) {
+          mr = *reinterpret_cast<const f32x2*>(ln_rows + 2 * (wr * (16 * MI) + (lane >> 3) + mi * 16 + it * 8));
+        } else {
+          float mu_, rs_;
+          ln_row_stats<T>(a, m0 + wr * (16 * MI) + (lane >> 3) + mi * 16 + it * 8, mu_, rs_);
+          mr = f32x2{mu_, rs_};
+        }
 #pragma unroll
         for (int r = 0; r < 8; ++r) vv[r] = fmaf(mr[1], fmaf(-mr[0], lc[r], c[it][r >> 2][r & 3]), bv[r]);
       } else {
@@ -542,8 +591,12 @@ __device__ __forceinline__ void mfma_epilogue_band(const LinArgs& a, f32x4 (&acc
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
         const int rl = wr * (16 * MI) + (lane >> 3) + mi * 16 + it * 8;
-        ln_mu[it] = ln_rows[2 * rl];
-        ln_rs[it] = ln_rows[2 * rl + 1];
+        if (ln_rows != nullptr) {
+          ln_mu[it] = ln_rows[2 * rl];
+          ln_rs[it] = ln_rows[2 * rl + 1];
+        } else {
+          ln_row_stats<T>(a, m0 + rl, ln_mu[it], ln_rs[it]);
+        }
       }
     }
 #pragma unroll
@@ -1527,6 +1580,22 @@ static int launch_lnfold_consumer(const LinArgs& a, hipStream_t st) {
     m.tail_rows = rem;
   }
   const int64_t t320 = (int64_t)((m.n_rows + 319) / 320) * ((a.O + 255) / 256);
+  // few rows (one rank's share of a sharded mesh, small meshes): a round of big tiles leaves most of the chip idle (642 rows =
+  // 3 x 8 tiles on 256 CUs) - the 64 x 128 kernels take the fold through their epilogue, statistics read from L1
+  static const int small_rows = [] { return env_int(getenv("ANEMOI_LNFOLD_SMALL_ROWS"), 4096, 0, 1 << 30); }();
+  if (a.n_rows < small_rows) {
+    LinArgs a2 = a;
+    if (rem > 0 && rem <= kTail && a.n_rows > kBigM) a2.ln_tail_begin = a.n_rows - rem;
+    const LinArgs& a = a2;
+    const double c34 = [&] { const int nk = a.K1 / BK; const double c4 = tile_cost_us(256, 128, a.n_rows, a.O, nk), c3 = tile_cost_us(192, 128, a.n_rows, a.O, nk); return c3 < c4 ? c3 : c4; }();
+    if (tile_cost_us(64, 128, a.n_rows, a.O, a.K1 / BK) < 0.9 * c34) {
+      const int64_t t1 = (int64_t)((a.n_rows + SM - 1) / SM) * ((a.O + SN - 1) / SN);
+      const bool gelu = a.act == ANEMOI_ACT_GELU;
+      if (t1 <= 256 && a.K1 % SK == 0)
+        return gelu ? launch_splitwave<T, EPI_LNFOLD | EPI_GELU>(a, st) : launch_splitwave<T, EPI_LNFOLD>(a, st);
+      return gelu ? launch_persistent_wm<T, EPI_LNFOLD | EPI_GELU, 1, false, 2>(a, st) : launch_persistent_wm<T, EPI_LNFOLD, 1, false, 2>(a, st);
+    }
+  }
   // 160-row tiles also beyond one round (40 320-row mapper GEMMs): the fold's epilogue has no registers to spare at 160
   // accumulators per lane (MI = 10: +7 us on [40320 x 512] -> 1024), at 80 it is free; ANEMOI_LNFOLD_MI5=0 restores the rule
   static const int always5 = [] { const char* e = getenv("ANEMOI_LNFOLD_MI5"); return e ? atoi(e) : 1; }();
