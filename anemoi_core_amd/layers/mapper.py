@@ -35,17 +35,22 @@ from ..utils.tensors import version
 
 
 class _LocalGraphCache:
-    """Per-mapper cache of the rank-local bipartite graph (static)."""
+    """Per-mapper cache of the rank-local bipartite graph (static).  A few entries, not one: the needed-rows plans live with
+    their graph and are built COLLECTIVELY - a rank that alternates between the sharded forward and an unsharded one (a
+    reference forward on rank 0) must not drop its sharded entry and re-plan alone while its peers wait in the exchange."""
 
-    def __init__(self):
-        self.key = None
-        self.val = None
+    def __init__(self, keep: int = 4):
+        self.entries: dict = {}
+        self.keep = keep
 
     def get(self, key, build):
-        if self.key != key:
-            self.val = build()
-            self.key = key
-        return self.val
+        hit = self.entries.get(key)
+        if hit is None:
+            hit = build()
+            if len(self.entries) >= self.keep:
+                self.entries.pop(next(iter(self.entries)))
+            self.entries[key] = hit
+        return hit
 
 
 class BaseMapper(nn.Module):

@@ -545,14 +545,17 @@ def main():
             ok, why = 1, ""
             try:
                 wire.check()
-                ref = model(inp)["data"] if rank == 0 else torch.empty_like(out)
+                if rank == 0:  # on a COPY: the model's static caches (rank-local graphs, collectively built plans) stay sharded
+                    import copy
+
+                    ref = copy.deepcopy(model)(inp)["data"]
                 holder = [ref.float().cpu() if rank == 0 else None]
                 torch.distributed.broadcast_object_list(holder, src=0)
                 err = float((out.float().cpu() - holder[0]).abs().max())
                 scale = max(1.0, float(holder[0].abs().max()))
                 if not err <= (2e-5 if dtype == torch.float32 else 2e-2) * scale:
                     ok, why = 0, f"sharded output differs from the unsharded forward by {err:.3e} (scale {scale:.2f})"
-                del ref, holder
+                holder = None
             except Exception as e:  # noqa: BLE001
                 ok, why = 0, f"{type(e).__name__}: {str(e)[:200]}"
             flag = torch.tensor([ok], device="cpu" if host_transport else device, dtype=torch.int32)

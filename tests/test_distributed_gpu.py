@@ -383,3 +383,30 @@ def test_peer_wire_rows_flags_and_graph_replay_under_uneven_load(world):
     compared with what the sender's seeded generator says it sent."""
     for o in _spawn(_peer_wire_worker, world):
         assert o["bad"] == [] and o["channels"] == 1 + 3  # barrier + the three exchanges of the forward
+
+
+def _alternating_worker(rank, world, group):
+    model, c = _model()
+    x = {"data": c["x"].cuda()}
+    with torch.inference_mode():
+        y1 = model(x, model_comm_group=group)["data"].clone()
+        dec = next(iter(model.decoder.values()))
+        plans_before = {k: id(v["plans"]) for k, v in dec._local.entries.items()}
+        n_plans = sum(len(v["plans"]) for v in dec._local.entries.values())
+        if rank == 0:
+            y0 = model(x)["data"].clone()  # an unsharded forward on ONE rank only (what bench.py's wire check does on a copy)
+        y2 = model(x, model_comm_group=group)["data"].clone()  # must not re-plan (collectively) on rank 0 alone
+        plans_after = {k: id(v["plans"]) for k, v in dec._local.entries.items()}
+    ok = all(plans_after.get(k) == v for k, v in plans_before.items()) and n_plans >= 1
+    return dict(ok=ok, same=bool(torch.equal(y1, y2)), unsharded=(y0.cpu() if rank == 0 else None), out=y2.cpu())
+
+
+def test_unsharded_forward_between_sharded_ones_keeps_the_collectively_built_plans():
+    """The rank-local graphs and their needed-rows plans (built with collectives) survive an unsharded forward on one rank: a
+    single-entry cache made that rank re-plan alone - its peers were already waiting in the next exchange (found with the
+    device-initiated wire, where that is a time-out instead of a gloo hang)."""
+    c = load_golden("model_tiny.pt")["gt"]
+    outs = _spawn(_alternating_worker, 2)
+    for o in outs:
+        assert o["ok"] and o["same"] and float((o["out"] - c["out"]).abs().max()) < 2e-4
+    assert float((outs[0]["unsharded"] - c["out"]).abs().max()) < 2e-4

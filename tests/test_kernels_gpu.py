@@ -337,7 +337,7 @@ def test_cpu_tensor_fails_loudly(ops):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 # 320-row tiles + 2 tail rows / whole tiles / partial last tile / tail of 10 / 320 k + 162 and 320 k + 192: <= 32 rows beyond a multiple
 # of 160 but NOT of 320 (the producer used to peel them without strip sums while the consumer expected sums)
-@pytest.mark.parametrize("N", [10242, 640, 4000, 330, 5282, 5312])
+@pytest.mark.parametrize("N", [10242, 640, 4000, 330, 5282, 5312, 642, 1469, 2562])  # the last three: small-tile consumers (< 4096 rows)
 def test_layernorm_folded_into_neighbouring_gemms(ops, dtype, N):
     """anemoi_linear_stats_fwd + anemoi_linear_lnfold_fwd: y = h W2^T + b2 + res with row statistics, then
     act(LN(y) W1^T + b1) from the raw y — against fp32 torch, and the producer's y equal to the plain GEMM's to rounding."""

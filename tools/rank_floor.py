@@ -9,6 +9,9 @@ zero-latency, zero-bandwidth-cost exchange - an upper bound of what P GPUs can d
   * "one hipGraph"       the whole per-rank forward as ONE graph (what device-initiated peer writes would allow),
   * "segmented chain"    the product's SegmentedGraph replay (one graph per stretch between two collectives) with no-op
                          collectives: the host-side price of re-issuing collectives between graphs is in, the wire is not.
+  * --wire ipc           additionally: the product's device-initiated wire (distributed/peer.py) with rank 0's exchange kernels
+                         doing everything but WAIT - rows are stored into the (idle) peers' buffers, released and flagged; the
+                         peers' flags are not awaited.  One graph; what the exchange kernels themselves add to the floor.
 
     python tools/rank_floor.py --world 8 --hidden-res 5        (prints one JSON line)
 """
@@ -38,6 +41,11 @@ def worker(rank, world, init_file, args, out_file):
     host_transport.install()
     group = dist.group.WORLD
     dev = torch.device("cuda", 0)
+    wire = None
+    if args.wire == "ipc":
+        from anemoi_core_amd.distributed import peer
+
+        wire = peer.install(group)
     ns = argparse.Namespace(data_grid=args.data_grid, hidden_res=args.hidden_res, kind="gt", channels=512, layers=args.layers, heads=16, vars=84)
     g, model, x = bench.build(ns, dev)
     model = model.to(dev).to(torch.bfloat16)
@@ -49,6 +57,33 @@ def worker(rank, world, init_file, args, out_file):
         torch.cuda.synchronize()
         dist.barrier()
         res = None
+        t_ipc = None
+        if wire is not None:
+            wire.check()
+            if rank == 0:
+                for ch in wire._channels:
+                    ch.table[5].zero_()  # expect nobody: the peers stay idle from here on
+                torch.cuda.synchronize()
+                for _ in range(3):
+                    step()
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    step()
+                torch.cuda.current_stream().wait_stream(s)
+                gi = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gi):
+                    step()
+                for _ in range(3):
+                    gi.replay()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    gi.replay()
+                torch.cuda.synchronize()
+                t_ipc = (time.perf_counter() - t0) / args.steps * 1e3
+                del gi
+            P._all_to_all_single, P._all_gather_into_tensor, P._push_rows, P.recv_buffer, P.forward_scope = wire._saved
         if rank == 0:
             # the wire becomes a no-op; "collective" still marks the segment boundaries of the product's replay scheme
             noop = lambda *a, **k: collective(lambda: None)  # noqa: E731
@@ -86,6 +121,7 @@ def worker(rank, world, init_file, args, out_file):
             res = {"world": world, "hidden_res": args.hidden_res, "data_grid": args.data_grid, "layers": args.layers,
                    "local_rows": int(plan.info.num_local_nodes), "halo_rows": int(sum(plan.recv_counts)),
                    "ms_rank_one_graph": round(t_one, 4), "ms_rank_segmented_noop_wire": round(t_seg, 4), "graphs": sg.num_graphs,
+                   "ms_rank_one_graph_ipc_push_no_wait": None if t_ipc is None else round(t_ipc, 4),
                    "collectives": sg.num_collectives, "components": {k: v for k, v in comp.items() if k.endswith("_ms")},
                    "families": {k: {"calls": v["calls"], "us": round(v["us"], 1)} for k, v in fam.items()}}
             json.dump(res, open(out_file, "w"))
@@ -100,6 +136,7 @@ if __name__ == "__main__":
     ap.add_argument("--data-grid", default="o96")
     ap.add_argument("--layers", type=int, default=16)
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--wire", default="", choices=["", "ipc"])
     a = ap.parse_args()
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "res.json")
