@@ -143,8 +143,8 @@ template <typename T, int VEC, int LPH, int FE_PAD, bool KVADJ>
 __global__ __launch_bounds__(64 * kWavesPerBlock, 16 / kWavesPerBlock) void gt_attn_fused_edge_fwd_kernel(
     const T* __restrict__ q, int64_t ldq, const T* __restrict__ k, int64_t ldk, const T* __restrict__ v, int64_t ldv,
     const float* __restrict__ feat, const float* __restrict__ w_packed, const int32_t* __restrict__ row,
-    const int32_t* __restrict__ colptr, const T* __restrict__ addend, int64_t ldadd, T* __restrict__ out, int64_t ldo,
-    float* __restrict__ lse, int n_dst, int H, float scale) {
+    const int32_t* __restrict__ colptr, const int32_t* __restrict__ order, const T* __restrict__ addend, int64_t ldadd,
+    T* __restrict__ out, int64_t ldo, float* __restrict__ lse, int n_dst, int H, float scale, int out_wt) {
   using L = WLayout<VEC, FE_PAD>;
   extern __shared__ __attribute__((aligned(16))) float w_lds[];  // [64][kChunk]
   const int lane = threadIdx.x & 63;
@@ -195,7 +195,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 16 / kWavesPerBlock) void gt_a
   const float thr = kDeferThr / scale;
   constexpr int PF = 3;     // edges in flight per wave (modulo-unrolled: no register rotation, counted waits)
 
-  for (int d = d_lo + wave_in_xcd; d < d_hi; d += waves_in_xcd) {
+  // `order` (optional): the destination processed at position i.  The ~768 destinations an XCD works on at one moment are
+  // then a compact patch of the mesh instead of a whole latitude ring, so the K|V rows they gather fit that XCD's L2
+  // (layers/graphcache.py builds it from the graph; outputs are written at their own rows, the result does not depend on it).
+  for (int i = d_lo + wave_in_xcd; i < d_hi; i += waves_in_xcd) {
+    const int d = order ? __builtin_amdgcn_readfirstlane(order[i]) : i;
     // W' lives in LDS and is re-read per destination: without this barrier the compiler hoists all VEC*FE_PAD values
     // into registers across the loop (256 VGPRs, 1 wave/SIMD) and the kernel becomes latency-bound.
     asm volatile("" ::: "memory");
@@ -337,7 +341,22 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 16 / kWavesPerBlock) void gt_a
 #pragma unroll
       for (int j = 0; j < VEC; ++j) o[j] += ad[j];
     }
-    store_vec<T, VEC>(out + (int64_t)d * ldo + c0, o);
+    if constexpr (sizeof(T) * VEC == 16) {
+      if (out_wt) {
+        // write-through store (sc1): the output row is read by ANOTHER kernel, so keeping its line in this XCD's L2 only
+        // evicts K|V rows that later destinations of the window still gather (ANEMOI_ATTN_OUT_WT, measured A/B in DESIGN.md)
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+        Vec<T, VEC> tmp;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) tmp.v[j] = from_float<T>(o[j]);
+        T* dstp = out + (int64_t)d * ldo + c0;
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dstp), "v"(__builtin_bit_cast(u32x4, tmp)) : "memory");
+      } else {
+        store_vec<T, VEC>(out + (int64_t)d * ldo + c0, o);
+      }
+    } else {
+      store_vec<T, VEC>(out + (int64_t)d * ldo + c0, o);
+    }
     if (lse != nullptr && (lane % LPH) == 0) lse[(int64_t)d * H + lane / LPH] = (end > beg) ? m * scale + __logf(l) : 0.f;
   }
 }
@@ -428,6 +447,7 @@ struct AttnArgs {
   int fe, fe_pad;
   const float* w_packed;
   const int32_t *row, *colptr;
+  const int32_t* order = nullptr;
   const void* addend;
   int64_t ldadd;
   void* out;
@@ -464,6 +484,7 @@ static int launch_fast(const AttnArgs& a) {
     // persistent grid: at most ~6 workgroups per CU (LDS 25 KiB each, 5-6 waves/SIMD by registers); every wave walks
     // destinations d, d + total_waves, ... so the W' staging is paid once per workgroup
     static const int per_cu = [] { const char* e = getenv("ANEMOI_ATTN_BLOCKS_PER_CU"); return env_int(e, 6, 1, 32); }();
+    static const int out_wt = [] { return env_int(getenv("ANEMOI_ATTN_OUT_WT"), 0, 0, 1); }();
     const int max_blocks = 256 * per_cu;
     int blocks = (a.n_dst + kWavesPerBlock - 1) / kWavesPerBlock;
     blocks = blocks < max_blocks ? blocks : max_blocks;
@@ -475,7 +496,7 @@ static int launch_fast(const AttnArgs& a) {
     auto kern = kv_adjacent ? gt_attn_fused_edge_fwd_kernel<T, VEC, LPH, FE_PAD, true> : gt_attn_fused_edge_fwd_kernel<T, VEC, LPH, FE_PAD, false>;
     hipLaunchKernelGGL(kern, grid, block, L::kFloats * sizeof(float),
                        a.stream, (const T*)a.q, a.ldq, (const T*)a.k, a.ldk, (const T*)a.v, a.ldv, a.feat, a.w_packed,
-                       a.row, a.colptr, (const T*)a.addend, a.ldadd, (T*)a.out, a.ldo, a.lse, a.n_dst, a.H, scale);
+                       a.row, a.colptr, a.order, (const T*)a.addend, a.ldadd, (T*)a.out, a.ldo, a.lse, a.n_dst, a.H, scale, out_wt);
     return check_launch("gt_attn_fused_edge_fwd_kernel");
   };
   switch (a.fe_pad) {
@@ -560,14 +581,14 @@ extern "C" int anemoi_gt_attention_fwd(const void* q, int64_t ldq, const void* k
   const int D = H * C;
   ANEMOI_REQUIRE(ldq >= D && ldk >= D && ldv >= D && ldo >= D && (!e || lde >= D) && (!addend || ldadd >= D),
                  "gt_attention_fwd: leading dimension smaller than H*C=%d", D);
-  AttnArgs a{q, k, v, e, ldq, ldk, ldv, lde, nullptr, 0, 0, nullptr, row, colptr, addend, ldadd, out, ldo, lse, n_dst, n_src, H, C, as_stream(stream)};
+  AttnArgs a{q, k, v, e, ldq, ldk, ldv, lde, nullptr, 0, 0, nullptr, row, colptr, nullptr, addend, ldadd, out, ldo, lse, n_dst, n_src, H, C, as_stream(stream)};
   return dispatch(a, dtype);
 }
 
 extern "C" int anemoi_gt_attention_fused_edge_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v,
                                                   int64_t ldv, const float* edge_feat, int32_t fe_pad,
                                                   const float* w_packed, const int32_t* row, const int32_t* colptr,
-                                                  const void* addend, int64_t ldadd, void* out, int64_t ldo, float* lse,
+                                                  const int32_t* dst_order, const void* addend, int64_t ldadd, void* out, int64_t ldo, float* lse,
                                                   int32_t n_dst, int32_t n_src, int32_t H, int32_t C,
                                                   anemoi_dtype_t dtype, void* stream) {
   ANEMOI_REQUIRE(n_dst >= 0 && n_src >= 0 && H > 0 && C > 0, "gt_attention_fused_edge_fwd: bad sizes");
@@ -576,7 +597,7 @@ extern "C" int anemoi_gt_attention_fused_edge_fwd(const void* q, int64_t ldq, co
   ANEMOI_REQUIRE(fe_pad >= 4 && fe_pad % 4 == 0, "gt_attention_fused_edge_fwd: fe_pad must be a positive multiple of 4, got %d", fe_pad);
   const int D = H * C;
   ANEMOI_REQUIRE(ldq >= D && ldk >= D && ldv >= D && ldo >= D && (!addend || ldadd >= D), "gt_attention_fused_edge_fwd: leading dimension smaller than H*C=%d", D);
-  AttnArgs a{q, k, v, nullptr, ldq, ldk, ldv, 0, edge_feat, fe_pad - 1, fe_pad, w_packed, row, colptr, addend, ldadd, out, ldo, lse, n_dst, n_src, H, C, as_stream(stream)};
+  AttnArgs a{q, k, v, nullptr, ldq, ldk, ldv, 0, edge_feat, fe_pad - 1, fe_pad, w_packed, row, colptr, dst_order, addend, ldadd, out, ldo, lse, n_dst, n_src, H, C, as_stream(stream)};
   return dispatch(a, dtype);
 }
 

@@ -3,6 +3,7 @@
 "legitimate wins"); here each structure is derived once per (edge_index tensor, size) and reused by all layers."""
 from __future__ import annotations
 
+import os
 from collections import OrderedDict
 from typing import Optional
 
@@ -41,10 +42,19 @@ def _key(t: Tensor, *extra):
     return (t.data_ptr(), version(t), tuple(t.shape), str(t.device), t.dtype, *extra)
 
 
+_ATTN_ORDER = os.environ.get("ANEMOI_ATTN_ORDER", "1") != "0"
+
+
 def get_csc(edge_index: Tensor, size: tuple, edges_are_dst_sorted: bool = True) -> ops.CSC:
     size = (int(size[0]), int(size[1]))
-    return _csc_cache.get(_key(edge_index, size, bool(edges_are_dst_sorted)), edge_index,
-                          lambda: ops.build_csc(edge_index, size, edges_are_dst_sorted))
+
+    def build():
+        csc = ops.build_csc(edge_index, size, edges_are_dst_sorted)
+        if _ATTN_ORDER and edge_index.is_cuda:
+            csc.order = ops.processing_order(csc)  # locality-preserving work order of the fused attention (large square graphs)
+        return csc
+
+    return _csc_cache.get(_key(edge_index, size, bool(edges_are_dst_sorted)), edge_index, build)
 
 
 def get_edge_features(edge_attr: Tensor, perm: Optional[Tensor] = None) -> Tensor:

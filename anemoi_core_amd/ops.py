@@ -97,6 +97,7 @@ class CSC:
     n_src: int
     n_dst: int
     perm: Optional[Tensor] = None  # original -> CSC edge order when the input was not dst-sorted
+    order: Optional[Tensor] = None  # [n_dst] int32: the order the fused attention WORKS on the destinations (processing_order)
 
     @property
     def num_edges(self) -> int:
@@ -123,6 +124,62 @@ def build_csc(edge_index: Tensor, size: tuple[int, int], edges_are_dst_sorted: b
         colptr[1:] = torch.cumsum(torch.bincount(dst, minlength=n_dst), 0)
     return CSC(row=src.to(torch.int32).contiguous(), dst=dst.to(torch.int32).contiguous(),
                colptr=colptr.to(torch.int32).contiguous(), n_src=n_src, n_dst=n_dst, perm=perm)
+
+
+def processing_order(csc: CSC, slices: int = 8) -> Optional[Tensor]:
+    """A permutation of the destinations of a SQUARE graph that keeps mesh neighbours together inside each of the `slices`
+    contiguous index ranges the fused attention hands to the XCDs (csrc/gt_attention.hip): breadth-first order over the
+    SHORT edges of the range's own sub-graph.  Why: the hidden mesh is sorted by latitude, so ~768 consecutive destinations are
+    a whole latitude ring whose K|V neighbourhood (three rings, 2 KiB per row) overflows an XCD's 4 MiB L2 from res 6 on
+    (measured 1.65x the compulsory traffic); consecutive BFS levels of a strip form compact patches instead.  "Short": an edge
+    with an endpoint of minimal in-degree - in a multi-scale icosphere every finest-level edge touches a vertex that exists at
+    the finest level only (in-degree 6), while the long coarse-level edges join high-degree vertices; in a graph of uniform
+    degree every edge qualifies.  Host-side index work, once per static graph; None when there is nothing to gain (bipartite
+    graphs, graphs whose K|V rows fit the L2s anyway)."""
+    import numpy as np
+
+    n = csc.n_dst
+    if csc.n_src != n or n < 16384 or csc.num_edges == 0:
+        return None
+    src = csc.row.cpu().numpy().astype(np.int64)
+    dst = csc.dst.cpu().numpy().astype(np.int64)
+    deg = np.bincount(dst, minlength=n)
+    dmin = deg[deg > 0].min()
+    keep = np.minimum(deg[src], deg[dst]) == dmin
+    src, dst = src[keep], dst[keep]
+    per = (n + slices - 1) // slices
+    same = (src // per) == (dst // per)  # edges inside one XCD's range
+    src, dst = src[same], dst[same]
+    o = np.argsort(dst, kind="stable")
+    src, dst = src[o], dst[o]
+    ptr = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(ptr, dst + 1, 1)
+    ptr = np.cumsum(ptr)
+    seen = np.zeros(n, dtype=bool)
+    out = []
+    for x in range(slices):
+        lo, hi = x * per, min(n, (x + 1) * per)
+        nxt = lo
+        while nxt < hi:
+            if seen[nxt]:
+                nxt += 1
+                continue
+            frontier = np.array([nxt], dtype=np.int64)
+            seen[nxt] = True
+            while frontier.size:
+                out.append(frontier)
+                starts, ends = ptr[frontier], ptr[frontier + 1]
+                cnt = ends - starts
+                if cnt.sum() == 0:
+                    break
+                idx = np.repeat(starts - np.concatenate([[0], np.cumsum(cnt)[:-1]]), cnt) + np.arange(cnt.sum())
+                cand = np.unique(src[idx])
+                cand = cand[~seen[cand]]
+                seen[cand] = True
+                frontier = cand
+    order = np.concatenate(out) if out else np.arange(n)
+    assert order.size == n and np.array_equal(np.sort(order), np.arange(n)), "processing_order: not a permutation"
+    return torch.from_numpy(order.astype(np.int32)).to(csc.row.device)
 
 
 # ------------------------------------------------------------------------------------------ kernels
@@ -301,7 +358,8 @@ def gt_attention_fused_edge(q: Tensor, k: Tensor, v: Tensor, edge_feat: Tensor, 
     ap, lda = _rows(addend, "addend", q.dtype)
     rc = _lib.load().anemoi_gt_attention_fused_edge_fwd(
         qp, ldq, kp, ldk, vp, ldv, edge_feat.data_ptr(), fe_pad, w_packed.data_ptr(),
-        csc.row.data_ptr(), csc.colptr.data_ptr(), ap, lda, out.data_ptr(), D, lse.data_ptr() if return_lse else 0,
+        csc.row.data_ptr(), csc.colptr.data_ptr(), csc.order.data_ptr() if csc.order is not None else 0, ap, lda, out.data_ptr(), D,
+        lse.data_ptr() if return_lse else 0,
         csc.n_dst, csc.n_src, num_heads, D // num_heads, _dt(q), _stream())
     _lib.check(rc, "gt_attention_fused_edge_fwd")
     return (out, lse) if return_lse else out

@@ -77,10 +77,13 @@ int anemoi_gt_attention_bwd(const void* q, int64_t ldq, const void* k, int64_t l
  * Replaces: lin_edge(...) + the op above (layers/block.py:623-635 + triton/gt.py:81-179).
  * edge_feat: fp32 [M, fe_pad] with fe_pad = 4*ceil((Fe+1)/4): columns [0,Fe) = edge_attr, column Fe = 1.0
  * (carries the bias), the rest 0 (anemoi_pack_edge_features);  w_packed: fp32 [H*C, fe_pad] = [w_edge | b_edge | 0]
- * (anemoi_pack_edge_weights).  Both are built once per static graph / parameter version. */
+ * (anemoi_pack_edge_weights).  Both are built once per static graph / parameter version.
+ * dst_order (NULL = 0, 1, 2, ...): a permutation of the destinations giving the order in which the kernel WORKS on them (the
+ * reference's kernel takes program id = destination, triton/gt.py:100); every XCD processes a contiguous eighth of it, so an
+ * order that keeps mesh neighbours together keeps the gathered K|V rows in that XCD's L2.  The result does not depend on it. */
 int anemoi_gt_attention_fused_edge_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                                        const float* edge_feat, int32_t fe_pad, const float* w_packed,
-                                       const int32_t* row, const int32_t* colptr, const void* addend, int64_t ldadd,
+                                       const int32_t* row, const int32_t* colptr, const int32_t* dst_order, const void* addend, int64_t ldadd,
                                        void* out, int64_t ldo, float* lse, int32_t n_dst, int32_t n_src, int32_t H,
                                        int32_t C, anemoi_dtype_t dtype, void* stream);
 

@@ -171,6 +171,36 @@ def test_attention_fused_edge_rescale_branches(ops, dtype):
         assert_close(lse, O.gt_conv_lse(f(q), f(k), e, ei, (n, n)), dtype, f"fused rescale lse [{mode}]")
 
 
+def test_attention_processing_order_changes_nothing(ops, monkeypatch):
+    """The locality-preserving WORK order of the fused attention (ops.processing_order: BFS over the short edges inside every
+    XCD's index range, res-6 mesh) is a permutation, differs from the identity, and the kernel's output and log-sum-exp are
+    bit-identical with and without it, also with the write-through output stores (ANEMOI_ATTN_OUT_WT=1 is read at first launch:
+    covered by the alternative-build A/B runs, here the default)."""
+    from anemoi_core_amd.graphs.synthetic import build_synthetic_graph
+
+    g = build_synthetic_graph("o8", 6)
+    n, H, D, fe = g.num_hidden, 16, 512, 11
+    ei = torch.from_numpy(g.proc_edge_index).to(DEV)
+    csc = ops.build_csc(ei, (n, n))
+    order = ops.processing_order(csc)
+    assert order is not None and order.dtype == torch.int32 and order.shape == (n,)
+    assert torch.equal(torch.sort(order.long())[0], torch.arange(n, device=DEV)) and not torch.equal(order.long(), torch.arange(n, device=DEV))
+    per = (n + 7) // 8  # every XCD keeps its own index range
+    assert torch.equal(order.long() // per, torch.arange(n, device=DEV) // per)
+    gen = torch.Generator().manual_seed(3)
+    q, k, v = (torch.randn(n, D, generator=gen).to(torch.bfloat16).to(DEV) for _ in range(3))
+    feat = ops.pack_edge_features(torch.randn(ei.shape[1], fe, generator=gen).to(DEV))
+    w = ops.pack_edge_weights((torch.randn(D, fe, generator=gen) / 3).to(torch.bfloat16).to(DEV), torch.zeros(D, dtype=torch.bfloat16, device=DEV))
+    plain = ops.gt_attention_fused_edge(q, k, v, feat, w, csc, H, return_lse=True)
+    csc.order = order
+    ordered = ops.gt_attention_fused_edge(q, k, v, feat, w, csc, H, return_lse=True)
+    assert torch.equal(plain[0], ordered[0]) and torch.equal(plain[1], ordered[1])
+    small = ops.build_csc(ei[:, (ei[0] < 1000) & (ei[1] < 1000)], (1000, 1000))
+    assert ops.processing_order(small) is None  # nothing to gain: the rows fit the L2s
+    bip = ops.build_csc(torch.from_numpy(g.enc_edge_index).to(DEV), (g.num_data, n))
+    assert ops.processing_order(bip) is None  # bipartite: no destination-destination adjacency to walk
+
+
 def test_attention_strided_views(ops):
     """q/k/v as column slices of one fused [N, 4D] projection buffer (leading dimension 4D)."""
     gen = torch.Generator().manual_seed(5)

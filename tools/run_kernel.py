@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Developer aid: launch ONE kernel of the benchmark layer `reps` times (for rocprofv3 --pmc / --kernel-trace).
-usage: python tools/run_kernel.py <substring of the case name> [reps]"""
+usage: python tools/run_kernel.py <substring of the case name> [reps]        (ANEMOI_RUN_KERNEL_RES=6: the res-6 hidden mesh)"""
 import os
 import sys
 from types import SimpleNamespace
@@ -10,7 +10,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
-args = SimpleNamespace(data_grid="o96", hidden_res=5, layers=1, channels=512, heads=16, vars=84, kind="gt")
+args = SimpleNamespace(data_grid="o96", hidden_res=int(os.environ.get("ANEMOI_RUN_KERNEL_RES", "5")), layers=1, channels=512, heads=16, vars=84, kind="gt")
 dev = torch.device("cuda", 0)
 g, model, x = bench.build(args, dev)
 model = model.to(dev).to(torch.bfloat16)
