@@ -170,19 +170,30 @@ class GraphTransformerBaseBlock(BaseBlock):
             from ..autograd import attention, fused_attention
 
             wdt = self.lin_edge.weight.dtype
-            if (fused is not None and not self.qk_norm and isinstance(self.edge_pre_mlp, nn.Identity) and _FUSED_EDGE_BWD
-                    and ops.fused_edge_backward_supported(query.shape[1], H, edge_attr.shape[1])):
-                # lin_edge fused into the attention in forward AND backward: E / dE never exist; the packed features are shared
-                # by the layers of a processor
-                fkey = (id(edge_attr), id(csc.perm), "feat")
-                feat = None if edge_prep is None else edge_prep.get(fkey)
-                if feat is None:
-                    feat = ag.pack_edge_features(edge_attr if csc.perm is None else edge_attr.index_select(0, csc.perm))
-                    if edge_prep is not None:
-                        edge_prep[fkey] = feat
-                        edge_prep.setdefault("anchors", []).append((edge_attr, csc.perm))
+            if fused is not None and _FUSED_EDGE_BWD and ops.fused_edge_backward_supported(query.shape[1], H, edge_attr.shape[1]):
+                # lin_edge fused into the attention in forward AND backward: E / dE never exist
+                if isinstance(self.edge_pre_mlp, nn.Identity):
+                    fkey = (id(edge_attr), id(csc.perm), "feat")  # the packed features are shared by the layers of a processor
+                    feat = None if edge_prep is None else edge_prep.get(fkey)
+                    if feat is None:
+                        feat = ag.pack_edge_features(edge_attr if csc.perm is None else edge_attr.index_select(0, csc.perm))
+                        if edge_prep is not None:
+                            edge_prep[fkey] = feat
+                            edge_prep.setdefault("anchors", []).append((edge_attr, csc.perm))
+                else:
+                    # edge_pre_mlp (block.py:585-586) is this block's own Linear + GELU on the [M, edge_dim] attributes: it
+                    # runs as such (autograd through the GEMM path), its output is packed for the fused kernel, and the
+                    # kernel's feature gradient flows back into it
+                    ea = edge_attr if csc.perm is None else edge_attr.index_select(0, csc.perm)
+                    feat = ag.pack_edge_features(self._pad_edge(ea.to(wdt), self.edge_pre_mlp[0], act="gelu"))
+                bufs = tuple(fused["bufs"])
                 spec = {"A": query.shape[1], **{kk: fused[kk] for kk in ("q", "k", "v", "s")}}
-                return ag.fused_edge_attention(spec, fused["bufs"], feat, self.lin_edge, csc, H, get_reverse_csr(csc))
+                if self.qk_norm:
+                    # q_norm / k_norm made NEW tensors of q and k: they enter as two more (whole) buffers; v and the self term
+                    # stay column slabs of the projection buffers, whose q / k columns get their gradient through the norms
+                    bufs = (*bufs, query.contiguous(), key.contiguous())
+                    spec["q"], spec["k"] = (len(bufs) - 2, 0), (len(bufs) - 1, 0)
+                return ag.fused_edge_attention(spec, bufs, feat, self.lin_edge, csc, H, get_reverse_csr(csc))
             pkey = (id(edge_attr), id(csc.perm), wdt)
             ea = None if edge_prep is None else edge_prep.get(pkey)
             if ea is None:

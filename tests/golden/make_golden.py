@@ -172,6 +172,48 @@ def gen_blocks():
     save("blocks.pt", out)
 
 
+def gen_blocks_train():
+    """Blocks with the options whose TRAINING path VERDICT r2 item 9 asks for - edge_pre_mlp and qk_norm (block.py:585-586,
+    637-687) - with the reference's forward output AND the reference's own autograd gradients of loss = sum(out * w) w.r.t. the
+    input, the edge attributes and every parameter."""
+    gen = torch.Generator().manual_seed(977)
+    lk = load_layer_kernels()
+    out = {}
+    torch.manual_seed(12)
+    for tag, qk_norm, pre in [("proc_edgepre_qknorm", True, True), ("proc_edgepre", False, True)]:
+        C, hid, H = 64, 128, 4
+        cfg = dict(in_channels=C, hidden_dim=hid, out_channels=C, num_heads=H, edge_dim=11, qk_norm=qk_norm, edge_pre_mlp=pre)
+        blk = GraphTransformerProcessorBlock(layer_kernels=lk, graph_attention_backend="pyg", **cfg).train()
+        _randomise(blk, gen)
+        N, M = 60, 400
+        ei = _rand_graph(gen, N, N, M, (5,))
+        x = torch.randn(N, C, generator=gen).requires_grad_(True)
+        ea = torch.randn(M, 11, generator=gen).requires_grad_(True)
+        w = torch.randn(N, C, generator=gen)
+        y, _ = blk(x, ea, ei, GraphShardInfo(nodes=[N], edges=[M]), 1, N)
+        (y * w).sum().backward()
+        out[tag] = dict(cfg=cfg, params=_sd(blk), x=x.detach(), edge_attr=ea.detach(), edge_index=ei, w=w, out=y.detach(),
+                        dx=x.grad.clone(), d_edge_attr=ea.grad.clone(),
+                        grads={k: p.grad.clone() for k, p in blk.named_parameters() if p.grad is not None})
+        print(tag, "out", float(y.abs().mean()), "grads", len(out[tag]["grads"]))
+    C, hid, H = 64, 128, 4
+    cfg = dict(in_channels=C, hidden_dim=hid, out_channels=C, num_heads=H, edge_dim=7, qk_norm=True, edge_pre_mlp=True, update_src_nodes=False)
+    blk = GraphTransformerMapperBlock(layer_kernels=lk, graph_attention_backend="pyg", **cfg).train()
+    _randomise(blk, gen)
+    Ns, Nd, M = 70, 40, 300
+    ei = _rand_graph(gen, Ns, Nd, M, (0,))
+    xs = torch.randn(Ns, C, generator=gen).requires_grad_(True)
+    xd = torch.randn(Nd, C, generator=gen).requires_grad_(True)
+    ea = torch.randn(M, 7, generator=gen).requires_grad_(True)
+    w = torch.randn(Nd, C, generator=gen)
+    (ys, yd), _ = blk((xs, xd), ea, ei, BipartiteGraphShardInfo(src_nodes=[Ns], dst_nodes=[Nd], edges=[M]), 1, (Ns, Nd))
+    (yd * w).sum().backward()
+    out["map_edgepre_qknorm"] = dict(cfg=cfg, params=_sd(blk), x_src=xs.detach(), x_dst=xd.detach(), edge_attr=ea.detach(), edge_index=ei, w=w,
+                                     out_dst=yd.detach(), dx_src=xs.grad.clone(), dx_dst=xd.grad.clone(), d_edge_attr=ea.grad.clone(),
+                                     grads={k: p.grad.clone() for k, p in blk.named_parameters() if p.grad is not None})
+    save("blocks_train.pt", out)
+
+
 # ----------------------------------------------------------------------------------- processor / mapper level
 def gen_proc_mappers():
     gen = torch.Generator().manual_seed(777)
@@ -637,11 +679,13 @@ def gen_edges():
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ["conv", "blocks", "proc", "model", "batch", "grads", "sharding", "variants", "edges"]
+    which = sys.argv[1:] or ["conv", "blocks", "blocks_train", "proc", "model", "batch", "grads", "sharding", "variants", "edges"]
     if "conv" in which:
         gen_conv()
     if "blocks" in which:
         gen_blocks()
+    if "blocks_train" in which:
+        gen_blocks_train()
     if "proc" in which:
         gen_proc_mappers()
     if "model" in which:

@@ -33,6 +33,33 @@ def test_gt_processor_block(golden, tag):
     close(out, c["out"])
 
 
+@pytest.mark.parametrize("tag", ["proc_edgepre_qknorm", "proc_edgepre", "map_edgepre_qknorm"])
+def test_gt_blocks_with_edge_pre_mlp_forward_and_autograd(golden, tag):
+    """edge_pre_mlp / qk_norm blocks (block.py:585-586, 637-687): the oracle's forward AND its torch autograd against the
+    REFERENCE's output and the reference's own autograd gradients (fixture blocks_train.pt) - input, edge attributes, parameters."""
+    c = golden("blocks_train.pt")[tag]
+    p = {"." + k: v.clone().requires_grad_(True) for k, v in c["params"].items()}
+    ea = c["edge_attr"].clone().requires_grad_(True)
+    if tag.startswith("proc"):
+        x = c["x"].clone().requires_grad_(True)
+        out = O.gt_processor_block(p, "", x, ea, c["edge_index"], c["cfg"]["num_heads"])
+        close(out.detach(), c["out"])
+        (out * c["w"]).sum().backward()
+        close(x.grad, c["dx"], 2e-5)
+    else:
+        xs, xd = c["x_src"].clone().requires_grad_(True), c["x_dst"].clone().requires_grad_(True)
+        _, out = O.gt_mapper_block(p, "", xs, xd, ea, c["edge_index"], c["cfg"]["num_heads"])
+        close(out.detach(), c["out_dst"])
+        (out * c["w"]).sum().backward()
+        close(xs.grad, c["dx_src"], 2e-5)
+        close(xd.grad, c["dx_dst"], 2e-5)
+    close(ea.grad, c["d_edge_attr"], 2e-5)
+    assert len(c["grads"]) >= 20
+    for k, g in c["grads"].items():
+        key = "." + (k.replace("layer_norm_attention.", "layer_norm_attention_dest.") if "." + k not in p or p["." + k].grad is None else k)
+        close(p[key].grad, g, 2e-5 * max(1.0, float(g.abs().max())))
+
+
 @pytest.mark.parametrize("tag", ["map", "map_qknorm_updsrc"])
 def test_gt_mapper_block(golden, tag):
     c = golden("blocks.pt")[tag]
