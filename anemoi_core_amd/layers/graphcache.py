@@ -3,6 +3,7 @@
 "legitimate wins"); here each structure is derived once per (edge_index tensor, size) and reused by all layers."""
 from __future__ import annotations
 
+import dataclasses
 import os
 from collections import OrderedDict
 from typing import Optional
@@ -50,8 +51,10 @@ def get_csc(edge_index: Tensor, size: tuple, edges_are_dst_sorted: bool = True) 
 
     def build():
         csc = ops.build_csc(edge_index, size, edges_are_dst_sorted)
-        if _ATTN_ORDER and edge_index.is_cuda:
-            csc.order = ops.processing_order(csc)  # locality-preserving work order of the fused attention (large square graphs)
+        if _ATTN_ORDER:
+            order = ops.processing_order(csc)  # locality-preserving work order of the fused attention (large square graphs)
+            if order is not None:
+                csc = dataclasses.replace(csc, order=order)
         return csc
 
     return _csc_cache.get(_key(edge_index, size, bool(edges_are_dst_sorted)), edge_index, build)

@@ -68,3 +68,22 @@ def test_build_csc_host_logic():
         ops.build_csc(ei, (5, 4), edges_are_dst_sorted=True, check=True)
     empty = ops.build_csc(torch.zeros(2, 0, dtype=torch.long), (3, 2))
     assert empty.colptr.tolist() == [0, 0, 0] and empty.num_edges == 0
+
+
+def test_processing_order_is_attached_to_the_cached_csc_of_a_large_square_graph():
+    """Host logic of the fused attention's work order (ops.processing_order through layers/graphcache.get_csc): a permutation
+    that keeps every XCD's eighth of the index range, attached to the (frozen) CSC of the res-6 mesh; small and bipartite graphs
+    keep the identity."""
+    from anemoi_core_amd.graphs.synthetic import build_synthetic_graph
+    from anemoi_core_amd.layers.graphcache import get_csc
+
+    g = build_synthetic_graph("o8", 6)
+    n = g.num_hidden
+    csc = get_csc(torch.from_numpy(g.proc_edge_index), (n, n), True)
+    assert csc.order is not None and csc.order.dtype == torch.int32
+    assert torch.equal(torch.sort(csc.order.long())[0], torch.arange(n))
+    per = (n + 7) // 8
+    assert torch.equal(csc.order.long() // per, torch.arange(n) // per)
+    assert get_csc(torch.from_numpy(g.enc_edge_index), (g.num_data, n), True).order is None
+    g3 = build_synthetic_graph("o8", 3)
+    assert get_csc(torch.from_numpy(g3.proc_edge_index), (g3.num_hidden, g3.num_hidden), True).order is None

@@ -192,8 +192,9 @@ def test_attention_processing_order_changes_nothing(ops, monkeypatch):
     feat = ops.pack_edge_features(torch.randn(ei.shape[1], fe, generator=gen).to(DEV))
     w = ops.pack_edge_weights((torch.randn(D, fe, generator=gen) / 3).to(torch.bfloat16).to(DEV), torch.zeros(D, dtype=torch.bfloat16, device=DEV))
     plain = ops.gt_attention_fused_edge(q, k, v, feat, w, csc, H, return_lse=True)
-    csc.order = order
-    ordered = ops.gt_attention_fused_edge(q, k, v, feat, w, csc, H, return_lse=True)
+    import dataclasses
+
+    ordered = ops.gt_attention_fused_edge(q, k, v, feat, w, dataclasses.replace(csc, order=order), H, return_lse=True)
     assert torch.equal(plain[0], ordered[0]) and torch.equal(plain[1], ordered[1])
     small = ops.build_csc(ei[:, (ei[0] < 1000) & (ei[1] < 1000)], (1000, 1000))
     assert ops.processing_order(small) is None  # nothing to gain: the rows fit the L2s

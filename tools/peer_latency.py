@@ -81,12 +81,66 @@ def worker(rank, world, init_file, args):
     dist.destroy_process_group()
 
 
+def loopback(args):
+    """ONE process: the exchange kernel storing into its own arena, flagging itself and waiting for that flag - the kernel's
+    own cost (launch, row copy, system-scope release, flag round trip through uncached memory) without another process or
+    device in the picture.  Between two MI355X devices the stores and the flag additionally cross one xGMI link."""
+    import ctypes as C
+
+    sys.path.insert(0, REPO)
+    from anemoi_core_amd import _lib
+
+    lib = _lib.load()
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    D, nl, rows = 512, 1281, 2 * args.rows
+    pay, flg = C.c_void_p(), C.c_void_p()
+    _lib.check(lib.anemoi_peer_alloc(C.byref(pay), rows * D * 2, 0), "alloc")
+    _lib.check(lib.anemoi_peer_alloc(C.byref(flg), 4096, 2), "alloc")
+    x = torch.randn(nl, D, device=dev).to(torch.bfloat16)
+    idx = torch.randint(0, nl, (rows,), device=dev, dtype=torch.int32)
+    tab = torch.tensor([[pay.value], [flg.value + 64], [0], [rows], [1], [1]], dtype=torch.int64, device=dev)
+
+    def go():
+        _lib.check(lib.anemoi_peer_exchange_rows(x.data_ptr(), D * 2, idx.data_ptr(), tab.data_ptr(), 1, D * 2, rows, flg.value + 64,
+                                                 flg.value, 5 * 100_000_000, torch.cuda.current_stream().cuda_stream), "exchange")
+
+    for _ in range(3):
+        go()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(args.layers):
+            go()
+    for _ in range(5):
+        g.replay()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.replays):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / args.replays / args.layers
+    from anemoi_core_amd.distributed.peer import _view
+
+    got = _view(pay.value, rows * D * 2, dev).view(torch.bfloat16).view(rows, D)
+    assert torch.equal(got, x[idx.long()]), "loopback rows differ"
+    print(f"[peer_latency] loopback, one process: {rows} rows x 1 KiB copied + released + flagged + flag awaited: {us:.2f} us per exchange "
+          f"({args.layers} per graph, {args.replays} replays)")
+    lib.anemoi_peer_free(pay)
+    lib.anemoi_peer_free(flg)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
+    ap.add_argument("--loopback", action="store_true")
     ap.add_argument("--world", type=int, default=2)
     ap.add_argument("--rows", type=int, default=188)
     ap.add_argument("--layers", type=int, default=16)
     ap.add_argument("--replays", type=int, default=200)
     a = ap.parse_args()
+    if a.loopback:
+        loopback(a)
+        sys.exit(0)
     with tempfile.TemporaryDirectory() as tmp:
         mp.spawn(worker, args=(a.world, os.path.join(tmp, "init"), a), nprocs=a.world, join=True)

@@ -5,7 +5,7 @@ OUT=$R/gpurun_out/r3d
 mkdir -p $OUT
 export ANEMOI_PEER_TIMEOUT_S=15
 (timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_distributed_gpu.py -m gpu -x -q 2>&1 | tail -15) > $OUT/tests_a.log 2>&1
-(timeout 600 python -m pytest tests/test_config3_sharded_gpu.py -m gpu -x -q -k "bench_entry" 2>&1 | grep -v "amdgpu.ids\|Gloo" | tail -30) > $OUT/tests_bench8.log 2>&1
+(timeout 900 python -m pytest tests/test_config3_sharded_gpu.py tests/test_training_gpu.py -m gpu -x -q -k "bench_entry or edge_pre" 2>&1 | grep -v "amdgpu.ids\|Gloo" | tail -30) > $OUT/tests_bench8.log 2>&1
 # LayerNorm fold on small meshes (res 3 = 642, res 4 = 2562 hidden nodes): old gate (4096 rows) against no gate
 for r in 3 4; do for m in 4096 0; do
   echo "res $r fold_min_rows $m" >> $OUT/small_mesh.log
@@ -16,8 +16,10 @@ for m in 4096 0; do
   ANEMOI_LN_FOLD_MIN_ROWS=$m timeout 600 python tools/rank_floor.py --world 8 --hidden-res 5 --wire ipc > $OUT/floor_w8_r5_fold$m.json 2> $OUT/floor_w8_r5_fold$m.err
 done
 ANEMOI_LN_FOLD_MIN_ROWS=0 timeout 600 python tools/rank_floor.py --world 8 --hidden-res 6 --wire ipc > $OUT/floor_w8_r6_fold0.json 2> $OUT/floor_w8_r6.err
-timeout 300 python tools/peer_latency.py --world 2 > $OUT/peer_latency.log 2>&1
-timeout 300 python tools/peer_latency.py --world 8 --rows 256 >> $OUT/peer_latency.log 2>&1
+timeout 300 python tools/peer_latency.py --loopback > $OUT/peer_latency.log 2>&1
+timeout 300 python tools/peer_latency.py --loopback --rows 512 >> $OUT/peer_latency.log 2>&1
+timeout 300 python tools/peer_latency.py --world 2 >> $OUT/peer_latency.log 2>&1
+timeout 300 python tools/peer_latency.py --world 3 >> $OUT/peer_latency.log 2>&1
 # attention work order / write-through output stores at res 6 (the processor kernel alone, then the forward)
 for o in 0 1; do for w in 0 1; do
   echo "order $o out_wt $w" >> $OUT/attn_order.log
