@@ -48,6 +48,7 @@ struct PeerArgs {
   uint32_t* local_flags;  // [P] then seq, ticket
   uint32_t* status;
   uint64_t timeout_ticks;
+  int32_t write_through;  // 1: rows leave with system-scope write-through stores (no L2 write-back before the flag)
 };
 
 __device__ __forceinline__ uint32_t ld_sys(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
@@ -69,13 +70,23 @@ __global__ __launch_bounds__(kPeerThreads) void peer_exchange_kernel(PeerArgs a)
     while (row >= send_begin[p] + send_count[p]) ++p;  // P is small; begins ascend, empty peers are skipped by the test
     const int src_row = a.send_index ? a.send_index[row] : row;
     const uint4 v = *reinterpret_cast<const uint4*>(a.src + (int64_t)src_row * a.ld_src + (int64_t)col * 16);
-    *reinterpret_cast<uint4*>(reinterpret_cast<char*>(remote_base[p]) + (row - send_begin[p]) * row_bytes + (int64_t)col * 16) = v;
+    char* dstp = reinterpret_cast<char*>(remote_base[p]) + (row - send_begin[p]) * row_bytes + (int64_t)col * 16;
+    if (a.write_through) {
+      // 16-byte system-scope write-through store: the bytes go straight to their home (the peer's HBM over xGMI), nothing
+      // stays dirty in this XCD's L2, so publishing needs a drained vmcnt instead of a buffer_wbl2 of the whole L2 (guide:
+      // "sc1 payload -> vmcnt(0) -> sc1 flag" costs 1.7-1.9x a bare hand-off, the write-back form 2-2.5x and more under load)
+      typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dstp), "v"(__builtin_bit_cast(u32x4, v)) : "memory");
+    } else {
+      *reinterpret_cast<uint4*>(dstp) = v;
+    }
   }
+  if (a.write_through) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every lane's own stores have left
   __syncthreads();
   if (threadIdx.x == 0) {
     // publish this workgroup's stores at system scope BEFORE its ticket can be seen (guide: fence, then a drained vmcnt the
     // compiler cannot drop, then the flag / ticket)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    if (!a.write_through) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = (t == gridDim.x - 1);
@@ -172,8 +183,9 @@ extern "C" int anemoi_peer_exchange_rows(const void* src, int64_t ld_src_bytes, 
                                                          (reinterpret_cast<uintptr_t>(src) & 15) == 0)),
                  "peer_exchange_rows: rows must be 16-byte multiples at 16-byte aligned addresses (row_bytes=%d ld=%lld)", row_bytes,
                  (long long)ld_src_bytes);
+  static const int write_through = env_int(getenv("ANEMOI_PEER_WRITE_THROUGH"), 1, 0, 1);
   PeerArgs a{static_cast<const char*>(src), ld_src_bytes, send_index, table, n_peers, row_bytes / 16, total_rows, local_flags, status,
-             (uint64_t)(timeout_ticks > 0 ? timeout_ticks : 0)};
+             (uint64_t)(timeout_ticks > 0 ? timeout_ticks : 0), write_through};
   // a few workgroups move <= 1 MB faster than one (stores in flight over the links); a barrier is one workgroup
   const int64_t chunks = (int64_t)total_rows * (row_bytes / 16);
   int grid = (int)((chunks + 4 * kPeerThreads - 1) / (4 * kPeerThreads));

@@ -256,8 +256,6 @@ class GraphTransformerBaseBlock(BaseBlock):
         H, C, A = self.num_heads, self.out_channels_conv, self.attn_channels
         if H % P:
             raise ValueError(f"shard_strategy='heads': num_heads ({H}) must be divisible by the model-parallel size ({P})")
-        if not isinstance(self.edge_pre_mlp, nn.Identity):
-            raise NotImplementedError("edge_pre_mlp with shard_strategy='heads'")
         Hl = H // P
         src_sizes, dst_sizes = list(src_sizes), list(dst_sizes)
         csc = get_csc(ei_full, (sum(src_sizes), sum(dst_sizes)), True)
@@ -278,6 +276,11 @@ class GraphTransformerBaseBlock(BaseBlock):
             lin = self.lin_edge
             ea = ea_full if csc.perm is None else ea_full.index_select(0, csc.perm)
             ea = ea.to(lin.weight.dtype)
+            if not isinstance(self.edge_pre_mlp, nn.Identity):
+                # edge_pre_mlp (block.py:585-586) acts on the [M, edge_dim] attributes before any head exists: every rank applies
+                # it to the gathered attributes (replicated, M x edge_dim^2 flops); its parameter gradients are this rank's heads'
+                # share and are completed by reduce_parameter_gradients like all others
+                ea = self._pad_edge(ea, self.edge_pre_mlp[0], act="gelu")
             w_e = lin.weight[rows]
             pad = (-ea.shape[1]) % 8
             if pad and ea.dtype != torch.float32:  # 16-bit operand rows must be 16-byte aligned
@@ -285,7 +288,12 @@ class GraphTransformerBaseBlock(BaseBlock):
             e = ops.linear(ea, w_e, None if lin.bias is None else lin.bias[rows])
             o = attention(q, k, v, e, csc, Hl, get_reverse_csr(csc))
         else:
-            feat = get_edge_features(ea_full, csc.perm)
+            if isinstance(self.edge_pre_mlp, nn.Identity):
+                feat = get_edge_features(ea_full, csc.perm)
+            else:
+                pre = self.edge_pre_mlp[0]
+                ea = ea_full if csc.perm is None else ea_full.index_select(0, csc.perm)
+                feat = ops.pack_edge_features(ops.linear(ea.to(pre.weight.dtype), pre.weight, pre.bias, act="gelu"))
             o = ops.gt_attention_fused_edge(q, k, v, feat, self._fused.packed_edge(self.lin_edge)[rows], csc, Hl)  # [n_dst_full, Hl*C]
         n_loc = q_loc.shape[0]
         back = comm.all_to_all_rows(o, dst_sizes, [n_loc] * P, group)  # [P*n_loc, Hl*C]: block r = heads of rank r

@@ -187,8 +187,8 @@ class GraphTransformerBaseMapper(BaseMapper):
         """shard_strategy="heads" (reference mapper.py:388-444): source and destination rows sharded for the embeddings,
         projections and MLP; the attention runs on the whole bipartite graph for this rank's heads
         (``GraphTransformerBaseBlock._heads_attention``)."""
-        if self.proc.update_src_nodes:
-            raise NotImplementedError("update_src_nodes with shard_strategy='heads'")
+        # update_src_nodes: the block's source-side MLP is row-local (it runs on this rank's source rows like everywhere else);
+        # like the reference's GraphTransformer mappers (mapper.py:445-477) only the destination rows are returned
         x_src, x_dst = x
         edge_attr, edge_index = ensure_edges_are_dst_sorted(
             edge_attr, edge_index, edges_are_sharded=shard_info.edges_are_sharded(), model_comm_group=group,

@@ -410,3 +410,59 @@ def test_unsharded_forward_between_sharded_ones_keeps_the_collectively_built_pla
     for o in outs:
         assert o["ok"] and o["same"] and float((o["out"] - c["out"]).abs().max()) < 2e-4
     assert float((outs[0]["unsharded"] - c["out"]).abs().max()) < 2e-4
+
+
+def _heads_edgepre_cfg():
+    s = load_golden("sharding.pt")
+    return {**s["cfg"], "edge_pre_mlp": True, "qk_norm": True}
+
+
+def _heads_edgepre_module(strategy):
+    from anemoi_core_amd.layers.processor import GraphTransformerProcessor
+
+    torch.manual_seed(1234)  # the same random parameters on every rank and in the single-rank reference run
+    return GraphTransformerProcessor(**{**_heads_edgepre_cfg(), "shard_strategy": strategy}).cuda()
+
+
+def _heads_edgepre_worker(rank, world, group, train):
+    from anemoi_core_amd.distributed.primitives import reduce_parameter_gradients, shard_tensor
+    from anemoi_core_amd.distributed.shapes import GraphShardInfo, get_shard_sizes
+
+    s = load_golden("sharding.pt")
+    proc = _heads_edgepre_module("heads").train(train)
+    x, ea, ei = s["x"].cuda(), s["edge_attr"].cuda(), s["edge_index"].cuda()
+    sizes = get_shard_sizes(x, 0, group)
+    x_loc = shard_tensor(x, 0, sizes, group).clone().requires_grad_(train)
+    with torch.set_grad_enabled(train):
+        y = proc(x_loc, 1, GraphShardInfo(nodes=sizes, edges=None), ea, ei, model_comm_group=group)
+    if not train:
+        return dict(out=y.cpu())
+    w = torch.randn(s["out"].shape, generator=torch.Generator().manual_seed(5)).cuda()
+    r0 = sum(sizes[:rank])
+    (y * w[r0:r0 + sizes[rank]]).sum().backward()
+    reduce_parameter_gradients(proc, group)
+    return dict(out=y.detach().cpu(), dx=x_loc.grad.cpu(), grads={k: p.grad.cpu() for k, p in proc.named_parameters()})
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_heads_strategy_with_edge_pre_mlp_and_qk_norm_equals_single_rank(train):
+    """edge_pre_mlp (+ qk_norm) under shard_strategy="heads" (block.py:585-586, 689-759): forward and, in
+    training, all gradients of 2 ranks on the HIP kernels == the single-GPU run of the same module (whose blocks are pinned to
+    the reference's output and autograd by blocks_train.pt)."""
+    from anemoi_core_amd.distributed.shapes import GraphShardInfo
+
+    s = load_golden("sharding.pt")
+    outs = _spawn(_heads_edgepre_worker, 2, train)
+    proc = _heads_edgepre_module("edges").train(train)
+    x = s["x"].cuda().requires_grad_(train)
+    with torch.set_grad_enabled(train):
+        ref = proc(x, 1, GraphShardInfo(), s["edge_attr"].cuda(), s["edge_index"].cuda())
+    assert float((torch.cat([o["out"] for o in outs]) - ref.detach().cpu()).abs().max()) < 1e-4
+    if train:
+        w = torch.randn(s["out"].shape, generator=torch.Generator().manual_seed(5)).cuda()
+        (ref * w).sum().backward()
+        assert float((torch.cat([o["dx"] for o in outs]) - x.grad.cpu()).abs().max()) <= 3e-4 * float(x.grad.abs().max())
+        want = {k: p.grad.cpu() for k, p in proc.named_parameters()}
+        for o in outs:
+            for k, g in o["grads"].items():
+                assert float((g - want[k]).abs().max()) <= 3e-4 * float(want[k].abs().max()) + 1e-6, k
