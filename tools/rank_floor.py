@@ -58,12 +58,25 @@ def worker(rank, world, init_file, args, out_file):
         dist.barrier()
         res = None
         t_ipc = None
+        scratch = None
         if wire is not None:
             wire.check()
             if rank == 0:
+                # rank 0 goes on ALONE: its exchange kernels keep doing everything but wait - the rows are stored (into a
+                # scratch area of its own, the peers are about to leave), released and flagged; nobody's flag is awaited
+                scratch = torch.empty(max(ch.send_rows * ch.row_bytes for ch in wire._channels) + 256, dtype=torch.uint8, device=dev)
                 for ch in wire._channels:
-                    ch.table[5].zero_()  # expect nobody: the peers stay idle from here on
+                    ch.table[0].fill_(scratch.data_ptr())
+                    ch.table[1].fill_(wire.flag_ptr + 8)  # a spare word of this rank's own flag block
+                    ch.table[5].zero_()
                 torch.cuda.synchronize()
+        dist.barrier()
+        if rank != 0:
+            # the idle peers' contexts on the shared GPU disturb rank 0's wall clock: they leave first
+            os._exit(0)
+        time.sleep(8.0)
+        if wire is not None:
+            if rank == 0:
                 for _ in range(3):
                     step()
                 s = torch.cuda.Stream()
@@ -125,8 +138,7 @@ def worker(rank, world, init_file, args, out_file):
                    "collectives": sg.num_collectives, "components": {k: v for k, v in comp.items() if k.endswith("_ms")},
                    "families": {k: {"calls": v["calls"], "us": round(v["us"], 1)} for k, v in fam.items()}}
             json.dump(res, open(out_file, "w"))
-        dist.barrier()
-    dist.destroy_process_group()
+    os._exit(0)  # the peers are gone: no collective shutdown
 
 
 if __name__ == "__main__":
