@@ -103,7 +103,9 @@ __global__ __launch_bounds__(kPeerThreads) void peer_exchange_kernel(PeerArgs a)
     const int64_t* signal = a.table + 4 * a.P;
     const int64_t* expect = a.table + 5 * a.P;
     if (signal[p]) __hip_atomic_store(reinterpret_cast<uint32_t*>(remote_flag[p]), epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (expect[p]) {
+    // fail fast: once a wait of this rank has timed out (status != 0) later exchanges do not wait again - a broken wire costs
+    // ONE time-out, after which the host finds the status word (PeerWire.check) and falls back to the RCCL path
+    if (expect[p] && ld_sys(a.status) == 0) {
       const uint64_t t0 = wall_clock64();
       while ((int32_t)(ld_sys(a.local_flags + p) - epoch) < 0) {
         __builtin_amdgcn_s_sleep(8);

@@ -22,7 +22,8 @@ from ..distributed.partition import build_graph_partition_from_shard_info
 from ..distributed.shapes import BipartiteGraphShardInfo, GraphShardInfo, comm_rank, comm_size, model_is_distributed
 from .conv import GraphConv
 from .graphcache import get_csc, get_edge_features, get_reverse_csr
-from .kernels import ConditionalLayerNorm, PaddedLinear, apply_layer_norm
+from .kernels import PaddedLinear
+from .normalization import ConditionalLayerNorm, apply_layer_norm
 from .mlp import MLP
 from .utils import compute_mlp_hidden_dim
 from ..utils.tensors import version
