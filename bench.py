@@ -735,22 +735,22 @@ def main():
 
             def roof(name, bound):
                 d = fam[name]
-                # ONE definition of the kernel's duration: the HIP-event bracket minus what a bracket adds to the kernel inside it
-                # (`bracket_overhead_us`, calibrated in the same backed-up queue: bracketed launches of one small kernel against
-                # the same launches back to back) - which is what rocprofv3's kernel trace of the timed replays reports for the
-                # same launches (profiles/, `rocprof_cross_check`); the raw-bracket figure stays beside it as the lower bound
+                # ONE definition of the kernel's duration for `achieved` / `frac`: the HIP-event bracket on the launch stream as it
+                # is (kernel + the gaps to its two markers) - a LOWER bound of the kernel's rate that needs no calibration.  Beside
+                # it: the same with the calibrated bracket overhead subtracted (an UPPER bound: `bracket_overhead_us` is measured on a
+                # small kernel, whose launch / retire the markers overlap less than a 30 us GEMM's) and the figure from the
+                # committed rocprofv3 trace of the timed replays (`rocprof_cross_check`), which lies between the two.
                 us_net = max(d["us"] - d["calls"] * d["marker_us"], 1e-3)
                 work, scale, peak, unit = ((d["flops"], 1e6, MFMA_BF16_PEAK_TFLOPS, "TFLOP/s") if bound == "mfma"
                                            else (d["bytes"], 1e3, HBM_PEAK_GBS, "GB/s"))
-                ach, ach_raw = work / us_net / scale, work / d["us"] / scale
+                ach, ach_net = work / d["us"] / scale, work / us_net / scale
                 tr = traffic.get(name)
                 return {"kernel": name, "bound": bound, "achieved": round(ach, 1), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
-                        "achieved_raw_brackets": round(ach_raw, 1), "frac_raw_brackets": round(ach_raw / peak, 4),
+                        "achieved_overhead_subtracted": round(ach_net, 1), "frac_overhead_subtracted": round(ach_net / peak, 4),
                         "bracket_overhead_us": d["marker_us"], "empty_bracket_us": d["empty_bracket_us"],
-                        "avg_launch_us_raw_bracket": round(d["us"] / d["calls"], 2),
                         "traffic": tr, "algorithmic_bytes_per_launch": round(d["bytes"] / d["calls"]),
                         "traffic_over_algorithmic": round(tr / (d["bytes"] / d["calls"]), 3) if tr else None,
-                        "calls_per_step": d["calls"], "avg_launch_us": round(us_net / d["calls"], 2)}
+                        "calls_per_step": d["calls"], "avg_launch_us": round(d["us"] / d["calls"], 2)}
 
             res["kernel_families"] = {k: {"calls": v["calls"], "total_us": round(v["us"], 1), "avg_us": round(v["us"] / v["calls"], 2),
                                           "flops": v["flops"], "bytes": v["bytes"],
@@ -759,15 +759,16 @@ def main():
             dom = max(fam, key=lambda k: fam[k]["us"])
             res["roofline"] = roof(dom, "mfma" if fam[dom]["flops"] else "hbm")
             res["roofline"]["traffic_source"] = traffic_file
-            res["roofline"]["how"] = ("sum of algorithmic work of all launches of the family in one forward / sum of their durations; duration = "
-                                      "HIP-event bracket on the launch stream minus `bracket_overhead_us` (what a bracket adds to the kernel inside "
-                                      "it: 48 bracketed launches of one small kernel against the same 48 back to back, same backed-up queue); the "
-                                      "rocprofv3 --kernel-trace summary of the timed replays in profiles/ gives the same per-launch durations "
-                                      "(`rocprof_cross_check`); `*_raw_brackets` = without the subtraction (lower bound)")
+            res["roofline"]["how"] = ("sum of algorithmic work of all launches of the family in one forward / sum of their HIP-event brackets on the "
+                                      "launch stream (kernel + the gaps to its two markers: a lower bound of the rate); `*_overhead_subtracted` "
+                                      "= the same minus `bracket_overhead_us` per launch (48 bracketed launches of one small kernel against the "
+                                      "same 48 back to back, same backed-up queue: an upper bound); `rocprof_cross_check` = the family's "
+                                      "duration in the committed rocprofv3 --kernel-trace summary of the timed replays (profiles/)")
             res["roofline"]["rocprof_cross_check"] = rocprof_cross_check(args.config, dom, fam[dom], "mfma" if fam[dom]["flops"] else "hbm")
             gs = "gt_attn_fused_edge_fwd_kernel" if args.kind == "gt" else "edge_ln_res_segsum_kernel"
             if gs in fam:
                 res["roofline"]["gather_scatter"] = roof(gs, "hbm")
+                res["roofline"]["gather_scatter"]["rocprof_cross_check"] = rocprof_cross_check(args.config, gs, fam[gs], "hbm")
         if world == 1 and not args.no_cpu_baseline:
             cfg = {"num_heads": args.heads, "num_layers": args.layers, "num_channels": args.channels, "kind": args.kind}
             try:
