@@ -48,7 +48,7 @@ struct PeerArgs {
   uint32_t* local_flags;  // [P] then seq, ticket
   uint32_t* status;
   uint64_t timeout_ticks;
-  int32_t write_through;  // 1: rows leave with system-scope write-through stores (no L2 write-back before the flag)
+  int32_t write_through;  // 1: rows leave with system-scope write-through stores (the release then has nothing to write back)
 };
 
 __device__ __forceinline__ uint32_t ld_sys(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
@@ -81,12 +81,11 @@ __global__ __launch_bounds__(kPeerThreads) void peer_exchange_kernel(PeerArgs a)
       *reinterpret_cast<uint4*>(dstp) = v;
     }
   }
-  if (a.write_through) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every lane's own stores have left
   __syncthreads();
   if (threadIdx.x == 0) {
     // publish this workgroup's stores at system scope BEFORE its ticket can be seen (guide: fence, then a drained vmcnt the
     // compiler cannot drop, then the flag / ticket)
-    if (!a.write_through) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = (t == gridDim.x - 1);
@@ -95,21 +94,14 @@ __global__ __launch_bounds__(kPeerThreads) void peer_exchange_kernel(PeerArgs a)
   if (!s_last) return;
   // ---- last workgroup: every workgroup's rows are released; signal the peers, wait for theirs
   const uint32_t epoch = s_epoch;
-  // write-through rows: every workgroup drained its own stores before it took its ticket, so having seen the last ticket is
-  // all the ordering the flags need - no cache maintenance at all on this path (each fence is 2-6 us, guide section 4)
-  if (!a.write_through && threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the other workgroups' releases, through their tickets
   __syncthreads();
   if ((int)threadIdx.x < a.P) {
     const int p = threadIdx.x;
     const int64_t* remote_flag = a.table + a.P;
     const int64_t* signal = a.table + 4 * a.P;
     const int64_t* expect = a.table + 5 * a.P;
-    if (signal[p]) {
-      if (a.write_through)
-        __hip_atomic_store(reinterpret_cast<uint32_t*>(remote_flag[p]), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      else
-        __hip_atomic_store(reinterpret_cast<uint32_t*>(remote_flag[p]), epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    if (signal[p]) __hip_atomic_store(reinterpret_cast<uint32_t*>(remote_flag[p]), epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     // fail fast: once a wait of this rank has timed out (status != 0) later exchanges do not wait again - a broken wire costs
     // ONE time-out, after which the host finds the status word (PeerWire.check) and falls back to the RCCL path
     if (expect[p] && ld_sys(a.status) == 0) {
@@ -125,8 +117,7 @@ __global__ __launch_bounds__(kPeerThreads) void peer_exchange_kernel(PeerArgs a)
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    // the peers' rows are read by LATER kernels of this stream (a kernel boundary is an acquire); nothing of this grid reads them
-    if (!a.write_through) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // pairs with the peers' releases; the rows themselves are read by LATER kernels
     __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(seq, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -193,7 +184,7 @@ extern "C" int anemoi_peer_exchange_rows(const void* src, int64_t ld_src_bytes, 
                                                          (reinterpret_cast<uintptr_t>(src) & 15) == 0)),
                  "peer_exchange_rows: rows must be 16-byte multiples at 16-byte aligned addresses (row_bytes=%d ld=%lld)", row_bytes,
                  (long long)ld_src_bytes);
-  static const int write_through = env_int(getenv("ANEMOI_PEER_WRITE_THROUGH"), 1, 0, 1);
+  static const int write_through = env_int(getenv("ANEMOI_PEER_WRITE_THROUGH"), 0, 0, 1);
   PeerArgs a{static_cast<const char*>(src), ld_src_bytes, send_index, table, n_peers, row_bytes / 16, total_rows, local_flags, status,
              (uint64_t)(timeout_ticks > 0 ? timeout_ticks : 0), write_through};
   // a few workgroups move <= 1 MB faster than one (stores in flight over the links); a barrier is one workgroup
