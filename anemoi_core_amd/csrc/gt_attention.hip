@@ -540,9 +540,12 @@ static int launch_fast(const AttnArgs& a) {
     // the fused [q|k|v|self] projection buffer: v sits right behind k in every row
     const bool kv_adjacent = (const T*)a.v == (const T*)a.k + 64 * VEC && a.ldv == a.ldk &&
                              (int64_t)a.n_src * a.ldk < (int64_t(1) << 32);
-    // the head's feature terms shared out among its lanes where they divide evenly (ANEMOI_ATTN_FSPLIT=0: every lane all of them)
+    // ANEMOI_ATTN_FSPLIT=1: the head's feature terms shared out among its lanes (where they divide evenly).  Built to cut VALU
+    // slots (45 -> 37 per edge) and measured SLOWER on MI355X - 26.7 -> 29.7 us at res 5, 91.8 -> 95.2 us at res 6, forward
+    // 2.976 -> 3.019 ms: the per-lane feature load is a third vector-memory instruction per edge next to the K and V rows,
+    // and that pipe, not the VALU, is what the saved slots were waiting on.  Off; kept as the record of the experiment.
     constexpr bool kCanSplit = LPH > 1 && FE_PAD % LPH == 0;
-    static const int fsplit = [] { return env_int(getenv("ANEMOI_ATTN_FSPLIT"), 1, 0, 1); }();
+    static const int fsplit = [] { return env_int(getenv("ANEMOI_ATTN_FSPLIT"), 0, 0, 1); }();
     auto kern = kv_adjacent ? gt_attn_fused_edge_fwd_kernel<T, VEC, LPH, FE_PAD, true, false> : gt_attn_fused_edge_fwd_kernel<T, VEC, LPH, FE_PAD, false, false>;
     if constexpr (kCanSplit) {
       if (fsplit) kern = kv_adjacent ? gt_attn_fused_edge_fwd_kernel<T, VEC, LPH, FE_PAD, true, true> : gt_attn_fused_edge_fwd_kernel<T, VEC, LPH, FE_PAD, false, true>;

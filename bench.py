@@ -596,19 +596,26 @@ def main():
             ok, why = 1, ""
             try:
                 wire.check()
-                if rank == 0:  # on a COPY: the model's static caches (rank-local graphs, collectively built plans) stay sharded
+            except Exception as e:  # noqa: BLE001
+                ok, why = 0, f"{type(e).__name__}: {str(e)[:200]}"
+            # every collective of this check is issued by EVERY rank whatever happened to it above
+            holder = [None]
+            if rank == 0:
+                try:  # on a COPY: the model's static caches (rank-local graphs, collectively built plans) stay sharded
                     import copy
 
-                    ref = copy.deepcopy(model)(inp)["data"]
-                holder = [ref.float().cpu() if rank == 0 else None]
-                torch.distributed.broadcast_object_list(holder, src=0)
+                    holder = [copy.deepcopy(model)(inp)["data"].float().cpu()]
+                except Exception as e:  # noqa: BLE001
+                    ok, why = 0, f"unsharded reference forward failed: {type(e).__name__}: {str(e)[:200]}"
+            torch.distributed.broadcast_object_list(holder, src=0)
+            if ok and holder[0] is not None:
                 err = float((out.float().cpu() - holder[0]).abs().max())
                 scale = max(1.0, float(holder[0].abs().max()))
                 if not err <= (2e-5 if dtype == torch.float32 else 2e-2) * scale:
                     ok, why = 0, f"sharded output differs from the unsharded forward by {err:.3e} (scale {scale:.2f})"
-                holder = None
-            except Exception as e:  # noqa: BLE001
-                ok, why = 0, f"{type(e).__name__}: {str(e)[:200]}"
+            elif holder[0] is None:
+                ok = 0
+            holder = None
             flag = torch.tensor([ok], device="cpu" if host_transport else device, dtype=torch.int32)
             torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
             if int(flag.item()) == 0:

@@ -12,7 +12,9 @@ Checked, for every rank's (replicated) output of the exact 16-layer benchmark mo
     1.3 k rows than the unsharded ones on 10 k rows, so the K-sums are associated differently - bit-equality is reported, not
     required) and to `oracle.enc_proc_dec_forward` within 5e-5 * s (the unsharded model's own bound, test_fullsize_parity_gpu.py);
   * bf16: within the 16-bit bound of the unsharded model test (max 2e-2 * s, mean 5e-3) against the fp32 oracle on rounded values;
-  * all ranks return bit-identical outputs (the output all-gather);
+  * all ranks return bit-identical outputs (the output all-gather); a forward on a DIFFERENT input through the same receive
+    buffers equals the unsharded forward on that input as well (fp32: bit for bit), and the first input repeated afterwards
+    reproduces the first output;
   * N_halo per rank equals an independent count from the global edge list and lies in SURVEY.md §8(e)'s table
     (res 5: 277 at P = 2, 260-501 at P = 4, 188-517 at P = 8; res 6, P = 8: 338-1 066).
 """
@@ -45,12 +47,17 @@ def _worker(rank, world, group, hidden_res, layers, dtype_name, wire):
     g, model, x = bench.build(_args(hidden_res, layers), DEV)
     model = model.to(DEV).to(dtype)
     inp = {"data": x.to(DEV).to(dtype)}
+    other = {"data": (x * 0.5 + 0.25).to(DEV).to(dtype)}
     with torch.inference_mode():
         y = model(inp, model_comm_group=group)["data"].clone()
-        y2 = model(inp, model_comm_group=group)["data"]  # second pass: every plan and static cache is reused
+        # a DIFFERENT input through the same receive buffers, then the first one again: rows left over from the previous forward
+        # (a late peer, a stale cache line) cannot pass for the right ones, as they could with one input repeated
+        y_other = model(other, model_comm_group=group)["data"].clone()
+        y2 = model(inp, model_comm_group=group)["data"]  # every plan, channel and static cache reused
         torch.cuda.synchronize()
     plan = model.processor._halo_cache["plan"]
-    return dict(out=y.float().cpu(), repeat_equal=bool(torch.equal(y, y2)), n_local=int(plan.info.num_local_nodes),
+    return dict(out=y.float().cpu(), out_other=y_other.float().cpu() if rank in (0, world - 1) else None,
+                repeat_equal=bool(torch.equal(y, y2)), n_local=int(plan.info.num_local_nodes),
                 recv_counts=[int(c) for c in plan.recv_counts], send_counts=[int(c) for c in plan.send_counts])
 
 
@@ -71,12 +78,13 @@ def _reference(hidden_res, layers, dtype):
         m = model.to(DEV).to(dtype)
         with torch.inference_mode():
             hip = m({"data": x.to(DEV).to(dtype)})["data"].float().cpu()
+            hip_other = m({"data": (x * 0.5 + 0.25).to(DEV).to(dtype)})["data"].float().cpu()
         del m
         torch.cuda.empty_cache()
         with torch.no_grad():
             want = O.enc_proc_dec_forward(params, dict(kind="gt", num_heads=16, num_layers=layers, num_channels=512), g,
                                           x.to(dtype).float())
-        _REF[key] = (g, hip, want)
+        _REF[key] = (g, hip, want, hip_other)
     return _REF[key]
 
 
@@ -95,11 +103,14 @@ def _independent_halo_counts(g, world):
     return dst_splits, out
 
 
-def _check_run(outs, g, hip, want, hidden_res, world, dtype):
+def _check_run(outs, g, hip, want, hidden_res, world, dtype, hip_other):
     s = max(1.0, float(want.abs().max()))
     for r, o in enumerate(outs):
-        assert o["repeat_equal"], f"rank {r}: second forward differs from the first"
+        assert o["repeat_equal"], f"rank {r}: the forward repeated after another input differs from the first"
         assert torch.equal(o["out"], outs[0]["out"]), f"rank {r}: gathered output differs from rank 0's"
+        if o["out_other"] is not None:  # the forward on the OTHER input, first and last rank
+            e = float((o["out_other"] - hip_other).abs().max())
+            assert (e == 0.0) if dtype == torch.float32 else (e <= 2e-2 * max(1.0, float(hip_other.abs().max()))), (r, e)
     got = outs[0]["out"]
     assert got.shape == want.shape == (1, 1, 1, g.num_data, 84) and torch.isfinite(got).all()
     e_hip, e_or = (got - hip).abs(), (got - want).abs()
@@ -124,17 +135,17 @@ def _check_run(outs, g, hip, want, hidden_res, world, dtype):
 @pytest.mark.parametrize("world,dtype", [(4, torch.float32), (8, torch.float32), (8, torch.bfloat16)])
 def test_o96_res5_bench_model_sharded_equals_unsharded_and_oracle(world, dtype, wire):
     """(a) world 4 and 8, O96 -> res 5, the 16-layer 512-channel benchmark model."""
-    g, hip, want = _reference(5, 16, dtype)
+    g, hip, want, hip_other = _reference(5, 16, dtype)
     outs = _spawn(_worker, world, 5, 16, str(dtype).split(".")[1], wire)
-    _check_run(outs, g, hip, want, 5, world, dtype)
+    _check_run(outs, g, hip, want, 5, world, dtype, hip_other)
 
 
 @pytest.mark.parametrize("wire", WIRES)
 def test_o96_res6_two_layers_sharded_over_eight_ranks(wire):
     """(b) the res-6 variant of config 3 (40 962 hidden nodes, 5 121 + 338..1 058 rows per rank), 2 processor layers, bf16."""
-    g, hip, want = _reference(6, 2, torch.bfloat16)
+    g, hip, want, hip_other = _reference(6, 2, torch.bfloat16)
     outs = _spawn(_worker, 8, 6, 2, "bfloat16", wire)
-    _check_run(outs, g, hip, want, 6, 8, torch.bfloat16)
+    _check_run(outs, g, hip, want, 6, 8, torch.bfloat16, hip_other)
 
 
 @pytest.mark.parametrize("wire", WIRES)
