@@ -784,7 +784,7 @@ def main():
             except Exception as e:  # noqa: BLE001  (a baseline leg must never take the benchmark line down)
                 res["gpu_eager_baseline"] = {"error": f"{type(e).__name__}: {e}"}
             torch.cuda.empty_cache()
-            res["cpu_baseline"] = cpu_baseline(params_fp32, cfg, g, x)
+            res["cpu_baseline"] = cpu_baseline(params_fp32, cfg, g, x, budget_s=float(os.environ.get("ANEMOI_BENCH_CPU_BUDGET_S", "150")))
         print(json.dumps(res), flush=True)
     if world > 1:
         if wire is not None:
