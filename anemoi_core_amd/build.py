@@ -16,6 +16,7 @@ REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIBPATH = os.path.join(LIBDIR, "libanemoi_hip.so")
+EXT_PATH = os.path.join(LIBDIR, "libanemoi_torch.so")
 INCLUDE = os.path.join(REPO, "include")
 
 SOURCES = ["lib.cpp", "gt_attention.hip", "gt_attention_bwd.hip", "rowwise.hip", "rowwise_bwd.hip", "linear.hip", "wgrad.hip", "peer.hip"]
@@ -62,7 +63,29 @@ def build_library(force: bool = False, verbose: bool = True, extra_flags: tuple[
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+    build_torch_extension(hipcc, force=force, verbose=verbose)
     return LIBPATH
+
+
+def build_torch_extension(hipcc: str, force: bool = False, verbose: bool = True) -> str:
+    """lib/libanemoi_torch.so: the TORCH_LIBRARY layer over the C ABI (csrc/torch_binding.cpp; host code only, links against
+    libanemoi_hip.so through $ORIGIN and against the libtorch of the running interpreter)."""
+    import torch
+
+    src = os.path.join(CSRC, "torch_binding.cpp")
+    if not force and _newer(EXT_PATH, [src, os.path.join(INCLUDE, "anemoi_hip.h"), LIBPATH]):
+        return EXT_PATH
+    troot = os.path.dirname(torch.__file__)
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = [hipcc, "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-I", INCLUDE, "-I", os.path.join(troot, "include"),
+           "-I", os.path.join(troot, "include", "torch", "csrc", "api", "include"), "-I", os.path.join(rocm, "include"), src, "-o", EXT_PATH,
+           "-L", LIBDIR, "-lanemoi_hip", "-L", os.path.join(troot, "lib"), "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch", "-ltorch_hip",
+           "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print("[build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return EXT_PATH
 
 
 if __name__ == "__main__":

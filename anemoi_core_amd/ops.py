@@ -17,7 +17,7 @@ from typing import Optional
 import torch
 from torch import Tensor
 
-from . import _lib
+from . import _ext, _lib
 
 _DT = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16, torch.float16: _lib.F16}
 
@@ -341,6 +341,10 @@ def gt_attention_fused_edge(q: Tensor, k: Tensor, v: Tensor, edge_feat: Tensor, 
                             addend: Optional[Tensor] = None, return_lse: bool = False):
     """Attention with lin_edge fused: edge_feat = pack_edge_features(edge_attr) fp32 [M, fe_pad];
     w_packed = pack_edge_weights(lin_edge.weight, lin_edge.bias) fp32 [D, fe_pad]."""
+    ext = _ext.ops()
+    if ext is not None:
+        out, lse = ext.gt_attention_fused_edge(q, k, v, edge_feat, w_packed, csc.row, csc.colptr, csc.order, csc.n_src, num_heads, addend, return_lse)
+        return (out, lse) if return_lse else out
     _dev(q, k, v, edge_feat, w_packed, addend, csc.row)
     D = q.shape[1]
     fe_pad = w_packed.shape[1]
@@ -424,6 +428,12 @@ def layer_norm(x: Tensor, weight: Tensor, bias: Optional[Tensor], eps: float = 1
 def _layer_norm_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], eps: float = 1e-5, residual: Optional[Tensor] = None,
                     out: Optional[Tensor] = None) -> Tensor:
     """``out``: a contiguous [rows, D] tensor (e.g. the leading rows of a larger buffer) that receives the result."""
+    ext = _ext.ops()
+    if ext is not None:  # the same entry point through the TORCH_LIBRARY layer: checks and marshalling in C++
+        if out is None:
+            return ext.layer_norm(x, weight, bias, float(eps), residual)
+        ext.layer_norm_out(x, weight, bias, float(eps), residual, out)
+        return out.view(x.shape)
     _dev(x, weight, bias, residual, out)
     D = x.shape[-1]
     x2 = x.reshape(-1, D)
@@ -471,6 +481,16 @@ def _linear_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, *, act
                 out: Optional[Tensor] = None, want_pre: bool = False):
     """``want_pre`` (training, act = "gelu"): returns (y, pre) with pre = the pre-activation stored by the same kernel, or
     (y, None) when the shape does not run on the DMA-ring kernels (the backward then recomputes it)."""
+    if not want_pre:
+        ext = _ext.ops()
+        if ext is not None:  # the same entry point through the TORCH_LIBRARY layer: checks and marshalling in C++
+            if act not in (None, "gelu"):
+                raise ValueError(f"unsupported activation {act!r}")
+            actc = _lib.ACT_GELU if act == "gelu" else _lib.ACT_NONE
+            if out is None:
+                return ext.linear(x, weight, bias, actc, residual, x2, g1, idx1, g2, idx2)
+            ext.linear_out(x, weight, bias, actc, residual, x2, g1, idx1, g2, idx2, out)
+            return out
     _dev(x, weight, bias, residual, x2, g1, idx1, g2, idx2, out)
     N, K1 = x.shape
     K2 = 0 if x2 is None else x2.shape[1]
@@ -677,6 +697,10 @@ def linear_wgrad(dz: Tensor, x: Tensor, with_bias_grad: bool = False):
 def linear_with_row_stats(x: Tensor, weight: Tensor, bias: Optional[Tensor], residual: Optional[Tensor] = None):
     """(y, stats) with y = x W^T + bias [+ residual] and stats [N, O/64, 2] fp32 = per 64-column strip (sum, sum of squares) of
     the stored rows of y — what ``linear_ln_folded`` needs to apply the LayerNorm of y.  None if the shape is not eligible."""
+    ext = _ext.ops()
+    if ext is not None:
+        y, stats = ext.linear_with_row_stats(x, weight, bias, residual)
+        return None if y.dim() != 2 else (y, stats)
     _dev(x, weight, bias, residual)
     N, K = x.shape
     O = weight.shape[0]
@@ -697,6 +721,10 @@ def linear_with_row_stats(x: Tensor, weight: Tensor, bias: Optional[Tensor], res
 def linear_ln_folded(x: Tensor, w_scaled: Tensor, c: Tensor, d: Tensor, stats: Tensor, eps: float, act: Optional[str] = None):
     """act(LayerNorm(x) W^T + b) from raw x, w_scaled = W * gamma, c = rowsum(w_scaled) (fp32), d = W beta + b (fp32) and the
     producer's row statistics of x.  None if the shape is not eligible (caller: LayerNorm + linear)."""
+    ext = _ext.ops()
+    if ext is not None:
+        y = ext.linear_ln_folded(x, w_scaled, c, d, stats, float(eps), _lib.ACT_GELU if act == "gelu" else _lib.ACT_NONE)
+        return None if y.dim() != 2 else y
     _dev(x, w_scaled, c, d, stats)
     N, K = x.shape
     O = w_scaled.shape[0]

@@ -87,3 +87,18 @@ def test_processing_order_is_attached_to_the_cached_csc_of_a_large_square_graph(
     assert get_csc(torch.from_numpy(g.enc_edge_index), (g.num_data, n), True).order is None
     g3 = build_synthetic_graph("o8", 3)
     assert get_csc(torch.from_numpy(g3.proc_edge_index), (g3.num_hidden, g3.num_hidden), True).order is None
+
+
+def test_torch_extension_loads_and_registers_its_ops():
+    """lib/libanemoi_torch.so (csrc/torch_binding.cpp) is built with the library, loads into this interpreter and registers the
+    five hot forward ops; CPU tensors are refused as loudly as on the ctypes path."""
+    from anemoi_core_amd import _ext
+    from anemoi_core_amd.build import build_library
+
+    build_library(verbose=False)
+    ext = _ext.ops()
+    assert ext is not None
+    for name in ("linear", "linear_out", "layer_norm", "layer_norm_out", "gt_attention_fused_edge", "linear_with_row_stats", "linear_ln_folded"):
+        assert hasattr(ext, name), name
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ext.layer_norm(torch.randn(4, 64), torch.ones(64), None, 1e-5, None)
