@@ -99,6 +99,7 @@ class PeerWire:
         self._channels: list = []
         self._seq = 0
         self._depth = 0
+        self._pending: Optional[_Channel] = None  # set by recv_buffer(), consumed by the exchange into that buffer
         self._barrier_ch = self._new_channel(("barrier",), [0] * self.world, [0] * self.world, 16, 0, barrier=True)
         dist.barrier(group=group)  # every rank has opened every arena before anyone stores into one
 
@@ -249,9 +250,8 @@ class PeerWire:
         row_bytes = src.shape[1] * es
         if row_bytes % 16 or (src.stride(0) * es) % 16 or src.data_ptr() % 16:
             raise PeerWireError(f"peer exchange: rows of {row_bytes} bytes (stride {src.stride(0) * es}) are not 16-byte multiples")
-        ch = getattr(self, "_pending", None)
-        self._pending = None
-        direct = ch is not None and self.owns(recv) and recv.data_ptr() == ch.region.data_ptr() + ch.head_rows * ch.row_bytes
+        ch, self._pending = self._pending, None
+        direct = ch is not None and (recv.numel() == 0 or (self.owns(recv) and recv.data_ptr() == ch.region.data_ptr() + ch.head_rows * ch.row_bytes))
         if not direct:
             if ch is not None:
                 raise PeerWireError("recv_buffer() must be followed by the exchange into that buffer")
