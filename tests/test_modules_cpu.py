@@ -118,3 +118,34 @@ def test_assemble_output_repeats_skip_over_output_steps():
     want[..., list(range(V_prog))] += x_skip.unsqueeze(1).expand(-1, T_out, -1, -1, -1)[..., list(range(V_prog))]
     assert got.shape == (1, T_out, 1, N, V_prog)
     torch.testing.assert_close(got, want, rtol=0, atol=0)
+
+
+def test_scoped_forward_finds_the_group_positionally_and_by_keyword(monkeypatch):
+    """distributed.primitives.scoped_forward wraps a module's forward in forward_scope(model_comm_group) - the device-initiated
+    wire's "one forward" marker - wherever the caller put the group; without a group nothing is entered."""
+    import contextlib
+
+    from anemoi_core_amd.distributed import primitives as P
+
+    seen = []
+
+    @contextlib.contextmanager
+    def scope(group):
+        seen.append(group)
+        yield
+
+    monkeypatch.setattr(P, "forward_scope", scope)
+
+    class M:
+        @P.scoped_forward
+        def forward(self, x, batch_size, model_comm_group=None, flag=True):
+            return x + 1
+
+        @P.scoped_forward
+        def kw_only(self, x, *, model_comm_group=None):
+            return x + 2
+
+    m = M()
+    assert m.forward(1, 2) == 2 and seen == []
+    assert m.forward(1, 2, "g0") == 2 and m.forward(1, 2, model_comm_group="g1") == 2 and m.kw_only(1, model_comm_group="g2") == 3
+    assert seen == ["g0", "g1", "g2"] and m.kw_only(1) == 3 and len(seen) == 3
