@@ -119,3 +119,21 @@ def test_predict_step_is_capturable_as_hip_graph(golden):
     gr.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, want)
+
+
+def test_predict_step_batch_of_two_equals_the_samples_one_by_one(golden):
+    """Batch > 1 through predict_step (the fused model-edge kernels take batch 1 only; a batch goes through the generic
+    assembly + the normaliser's own kernel): the samples of a batch do not interact, so the batch's output must be the
+    per-sample outputs stacked - each of which is pinned to the REFERENCE's predict_step by the test above."""
+    c = golden("edges.pt")["predict_step"]
+    model, pre, post = _model_and_processors(c)
+    b0 = c["batch"].to(DEV)
+    b1 = (b0 * 0.75 + 0.1 * b0.roll(1, dims=2)).contiguous()  # a second, different raw sample (same variable ranges)
+    n = c["cfg"]["n_step_input"]
+    one = [model.predict_step({"data": b}, {"data": pre}, {"data": post}, n)["data"] for b in (b0, b1)]
+    two = model.predict_step({"data": torch.cat([b0, b1], 0)}, {"data": pre}, {"data": post}, n)["data"]
+    assert two.shape[0] == 2 and two.shape[1:] == one[0].shape[1:]
+    scale = max(1.0, float(one[0].abs().max()))
+    for i in range(2):
+        assert float((two[i:i + 1] - one[i]).abs().max()) <= 2e-5 * scale, i
+    assert float((one[0].cpu() - c["out"]).abs().max()) <= 2e-5 * scale
