@@ -528,9 +528,15 @@ static int launch_fast(const AttnArgs& a) {
     constexpr int FE_PAD = decltype(fe_pad_c)::value;
     using L = WLayout<VEC, FE_PAD>;
     if (L::kFloats * sizeof(float) > 64 * 1024) return 1;  // beyond the default dynamic-LDS limit: generic path
-    // persistent grid: at most ~6 workgroups per CU (LDS 25 KiB each, 5-6 waves/SIMD by registers); every wave walks
-    // destinations d, d + total_waves, ... so the W' staging is paid once per workgroup
-    static const int per_cu = [] { const char* e = getenv("ANEMOI_ATTN_BLOCKS_PER_CU"); return env_int(e, 6, 1, 32); }();
+    // persistent grid: a few workgroups per CU (LDS 25 KiB each, 5-7 waves/SIMD by registers); every wave walks destinations
+    // d, d + total_waves, ... so the W' staging is paid once per workgroup.  How many: with the locality-preserving work order
+    // the number of destinations in flight per XCD is also the size of the window whose K|V rows should stay in the L2 -
+    // measured on MI355X (profiles/r03_attention_blocks_per_cu.txt, three repetitions): 10 242 destinations 27.4 / 26.9 / 26.1 us
+    // at 5 / 6 / 7 workgroups per CU, 40 962 destinations 80.6 / 89.6 / 84.2 us (5 workgroups = 640 waves per XCD = exactly 8
+    // destinations per wave, and the smallest window); forwards: O96 2.991 / 2.991 / 2.973 ms, O96 -> res 6 8.69 / 8.81 / 8.76 ms,
+    // N320 15.21 / 15.68 / 15.39 ms.  ANEMOI_ATTN_BLOCKS_PER_CU overrides the rule.
+    static const int per_cu_env = [] { const char* e = getenv("ANEMOI_ATTN_BLOCKS_PER_CU"); return env_int(e, 0, 0, 32); }();
+    const int per_cu = per_cu_env > 0 ? per_cu_env : (a.n_dst >= 20000 ? 5 : 7);
     static const int out_wt = [] { return env_int(getenv("ANEMOI_ATTN_OUT_WT"), 0, 0, 1); }();
     const int max_blocks = 256 * per_cu;
     int blocks = (a.n_dst + kWavesPerBlock - 1) / kWavesPerBlock;
