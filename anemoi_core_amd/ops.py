@@ -14,6 +14,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Optional
 
+import os
+
 import torch
 from torch import Tensor
 
@@ -139,7 +141,7 @@ def processing_order(csc: CSC, slices: int = 8) -> Optional[Tensor]:
     import numpy as np
 
     n = csc.n_dst
-    if csc.n_src != n or n < 16384 or csc.num_edges == 0:
+    if csc.n_src != n or n < int(os.environ.get("ANEMOI_ATTN_ORDER_MIN_NODES", "16384")) or csc.num_edges == 0:
         return None
     src = csc.row.cpu().numpy().astype(np.int64)
     dst = csc.dst.cpu().numpy().astype(np.int64)
