@@ -224,6 +224,11 @@ class PeerWire:
         try:
             if self._depth == 1:
                 self._seq = 0
+                if len(self._channels) == 1:
+                    # the first forward after install / reset: the ranks arrive from host-side set-up (model build, plans) that
+                    # may differ by many seconds, and the device barrier below has a time-out - meet on the host first.  Later
+                    # forwards are kept in step by their own exchanges.
+                    dist.barrier(group=self.group)
                 self._launch(self._barrier_ch, None, 0, None)
             yield
         finally:

@@ -557,7 +557,7 @@ def main():
             from anemoi_core_amd.distributed import peer
 
             try:
-                wire = peer.install(group, timeout_s=float(os.environ.get("ANEMOI_PEER_TIMEOUT_S", "5")))
+                wire = peer.install(group, timeout_s=float(os.environ.get("ANEMOI_PEER_TIMEOUT_S", "30")))
             except Exception as e:  # noqa: BLE001  (PeerWire set-up fails on all ranks together)
                 if transport == "ipc":
                     raise
