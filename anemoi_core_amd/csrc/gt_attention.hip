@@ -139,12 +139,11 @@ struct WLayout {
   static constexpr int kFloats = 64 * kChunk;
 };
 
-// FSPLIT: the FE_PAD edge-feature terms of a head are SHARED OUT among its LPH lanes (FE_PAD / LPH features per lane) instead of
-// every lane carrying all of them.  The head butterfly that finishes <q, k> sums the lanes' feature shares for free, the
-// weighted feature sums `sf` are kept per lane and gathered once per destination: per edge 2 x FE_PAD / LPH instead of
-// 2 x FE_PAD FMAs per lane, and the features arrive by ONE per-lane vector load instead of FE_PAD / 4 scalar loads (the kernel
-// is bound by instruction issue: DESIGN.md section 5).
-template <typename T, int VEC, int LPH, int FE_PAD, bool KVADJ, bool FSPLIT>
+// (An FSPLIT variant - the FE_PAD edge-feature terms of a head shared out among its LPH lanes, FE_PAD / LPH per lane, fetched by
+// one per-lane vector load instead of scalar loads - lived here in commits 99a7806..49471db: parity-green, 8 of ~45 VALU slots per
+// edge fewer, and SLOWER on MI355X, 26.7 -> 29.7 us at res 5 and 91.8 -> 95.2 us at res 6 (profiles/r03_attention_fsplit_ab.txt):
+// the third vector-memory instruction per edge costs more than the VALU slots it frees.  Removed again.)
+template <typename T, int VEC, int LPH, int FE_PAD, bool KVADJ>
 __global__ __launch_bounds__(64 * kWavesPerBlock, 16 / kWavesPerBlock) void gt_attn_fused_edge_fwd_kernel(
     const T* __restrict__ q, int64_t ldq, const T* __restrict__ k, int64_t ldk, const T* __restrict__ v, int64_t ldv,
     const float* __restrict__ feat, const float* __restrict__ w_packed, const int32_t* __restrict__ row,
@@ -222,41 +221,24 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 16 / kWavesPerBlock) void gt_a
     // exponent's multiplier (one multiply per edge less).
     // qw[f] = (1/LPH) * sum over the head's channels of q[c] * W'[c][f]  (pre-divided: every lane of the
     // head adds the same edge-feature term before the head butterfly).
-    constexpr int FPL = FSPLIT ? FE_PAD / LPH : FE_PAD;  // features a lane carries
-    const int hl = lane & (LPH - 1);                     // this lane's place in its head
-    float qw[FPL], sf[FPL];
-    {
-      float qw_all[FE_PAD];
+    float qw[FE_PAD], sf[FE_PAD];
 #pragma unroll
-      for (int f = 0; f < FE_PAD; ++f) {
-        // W' is stored [feature][channel] per lane: the VEC channels of a feature are contiguous (16-byte LDS reads) and
-        // the channel pairs map onto packed FMAs without shuffles, here and in the final W' * sum(p a)
-        float t = 0.f;
-        if constexpr (VEC % 2 == 0) {
-          f32x2 t2 = {0.f, 0.f};
+    for (int f = 0; f < FE_PAD; ++f) {
+      // W' is stored [feature][channel] per lane: the VEC channels of a feature are contiguous (16-byte LDS reads) and
+      // the channel pairs map onto packed FMAs without shuffles, here and in the final W' * sum(p a)
+      float t = 0.f;
+      if constexpr (VEC % 2 == 0) {
+        f32x2 t2 = {0.f, 0.f};
 #pragma unroll
-          for (int j = 0; j < VEC; j += 2)
-            t2 = __builtin_elementwise_fma(f32x2{qv[j], qv[j + 1]}, *reinterpret_cast<const f32x2*>(wl + f * VEC + j), t2);
-          t = t2[0] + t2[1];
-        } else {
+        for (int j = 0; j < VEC; j += 2)
+          t2 = __builtin_elementwise_fma(f32x2{qv[j], qv[j + 1]}, *reinterpret_cast<const f32x2*>(wl + f * VEC + j), t2);
+        t = t2[0] + t2[1];
+      } else {
 #pragma unroll
-          for (int j = 0; j < VEC; ++j) t = fmaf(qv[j], wl[f * VEC + j], t);
-        }
-        // unsplit: pre-divided, every lane of the head adds the same edge-feature term before the head butterfly
-        qw_all[f] = group_sum<LPH>(t) * (FSPLIT ? 1.0f : 1.0f / LPH);
+        for (int j = 0; j < VEC; ++j) t = fmaf(qv[j], wl[f * VEC + j], t);
       }
-#pragma unroll
-      for (int i = 0; i < FPL; ++i) {
-        if constexpr (FSPLIT) {  // lane hl keeps features hl * FPL + i (per destination: a handful of selects)
-          float sel = qw_all[i];
-#pragma unroll
-          for (int g = 1; g < LPH; ++g) sel = (hl == g) ? qw_all[g * FPL + i] : sel;
-          qw[i] = sel;
-        } else {
-          qw[i] = qw_all[i];
-        }
-        sf[i] = 0.f;
-      }
+      qw[f] = group_sum<LPH>(t) * (1.0f / LPH);  // pre-divided: every lane of the head adds the same edge-feature term
+      sf[f] = 0.f;
     }
     float m = -INFINITY, l = 0.f;
 
@@ -266,8 +248,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 16 / kWavesPerBlock) void gt_a
       const int n = min(64, end - chunk);
       const int my_src = (lane < n) ? row[chunk + lane] : 0;
       Raw kb[PF], vb[PF];
-      float fb[PF][FPL];
-      auto fetch = [&](int j, Raw& kr, Raw& vr, float (&fr)[FPL]) {
+      float fb[PF][FE_PAD];
+      auto fetch = [&](int j, Raw& kr, Raw& vr, float (&fr)[FE_PAD]) {
         j = min(j, n - 1);  // refills past the end re-read the last edge: an UNCONDITIONAL load keeps the ring registers
                             // free of select/copy code (a conditional one made the compiler wait for the load at once)
         const int s = __builtin_amdgcn_readlane(my_src, j);
@@ -285,18 +267,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 16 / kWavesPerBlock) void gt_a
           vr = *reinterpret_cast<const Raw*>(v + (int64_t)s * ldv + c0);
           a = feat + (int64_t)(chunk + j) * FE_PAD;
         }
-        if constexpr (FSPLIT) {
-          // this lane's FPL features of the edge: uniform base + per-lane offset -> one vector load per lane
-          struct __attribute__((packed, aligned(4))) Feats {
-            float v[FPL];
-          };
-          const Feats fv = *reinterpret_cast<const Feats*>(a + hl * FPL);
 #pragma unroll
-          for (int f = 0; f < FPL; ++f) fr[f] = fv.v[f];
-        } else {
-#pragma unroll
-          for (int f = 0; f < FPL; ++f) fr[f] = a[f];
-        }
+        for (int f = 0; f < FE_PAD; ++f) fr[f] = a[f];
       };
 #pragma unroll
       for (int st = 0; st < PF; ++st) fetch(st, kb[st], vb[st], fb[st]);
@@ -306,12 +278,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 16 / kWavesPerBlock) void gt_a
           const int j = j0 + st;
           if (j < n) {
             float dot = dot_rows<T, VEC>(q_raw, kb[st]);
-            if constexpr (FSPLIT) {  // this lane's share of the feature term; the head butterfly below adds the shares up
-              float fs = 0.f;
-#pragma unroll
-              for (int f = 0; f < FPL; ++f) fs = fmaf(fb[st][f], qw[f], fs);
-              dot += fs;
-            } else if constexpr (FE_PAD % 2 == 0) {  // feature pairs on packed FMAs (scalar-register pairs as loaded)
+            if constexpr (FE_PAD % 2 == 0) {  // feature pairs on packed FMAs (scalar-register pairs as loaded)
               f32x2 d2[2] = {{dot, 0.f}, {0.f, 0.f}};  // two chains: dependent packed FMAs back to back cost a wait state each
 #pragma unroll
               for (int f = 0; f < FE_PAD; f += 2)
@@ -330,7 +297,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 16 / kWavesPerBlock) void gt_a
 #pragma unroll
               for (int jj = 0; jj < VEC; ++jj) acc[jj] *= corr;
 #pragma unroll
-              for (int f = 0; f < FPL; ++f) sf[f] *= corr;
+              for (int f = 0; f < FE_PAD; ++f) sf[f] *= corr;
               m = m_new;
             }
             const float p = __builtin_amdgcn_exp2f((dot - m) * sl2e);
@@ -338,7 +305,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 16 / kWavesPerBlock) void gt_a
 #pragma unroll
             for (int jj = 0; jj < VEC; ++jj) acc[jj] = fmaf(p, to_float(vb[st].v[jj]), acc[jj]);
 #pragma unroll
-            for (int f = 0; f < FPL; ++f) sf[f] = fmaf(p, fb[st][f], sf[f]);
+            for (int f = 0; f < FE_PAD; ++f) sf[f] = fmaf(p, fb[st][f], sf[f]);
             fetch(j + PF, kb[st], vb[st], fb[st]);
           }
         }
@@ -347,16 +314,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 16 / kWavesPerBlock) void gt_a
 
     asm volatile("" ::: "memory");
     const float inv = (end > beg) ? 1.0f / l : 0.f;
-    float sfa[FE_PAD];  // the head's weighted feature sums, all of them in every lane again
-    if constexpr (FSPLIT) {
-#pragma unroll
-      for (int g = 0; g < LPH; ++g)
-#pragma unroll
-        for (int i = 0; i < FPL; ++i) sfa[g * FPL + i] = __shfl(sf[i], (lane & ~(LPH - 1)) | g, 64);
-    } else {
-#pragma unroll
-      for (int f = 0; f < FE_PAD; ++f) sfa[f] = sf[f];
-    }
     float o[VEC];
     if constexpr (VEC % 2 == 0) {
       f32x2 o2[VEC / 2];
@@ -364,7 +321,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 16 / kWavesPerBlock) void gt_a
       for (int j = 0; j < VEC; j += 2) o2[j / 2] = f32x2{acc[j], acc[j + 1]};
 #pragma unroll
       for (int f = 0; f < FE_PAD; ++f) {
-        const f32x2 s2 = {sfa[f], sfa[f]};
+        const f32x2 s2 = {sf[f], sf[f]};
 #pragma unroll
         for (int j = 0; j < VEC; j += 2) o2[j / 2] = __builtin_elementwise_fma(s2, *reinterpret_cast<const f32x2*>(wl + f * VEC + j), o2[j / 2]);
       }
@@ -378,7 +335,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 16 / kWavesPerBlock) void gt_a
       for (int j = 0; j < VEC; ++j) {
         float t = acc[j];
 #pragma unroll
-        for (int f = 0; f < FE_PAD; ++f) t = fmaf(sfa[f], wl[f * VEC + j], t);
+        for (int f = 0; f < FE_PAD; ++f) t = fmaf(sf[f], wl[f * VEC + j], t);
         o[j] = t * inv;
       }
     }
@@ -546,16 +503,7 @@ static int launch_fast(const AttnArgs& a) {
     // the fused [q|k|v|self] projection buffer: v sits right behind k in every row
     const bool kv_adjacent = (const T*)a.v == (const T*)a.k + 64 * VEC && a.ldv == a.ldk &&
                              (int64_t)a.n_src * a.ldk < (int64_t(1) << 32);
-    // ANEMOI_ATTN_FSPLIT=1: the head's feature terms shared out among its lanes (where they divide evenly).  Built to cut VALU
-    // slots (45 -> 37 per edge) and measured SLOWER on MI355X - 26.7 -> 29.7 us at res 5, 91.8 -> 95.2 us at res 6, forward
-    // 2.976 -> 3.019 ms: the per-lane feature load is a third vector-memory instruction per edge next to the K and V rows,
-    // and that pipe, not the VALU, is what the saved slots were waiting on.  Off; kept as the record of the experiment.
-    constexpr bool kCanSplit = LPH > 1 && FE_PAD % LPH == 0;
-    static const int fsplit = [] { return env_int(getenv("ANEMOI_ATTN_FSPLIT"), 0, 0, 1); }();
-    auto kern = kv_adjacent ? gt_attn_fused_edge_fwd_kernel<T, VEC, LPH, FE_PAD, true, false> : gt_attn_fused_edge_fwd_kernel<T, VEC, LPH, FE_PAD, false, false>;
-    if constexpr (kCanSplit) {
-      if (fsplit) kern = kv_adjacent ? gt_attn_fused_edge_fwd_kernel<T, VEC, LPH, FE_PAD, true, true> : gt_attn_fused_edge_fwd_kernel<T, VEC, LPH, FE_PAD, false, true>;
-    }
+    auto kern = kv_adjacent ? gt_attn_fused_edge_fwd_kernel<T, VEC, LPH, FE_PAD, true> : gt_attn_fused_edge_fwd_kernel<T, VEC, LPH, FE_PAD, false>;
     hipLaunchKernelGGL(kern, grid, block, L::kFloats * sizeof(float),
                        a.stream, (const T*)a.q, a.ldq, (const T*)a.k, a.ldk, (const T*)a.v, a.ldv, a.feat, a.w_packed,
                        a.row, a.colptr, a.order, (const T*)a.addend, a.ldadd, (T*)a.out, a.ldo, a.lse, a.n_dst, a.H, scale, out_wt);
