@@ -34,6 +34,9 @@ if __name__ == "__main__":
     ms = (time.perf_counter() - t0) / n * 1e3
     bad = [k for k, p in model.named_parameters() if p.grad is None or not bool(torch.isfinite(p.grad).all())]
     with torch.no_grad():
+        for _ in range(3):  # the first forward after an optimiser-free training loop re-derives the packed / folded weights
+            model(inp)
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(n):
             model(inp)
