@@ -392,6 +392,14 @@ __device__ __forceinline__ void ln_row_stats(const LinArgs& a, int m, float& mu,
   rs = rsqrtf(fmaxf(s2 * inv - mu * mu, 0.f) + a.ln_eps);
 }
 
+// The gather-add epilogue's row indices for one lane (rows mi * 16 + it * 8 of its wave's slab), loaded by the big-tile kernel during
+// the first K-step of the tile: otherwise every band of the epilogue pays two DEPENDENT global latencies - index, then row - with
+// the matrix cores idle (the GNN's edge GEMM: 98 us with the gather-add against 57 us without; GNN forward 8.03 -> 7.86 ms).
+template <int MI>
+struct GatherIdx {
+  int i1[MI][2], i2[MI][2];
+};
+
 // Fast path of the epilogue below for INTERIOR tiles (every row and column of the tile exists) with bias / residual / gather /
 // GELU only - the hot case.  The generic epilogue carries, per 16-byte store, the predicates of ragged tiles, the 4-column tail
 // of O % 8 == 4, the fp32-atomic split-K branch and 64-bit address products: measured on MI355X its on-chip work (stores
@@ -401,7 +409,7 @@ __device__ __forceinline__ void ln_row_stats(const LinArgs& a, int m, float& mu,
 // to be kept from reordering them) - the transposition of band mi+1 overlaps the arithmetic and stores of band mi.
 template <typename T, int EPI, int MI>
 __device__ __forceinline__ void mfma_epilogue_fast(const LinArgs& a, f32x4 (&acc)[MI][4], int m0, int n0, int wr, int wc, int lane,
-                                                   unsigned char* epi, const float* ln_rows = nullptr) {
+                                                   unsigned char* epi, const float* ln_rows = nullptr, const GatherIdx<MI>* gidx = nullptr) {
   using V8 = Vec<T, 8>;
   const int cp = lane & 7;
   const int nc = n0 + wc * 64 + cp * 8;
@@ -443,6 +451,7 @@ __device__ __forceinline__ void mfma_epilogue_fast(const LinArgs& a, f32x4 (&acc
   }
   // residual / gather rows of band mi+1 are requested BEFORE the stores of band mi: vmcnt retires in issue order (stores
   // included), so a load issued after a store cannot be waited for without waiting for that store's write acknowledgement too
+  // (two bands of gathered rows in flight instead of one: measured slower, 8.07 against 7.86 ms for the GNN forward)
   V8 rv[2], t1[2], t2[2], rv_n[2], t1_n[2], t2_n[2];
   auto fetch = [&](int mi, V8 (&r)[2], V8 (&g1)[2], V8 (&g2)[2]) {
 #pragma unroll
@@ -453,8 +462,12 @@ __device__ __forceinline__ void mfma_epilogue_fast(const LinArgs& a, f32x4 (&acc
       if constexpr ((EPI & EPI_RES) != 0) r[it] = *reinterpret_cast<const V8*>(rlane + (int64_t)(mi * 16 + it * 8) * a.ldr);
       if constexpr ((EPI & EPI_GATHER) != 0) {
         const int m = mrow0 + mi * 16 + it * 8;
-        g1[it] = *reinterpret_cast<const V8*>((const T*)a.g1 + (int64_t)a.idx1[m] * a.ldg1 + nc);
-        if (a.g2 != nullptr) g2[it] = *reinterpret_cast<const V8*>((const T*)a.g2 + (int64_t)a.idx2[m] * a.ldg2 + nc);
+        const int r1 = gidx != nullptr ? gidx->i1[mi][it] : a.idx1[m];
+        g1[it] = *reinterpret_cast<const V8*>((const T*)a.g1 + (int64_t)r1 * a.ldg1 + nc);
+        if (a.g2 != nullptr) {
+          const int r2 = gidx != nullptr ? gidx->i2[mi][it] : a.idx2[m];
+          g2[it] = *reinterpret_cast<const V8*>((const T*)a.g2 + (int64_t)r2 * a.ldg2 + nc);
+        }
       }
     }
   };
@@ -537,10 +550,11 @@ __device__ __forceinline__ void mfma_epilogue_fast(const LinArgs& a, f32x4 (&acc
 
 template <typename T, int EPI, int MI = 4>
 __device__ __forceinline__ void mfma_epilogue_band(const LinArgs& a, f32x4 (&acc)[MI][4], int m0, int n0, int wr, int wc,
-                                                   int lane, unsigned char* epi, bool interior, const float* ln_rows = nullptr) {
+                                                   int lane, unsigned char* epi, bool interior, const float* ln_rows = nullptr,
+                                                   const GatherIdx<MI>* gidx = nullptr) {
   if constexpr ((EPI & ~(EPI_RES | EPI_GATHER | EPI_GELU | EPI_STATS | EPI_LNFOLD)) == 0) {
     if (interior && !a.f32_atomic && a.fast_epi) {  // wave-uniform: one branch per tile
-      mfma_epilogue_fast<T, EPI, MI>(a, acc, m0, n0, wr, wc, lane, epi, ln_rows);
+      mfma_epilogue_fast<T, EPI, MI>(a, acc, m0, n0, wr, wc, lane, epi, ln_rows, gidx);
       return;
     }
   }
@@ -1160,6 +1174,7 @@ __global__ __launch_bounds__(512, 1) void linear_mfma_bigtile_kernel(LinArgs a, 
   constexpr int kPPW = kAPW + kWPW;
   constexpr int kStageBytes = (TBM + TBN) * BK * 2;
   constexpr int kStores = 2 * MI;  // stores per wave of an interior epilogue
+  constexpr bool kPreIdx = (EPI & EPI_GATHER) != 0 && MI <= 5;  // 4 * MI more live registers: the 320-row tile has none to spare
   static_assert(kPPW <= 2 * MI, "one DMA piece per 16-row band of a K-step");
   static_assert(kPPW + kStores <= 63, "vmcnt is a 6-bit counter");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2][A tile | W tile] [1 KiB dummy]
@@ -1276,6 +1291,9 @@ __global__ __launch_bounds__(512, 1) void linear_mfma_bigtile_kernel(LinArgs a, 
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
     float* ln_rows = reinterpret_cast<float*>(smem + STAGES * kStageBytes + 1024) + (j & 1) * TBM * 2;
+    GatherIdx<kPreIdx ? MI : 1> gidx;
+    const GatherIdx<MI>* gidx_p = nullptr;
+    if constexpr (kPreIdx) gidx_p = &gidx;
     if constexpr ((EPI & EPI_LNFOLD) != 0) {
       // mean / rstd of the tile's rows from the producer's strip sums (fixed order), one thread per row, while the first
       // K-tile is in flight; double-buffered over tiles, published by the K-loop's barriers
@@ -1315,6 +1333,21 @@ __global__ __launch_bounds__(512, 1) void linear_mfma_bigtile_kernel(LinArgs a, 
       counted_stores = false;
       __builtin_amdgcn_s_barrier();  // also: every wave has finished reading K-tile g-1, whose stage is refilled below
       asm volatile("" ::: "memory");
+      if constexpr (kPreIdx) {
+        // the epilogue's gather indices: requested here (after the wait above, so the counted waits stay exact; the next K-step's
+        // vmcnt(0) covers them), used ~nk K-steps later
+        if (kt == 0) {
+          const int mr = m0 + wr * (16 * MI) + (lane >> 3);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+              const int m = min(mr + mi * 16 + it * 8, a.n_rows - 1);
+              gidx.i1[mi][it] = a.idx1[m];
+              gidx.i2[mi][it] = a.g2 != nullptr ? a.idx2[m] : 0;
+            }
+        }
+      }
       const unsigned char* st = smem + (g % STAGES) * kStageBytes;
       begin_issue();
 #pragma unroll
@@ -1336,7 +1369,8 @@ __global__ __launch_bounds__(512, 1) void linear_mfma_bigtile_kernel(LinArgs a, 
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     const bool interior = (m0 + TBM <= a.n_rows) && (n0 + TBN <= a.O);
-    mfma_epilogue_band<T, EPI, MI>(a, acc, m0, n0, wr, wc, lane, smem + ((g - 1) % STAGES) * kStageBytes + wave * 4096, interior, ln_rows);
+    mfma_epilogue_band<T, EPI, MI>(a, acc, m0, n0, wr, wc, lane, smem + ((g - 1) % STAGES) * kStageBytes + wave * 4096, interior, ln_rows,
+                                   gidx_p);
     counted_stores = interior && (EPI & EPI_PRE) == 0;  // exactly kStores stores per wave, issued after the DMAs of the next K-tile
   }
 }

@@ -208,6 +208,103 @@ __global__ __launch_bounds__(64 * kRowWaves) void edge_ln_res_segsum_kernel(
   store_row<T, VEC, CH>(agg + (int64_t)d * ldagg, D, lane, sum);
 }
 
+// Quarter-wave variant for 512 16-bit channels (the GNN's edge rows): still one wave per destination, but FOUR of its in-edges at
+// a time - 16 lanes per edge row, CHQ 16-byte chunks per lane, so 2 * CHQ loads per lane are in flight instead of 2, the LayerNorm
+// reductions stay inside a DPP row, and the loads of the next four rows are issued before the current four are normalised.  A
+// destination of the processor mesh has ~8 in-edges: two trips through the loop instead of eight dependent ones.  The per-row
+// arithmetic is the one of the kernel above; the segment sum adds the lane groups' partial sums (fp32) at the end.
+// <T, 2, 32> is the half-wave form (two rows at a time, 32 lanes per row, half the registers).
+template <typename T, int CHQ, int LPR = 16>
+__global__ __launch_bounds__(64 * kRowWaves) void edge_ln_res_segsum_kernel_mr(
+    const T* __restrict__ z, int64_t ldz, const T* __restrict__ e_old, int64_t lde, const T* __restrict__ gamma,
+    const T* __restrict__ beta, float eps, const int32_t* __restrict__ colptr, T* __restrict__ e_new, int64_t ldn,
+    T* __restrict__ agg, int64_t ldagg, int n_dst) {
+  constexpr int D = LPR * 8 * CHQ, RPW = 64 / LPR;
+  using V8 = Vec<T, 8>;
+  const int lane = threadIdx.x & 63, l16 = lane % LPR, g = lane / LPR;
+  const int d = __builtin_amdgcn_readfirstlane(blockIdx.x * kRowWaves + (threadIdx.x >> 6));
+  if (d >= n_dst) return;
+  const int beg = __builtin_amdgcn_readfirstlane(colptr[d]);
+  const int end = __builtin_amdgcn_readfirstlane(colptr[d + 1]);
+  V8 gq[CHQ], bq[CHQ];
+#pragma unroll
+  for (int c = 0; c < CHQ; ++c) {
+    gq[c] = *reinterpret_cast<const V8*>(gamma + (c * LPR + l16) * 8);
+    if (beta != nullptr) {
+      bq[c] = *reinterpret_cast<const V8*>(beta + (c * LPR + l16) * 8);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bq[c].v[j] = from_float<T>(0.f);
+    }
+  }
+  float sum[CHQ][8];
+#pragma unroll
+  for (int c = 0; c < CHQ; ++c)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sum[c][j] = 0.f;
+  V8 zq[CHQ], eq[CHQ];
+  const auto fetch = [&](int m0, V8(&zz)[CHQ], V8(&ee)[CHQ]) {  // groups past the segment's end re-read its last row and drop the result
+    const int64_t m = min(m0 + g, end - 1);
+#pragma unroll
+    for (int c = 0; c < CHQ; ++c) {
+      zz[c] = *reinterpret_cast<const V8*>(z + m * ldz + (c * LPR + l16) * 8);
+      ee[c] = *reinterpret_cast<const V8*>(e_old + m * lde + (c * LPR + l16) * 8);
+    }
+  };
+  if (beg < end) fetch(beg, zq, eq);
+  for (int m0 = beg; m0 < end; m0 += RPW) {
+    V8 zn[CHQ], en[CHQ];
+    const bool more = m0 + RPW < end;  // wave-uniform
+    if (more) fetch(m0 + RPW, zn, en);
+    const bool live = m0 + g < end;
+    float v[CHQ][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < CHQ; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v[c][j] = to_float(zq[c].v[j]);
+        s += v[c][j];
+      }
+    const float mean = group_sum<LPR>(s) * (1.0f / D);
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < CHQ; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v[c][j] -= mean;
+        ss = fmaf(v[c][j], v[c][j], ss);
+      }
+    const float rstd = rsqrtf(group_sum<LPR>(ss) * (1.0f / D) + eps);
+#pragma unroll
+    for (int c = 0; c < CHQ; ++c) {
+      V8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        o.v[j] = from_float<T>(fmaf(v[c][j] * rstd, to_float(gq[c].v[j]), to_float(bq[c].v[j])) + to_float(eq[c].v[j]));
+        if (live) sum[c][j] += to_float(o.v[j]);  // what is stored (storage precision), as scatter(sum) over the stored e_new sees it
+      }
+      if (live) *reinterpret_cast<V8*>(e_new + (int64_t)(m0 + g) * ldn + (c * LPR + l16) * 8) = o;
+    }
+    if (more) {
+#pragma unroll
+      for (int c = 0; c < CHQ; ++c) {
+        zq[c] = zn[c];
+        eq[c] = en[c];
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CHQ; ++c) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if constexpr (LPR <= 16) sum[c][j] += __shfl_xor(sum[c][j], 16, 64);
+      if constexpr (LPR <= 32) sum[c][j] += __shfl_xor(sum[c][j], 32, 64);
+    }
+    if (g == 0) store_vec<T, 8>(agg + (int64_t)d * ldagg + (c * LPR + l16) * 8, sum[c]);
+  }
+}
+
 template <typename T, int VEC>
 __global__ __launch_bounds__(64 * kRowWaves) void gather_rows_kernel(const T* __restrict__ x, int64_t ldx,
                                                                      const int32_t* __restrict__ idx,
@@ -451,6 +548,21 @@ static int edge_launch(const void* z, int64_t ldz, const void* e_old, int64_t ld
   const int ch = pick_chunks(D, vec);
   ANEMOI_REQUIRE(ch > 0, "edge_ln_residual_segment_sum_fwd: D=%d too large (max %d)", D, 64 * vec * kMaxChunksLimit);
   const dim3 grid((n_dst + kRowWaves - 1) / kRowWaves), block(64 * kRowWaves);
+  static const int quarter = env_int(getenv("ANEMOI_SEGSUM_QUARTER"), 2, 0, 3);  // rows per wave at a time: 1 -> four, 2 -> two, 3 -> one
+  if constexpr (sizeof(T) == 2) {
+    if (quarter && vec == 8 && D == 512 && gamma != nullptr && n_dst > 0) {  // the GNN's 512-channel edge rows
+      if (quarter == 1)
+        hipLaunchKernelGGL((edge_ln_res_segsum_kernel_mr<T, 4, 16>), grid, block, 0, st, (const T*)z, ldz, (const T*)e_old, lde, (const T*)gamma,
+                           (const T*)beta, eps, colptr, (T*)e_new, ldn, (T*)agg, ldagg, n_dst);
+      else if (quarter == 2)
+        hipLaunchKernelGGL((edge_ln_res_segsum_kernel_mr<T, 2, 32>), grid, block, 0, st, (const T*)z, ldz, (const T*)e_old, lde, (const T*)gamma,
+                           (const T*)beta, eps, colptr, (T*)e_new, ldn, (T*)agg, ldagg, n_dst);
+      else
+        hipLaunchKernelGGL((edge_ln_res_segsum_kernel_mr<T, 1, 64>), grid, block, 0, st, (const T*)z, ldz, (const T*)e_old, lde, (const T*)gamma,
+                           (const T*)beta, eps, colptr, (T*)e_new, ldn, (T*)agg, ldagg, n_dst);
+      return check_launch("edge_ln_res_segsum_kernel_mr");
+    }
+  }
 #define E_CASE(V, C)                                                                                                    \
   case V * 16 + C:                                                                                                      \
     hipLaunchKernelGGL((edge_ln_res_segsum_kernel<T, V, C>), grid, block, 0, st, (const T*)z, ldz, (const T*)e_old,     \

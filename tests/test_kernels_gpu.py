@@ -327,6 +327,30 @@ def test_edge_ln_residual_segment_sum(ops, dtype, D):
     assert_close(e2, z.float() + e_old.float(), dtype, "no LN")
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("with_beta", [True, False])
+def test_edge_ln_residual_segment_sum_ragged_512(ops, dtype, with_beta):
+    """The 512-channel 16-bit kernel works on two in-edges of a destination at a time (32 lanes each) and prefetches the next two:
+    segments of 0, 1, 2, 3 (odd tails), 5, 8 and 37 edges, the first and the last destination empty."""
+    D = 512
+    gen = torch.Generator().manual_seed(7)
+    deg = torch.tensor([0, 1, 2, 3, 5, 8, 37, 0, 4, 1, 0, 7, 2, 0])
+    n_dst, m = deg.numel(), int(deg.sum())
+    dst = torch.repeat_interleave(torch.arange(n_dst), deg)
+    ei = torch.stack([torch.randint(0, 23, (m,), generator=gen), dst])
+    z, e_old = (3 * torch.randn(m, D, generator=gen) + 1).to(dtype), torch.randn(m, D, generator=gen).to(dtype)
+    g = (1 + 0.2 * torch.randn(D, generator=gen)).to(dtype)
+    b = (0.1 * torch.randn(D, generator=gen)).to(dtype) if with_beta else None
+    csc = ops.build_csc(ei.to(DEV), (23, n_dst))
+    e_new, agg = ops.edge_ln_residual_segment_sum(z.to(DEV), e_old.to(DEV), g.to(DEV), None if b is None else b.to(DEV), 1e-5, csc)
+    want_e = F.layer_norm(z.float(), (D,), g.float(), None if b is None else b.float()) + e_old.float()
+    assert_close(e_new, want_e, dtype, "e_new")
+    want_agg = torch.zeros(n_dst, D).index_add_(0, dst, e_new.float().cpu())  # sum of what was stored, fp32
+    assert torch.equal(agg.float().cpu()[deg == 0], torch.zeros(int((deg == 0).sum()), D)), "empty segments must give zero rows"
+    assert torch.equal(agg.float().cpu()[deg == 1], e_new.float().cpu()[(deg[dst] == 1)]), "a one-edge segment is that edge's row"
+    assert_close(agg, want_agg, dtype, "agg")
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gather_rows(ops, dtype):
     gen = torch.Generator().manual_seed(1)
