@@ -71,8 +71,12 @@ class GraphConv(nn.Module):
             raise ValueError("GraphConv requires dst-sorted edges (edge features are carried between layers)")
         D = self.in_channels
         lin0 = self.edge_mlp.mlp[0]
-        w = lin0.weight  # [out, 3D] = [W_i | W_j | W_e]
-        if x_src is x_dst and not ops._needs_grad(x_src, w):
+        gated = self.edge_mlp.mlp_implementation != "mlp"
+        if gated:  # first layer = gating(gate_proj(cat)) * value_proj(cat): the same gather-add GEMM on the fused [gate; value] weight
+            w, bias0 = lin0.fused_weights()
+        else:
+            w, bias0 = lin0.weight, lin0.bias  # [out, 3D] = [W_i | W_j | W_e]
+        if x_src is x_dst and not gated and not ops._needs_grad(x_src, w):
             # processor (one node set), inference: [x W_i^T | x W_j^T] as ONE node-level GEMM with the stacked weight
             # [W_i; W_j] (rebuilt only when the parameter changes); the edge GEMM gathers from the two column halves
             p = ops.linear(x_dst, self._stacked_node_weight(w, D))
@@ -84,7 +88,9 @@ class GraphConv(nn.Module):
         if ops._needs_grad(p_dst, p_src, edge_attr, w):  # training: the adjoint of the two row gathers = segment sums
             rowptr, edge_ids, _ = get_reverse_csr(csc)
             seg = dict(seg1=(csc.colptr, None), seg2=(rowptr, edge_ids))
-        h = ops.linear(edge_attr, w[:, 2 * D:], lin0.bias, act="gelu", g1=p_dst, idx1=csc.dst, g2=p_src, idx2=csc.row, **seg)
+        h = ops.linear(edge_attr, w[:, 2 * D:], bias0, act=None if gated else "gelu", g1=p_dst, idx1=csc.dst, g2=p_src, idx2=csc.row, **seg)
+        if gated:
+            h = ops.glu(h, lin0.kind)
         z = self.edge_mlp(h, skip_first=True, skip_layer_norm=True)
         ln = self.edge_mlp.layer_norm
         edges_new, out = ops.edge_ln_residual_segment_sum(z, edge_attr, None if ln is None else ln.weight,

@@ -99,14 +99,14 @@ class MLP(nn.Module):
         return h.view(*x.shape[:-1], h.shape[-1])
 
     def _forward_gated(self, x, mods, x2, residual, skip_layer_norm, skip_first):
-        if skip_first:
-            raise NotImplementedError("GraphConv with a gated edge MLP is not supported (its first layer is a gather-add GEMM)")
         h = x.reshape(-1, x.shape[-1])
         wdt = mods[0].gate_proj.weight.dtype
         if h.dtype != wdt:
             h = h.to(wdt)
         ln = None if skip_layer_norm else self.layer_norm
         for n, m in enumerate(mods[:-1]):
+            if n == 0 and skip_first:  # GraphConv applied the first gated layer itself (gather-add GEMM + gating kernel)
+                continue
             h = m(h, x2=x2 if n == 0 else None)
         last = mods[-1]
         kw = {}

@@ -228,7 +228,7 @@ def gt_backward_mapper(p: Params, prefix: str, x_src: Tensor, x_dst: Tensor, edg
 # ------------------------------------------------------------------------------------------ GraphConv (GNN) path
 def gconv_processor_block(p: Params, prefix: str, x: Tensor, edge_attr: Tensor, edge_index: Tensor):
     """GraphConvProcessorBlock.forward (layers/block.py:361-395)."""
-    if prefix + ".emb_edges.mlp.0.weight" in p:
+    if prefix + ".emb_edges.mlp.0.weight" in p or prefix + ".emb_edges.mlp.0.gate_proj.weight" in p:
         edge_attr = mlp(p, prefix + ".emb_edges", edge_attr)
     out, edges_new = graph_conv(p, prefix + ".conv", x, x, edge_attr, edge_index)
     nodes_new = mlp(p, prefix + ".node_mlp", torch.cat([x, out], dim=1)) + x

@@ -517,6 +517,43 @@ def gen_sharding():
     save("sharding.pt", out)
 
 
+def gen_gnn_gated():
+    """GraphConv blocks with a gated edge / node MLP (`mlp_implementation` = swiglu, geglu: layers/conv.py:29-81 builds its edge MLP with
+    it, layers/block.py:286-345 the node MLP and the edge embedding), forward and the reference's own autograd."""
+    gen = torch.Generator().manual_seed(2468)
+    lk = load_layer_kernels()
+    out = {}
+    torch.manual_seed(13)
+    C = 32
+    N, M = 50, 260
+    ei = _rand_graph(gen, N, N, M, (9,))
+    for kind, edge_dim, extra in (("swiglu", None, 0), ("geglu", 5, 1)):
+        blk = GraphConvProcessorBlock(in_channels=C, out_channels=C, num_chunks=1, mlp_extra_layers=extra, layer_kernels=lk, edge_dim=edge_dim,
+                                      mlp_implementation=kind).eval()
+        _randomise(blk, gen)
+        x = torch.randn(N, C, generator=gen).requires_grad_(True)
+        ea = torch.randn(M, edge_dim or C, generator=gen).requires_grad_(True)
+        y, e2 = blk(x, ea, ei, GraphShardInfo(nodes=[N], edges=[M]), None, size=(N, N))
+        wy, we = torch.randn(y.shape, generator=gen), torch.randn(e2.shape, generator=gen)
+        ((y * wy).sum() + (e2 * we).sum()).backward()
+        out[f"proc_{kind}"] = dict(cfg=dict(in_channels=C, out_channels=C, num_chunks=1, mlp_extra_layers=extra, edge_dim=edge_dim, mlp_implementation=kind),
+                                   params=_sd(blk), x=x.detach(), edge_attr=ea.detach(), edge_index=ei, out=y.detach(), edges_out=e2.detach(),
+                                   w_out=wy, w_edges=we, grad_x=x.grad.clone(), grad_edge_attr=ea.grad.clone(),
+                                   grads={k: v.grad.clone() for k, v in blk.named_parameters()})
+    Ns, Nd, Mm = 45, 30, 200
+    eim = _rand_graph(gen, Ns, Nd, Mm)
+    blk = GraphConvMapperBlock(in_channels=C, out_channels=C, num_chunks=1, mlp_extra_layers=0, update_src_nodes=True, layer_kernels=lk, edge_dim=None,
+                               mlp_implementation="swiglu").eval()
+    _randomise(blk, gen)
+    xs, xd, ea = torch.randn(Ns, C, generator=gen), torch.randn(Nd, C, generator=gen), torch.randn(Mm, C, generator=gen)
+    with torch.no_grad():
+        (ys, yd), e2 = blk((xs, xd), ea, eim, BipartiteGraphShardInfo(src_nodes=[Ns], dst_nodes=[Nd], edges=[Mm]), None, size=(Ns, Nd))
+    out["map_swiglu"] = dict(cfg=dict(in_channels=C, out_channels=C, num_chunks=1, mlp_extra_layers=0, update_src_nodes=True, edge_dim=None,
+                                      mlp_implementation="swiglu"),
+                             params=_sd(blk), x_src=xs, x_dst=xd, edge_attr=ea, edge_index=eim, out_src=ys, out_dst=yd, edges_out=e2)
+    save("gnn_gated.pt", out)
+
+
 # ----------------------------------------------------------------------------------- scope row f3 variants
 def gen_variants():
     """Gated MLP variants (layers/mlp.py:25-59) and ConditionalLayerNorm (layers/normalization.py:34-94)."""
@@ -679,7 +716,7 @@ def gen_edges():
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ["conv", "blocks", "blocks_train", "proc", "model", "batch", "grads", "sharding", "variants", "edges"]
+    which = sys.argv[1:] or ["conv", "blocks", "blocks_train", "proc", "model", "batch", "grads", "sharding", "variants", "gnn_gated", "edges"]
     if "conv" in which:
         gen_conv()
     if "blocks" in which:
@@ -698,5 +735,7 @@ if __name__ == "__main__":
         gen_sharding()
     if "variants" in which:
         gen_variants()
+    if "gnn_gated" in which:
+        gen_gnn_gated()
     if "edges" in which:
         gen_edges()

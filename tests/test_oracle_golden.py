@@ -189,6 +189,33 @@ def test_gated_and_conditional_blocks_match_reference(golden):
     assert float((got - c["out"]).abs().max()) < 2e-5
 
 
+def test_gnn_blocks_with_gated_mlps_forward_and_autograd(golden):
+    """GraphConv blocks whose edge / node MLPs (and edge embedding) are gated (fixture gnn_gated.pt, generated from the reference):
+    the oracle's forward against the reference's outputs, its torch autograd against the reference's own gradients."""
+    g = golden("gnn_gated.pt")
+    for kind in ("swiglu", "geglu"):
+        c = g[f"proc_{kind}"]
+        p = {"." + k: v.clone().requires_grad_(True) for k, v in c["params"].items()}
+        p["__mlp_implementation__"] = kind
+        x, ea = c["x"].clone().requires_grad_(True), c["edge_attr"].clone().requires_grad_(True)
+        y, e = O.gconv_processor_block(p, "", x, ea, c["edge_index"])
+        close(y.detach(), c["out"])
+        close(e.detach(), c["edges_out"])
+        ((y * c["w_out"]).sum() + (e * c["w_edges"]).sum()).backward()
+        close(x.grad, c["grad_x"], 2e-5)
+        close(ea.grad, c["grad_edge_attr"], 2e-5)
+        assert len(c["grads"]) >= 12
+        for k, gr in c["grads"].items():
+            close(p["." + k].grad, gr, 2e-5 * max(1.0, float(gr.abs().max())))
+    c = g["map_swiglu"]
+    p = {"." + k: v for k, v in c["params"].items()}
+    p["__mlp_implementation__"] = "swiglu"
+    (ys, yd), e = O.gconv_mapper_block(p, "", c["x_src"], c["x_dst"], c["edge_attr"], c["edge_index"], True)
+    close(ys, c["out_src"])
+    close(yd, c["out_dst"])
+    close(e, c["edges_out"])
+
+
 def test_boundings_match_reference(golden):
     c = golden("variants.pt")["bounding"]
     got = O.apply_boundings(c["x"], c["specs"], c["name_to_index"], c["statistics"], c["name_to_index_stats"])
