@@ -143,6 +143,10 @@ struct WLayout {
 // one per-lane vector load instead of scalar loads - lived here in commits 99a7806..49471db: parity-green, 8 of ~45 VALU slots per
 // edge fewer, and SLOWER on MI355X, 26.7 -> 29.7 us at res 5 and 91.8 -> 95.2 us at res 6 (profiles/r03_attention_fsplit_ab.txt):
 // the third vector-memory instruction per edge costs more than the VALU slots it frees.  Removed again.)
+// (Also tried, round 3: the PREFIX of a wave's next destination - work-order position and colptr words as scalar loads, the source ids
+// of its first 64 in-edges by LDS-DMA into a wave-private slot, so that no register is held during the flight - requested while the
+// current destination is worked on.  Parity-green; 96 VGPRs + 2 spilled at 5 waves per SIMD (100 without the cap = 4 waves), and
+// the O96 forward went from 2.99-3.00 to 3.02-3.03 ms on the same box in two placements of the request.  Not kept.)
 template <typename T, int VEC, int LPH, int FE_PAD, bool KVADJ>
 __global__ __launch_bounds__(64 * kWavesPerBlock, 16 / kWavesPerBlock) void gt_attn_fused_edge_fwd_kernel(
     const T* __restrict__ q, int64_t ldq, const T* __restrict__ k, int64_t ldk, const T* __restrict__ v, int64_t ldv,
