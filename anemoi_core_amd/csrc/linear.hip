@@ -355,21 +355,41 @@ constexpr int kEpiStores = 8;
 // stages them in LDS once per tile; with 64-row tiles on a few thousand rows the 8 lanes that share a row re-read its 64
 // bytes from L1 instead).  Same summation order as the LDS variant: bit-identical statistics.
 template <typename T>
-__device__ __forceinline__ void ln_row_stats(const LinArgs& a, int m, float& mu, float& rs) {
-  m = min(m, a.n_rows + a.tail_rows - 1);
+__device__ __forceinline__ void ln_row_stats(const LinArgs& a, int m, int cp, float& mu, float& rs) {
+  if (m >= a.n_rows + a.tail_rows) {  // a row of a ragged last tile that does not exist: never stored, nothing to fetch for it
+    mu = 0.f;
+    rs = 1.f;
+    return;
+  }
   const float* st = a.stats_in + (int64_t)m * a.ln_strips * 2;
   float s1 = 0.f, s2 = 0.f;
-  if (m >= a.ln_tail_begin) {  // a producer's peeled tail row: sums of the stored row itself (strip by strip, like the producer)
+  if (m >= a.ln_tail_begin) {
+    // a producer's peeled tail row: sums of the stored row itself, shared out over the 8 lanes that hold the row in the epilogue
+    // (cp = lane & 7; all eight are here together: same m) - eight loads in flight per lane and one butterfly, where one lane walking
+    // the row load by load took 60 us of a 9 us kernel (the reason the fold looked slow on small meshes)
     const T* xr = (const T*)a.x + (int64_t)m * a.ldx;
-    for (int k = 0; k < a.ln_D; k += 8) {
-      float xv[8];
-      load_vec<T, 8>(xr + k, xv);
+    for (int k0 = 0; k0 < a.ln_D; k0 += 512) {
+      float xv[8][8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        s1 += xv[i];
-        s2 = fmaf(xv[i], xv[i], s2);
+      for (int j = 0; j < 8; ++j) {
+        const int k = k0 + j * 64 + cp * 8;
+        if (k < a.ln_D) {
+          load_vec<T, 8>(xr + k, xv[j]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) xv[j][i] = 0.f;
+        }
       }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          s1 += xv[j][i];
+          s2 = fmaf(xv[j][i], xv[j][i], s2);
+        }
     }
+    s1 = group_sum<8>(s1);
+    s2 = group_sum<8>(s2);
   } else if (a.ln_strips == 8) {
     f32x4 v[4];
 #pragma unroll
@@ -407,11 +427,27 @@ struct GatherIdx {
 // an epilogue.  Here: no predicates, one 64-bit base per lane + uniform row offsets, and NO waits between a band's LDS writes
 // and its read-back (a wave's LDS instructions execute in order, so the read-back sees the writes; only the compiler has
 // to be kept from reordering them) - the transposition of band mi+1 overlaps the arithmetic and stores of band mi.
-template <typename T, int EPI, int MI>
+template <typename T, int EPI, int MI, bool LDS_STATS = false>
 __device__ __forceinline__ void mfma_epilogue_fast(const LinArgs& a, f32x4 (&acc)[MI][4], int m0, int n0, int wr, int wc, int lane,
                                                    unsigned char* epi, const float* ln_rows = nullptr, const GatherIdx<MI>* gidx = nullptr) {
   using V8 = Vec<T, 8>;
   const int cp = lane & 7;
+  // LayerNorm fold without the per-tile LDS table (the 64-row kernels): at D = 512 the 8 lanes that hold a row in this epilogue
+  // each fetch ONE of its 8 strip sums, for all 2 * MI rows of the lane up front (one latency instead of one per 16-row band: the
+  // band loop below used to wait ~1 us eight times), and a butterfly over the 8 lanes completes them where they are used.
+  [[maybe_unused]] f32x2 ln_part[MI][2];
+  [[maybe_unused]] const bool ln_strip_per_lane = a.ln_strips == 8;
+  if constexpr ((EPI & EPI_LNFOLD) != 0 && !LDS_STATS) {
+    if (ln_strip_per_lane) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int m = min(m0 + wr * (16 * MI) + (lane >> 3) + mi * 16 + it * 8, a.n_rows + a.tail_rows - 1);
+          ln_part[mi][it] = *reinterpret_cast<const f32x2*>(a.stats_in + ((int64_t)m * 8 + cp) * 2);
+        }
+    }
+  }
   const int nc = n0 + wc * 64 + cp * 8;
   const int mrow0 = m0 + wr * (16 * MI) + (lane >> 3);
   float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -498,11 +534,19 @@ __device__ __forceinline__ void mfma_epilogue_fast(const LinArgs& a, f32x4 (&acc
       float vv[8];
       if constexpr ((EPI & EPI_LNFOLD) != 0) {  // mean / rstd of the tile's rows sit in LDS (written at the start of the tile)
         f32x2 mr;
-        if (ln_rows != nullptr) {
+        if constexpr (LDS_STATS) {
           mr = *reinterpret_cast<const f32x2*>(ln_rows + 2 * (wr * (16 * MI) + (lane >> 3) + mi * 16 + it * 8));
         } else {
+          const int m = m0 + wr * (16 * MI) + (lane >> 3) + mi * 16 + it * 8;
           float mu_, rs_;
-          ln_row_stats<T>(a, m0 + wr * (16 * MI) + (lane >> 3) + mi * 16 + it * 8, mu_, rs_);
+          if (ln_strip_per_lane && m < a.ln_tail_begin) {  // (the 8 lanes of a row agree on both conditions)
+            const float s1 = group_sum<8>(ln_part[mi][it][0]), s2 = group_sum<8>(ln_part[mi][it][1]);
+            const float inv = 1.0f / (float)a.ln_D;
+            mu_ = s1 * inv;
+            rs_ = rsqrtf(fmaxf(s2 * inv - mu_ * mu_, 0.f) + a.ln_eps);
+          } else {
+            ln_row_stats<T>(a, m, cp, mu_, rs_);
+          }
           mr = f32x2{mu_, rs_};
         }
 #pragma unroll
@@ -548,13 +592,13 @@ __device__ __forceinline__ void mfma_epilogue_fast(const LinArgs& a, f32x4 (&acc
   }
 }
 
-template <typename T, int EPI, int MI = 4>
+template <typename T, int EPI, int MI = 4, bool LDS_STATS = false>
 __device__ __forceinline__ void mfma_epilogue_band(const LinArgs& a, f32x4 (&acc)[MI][4], int m0, int n0, int wr, int wc,
                                                    int lane, unsigned char* epi, bool interior, const float* ln_rows = nullptr,
                                                    const GatherIdx<MI>* gidx = nullptr) {
   if constexpr ((EPI & ~(EPI_RES | EPI_GATHER | EPI_GELU | EPI_STATS | EPI_LNFOLD)) == 0) {
     if (interior && !a.f32_atomic && a.fast_epi) {  // wave-uniform: one branch per tile
-      mfma_epilogue_fast<T, EPI, MI>(a, acc, m0, n0, wr, wc, lane, epi, ln_rows, gidx);
+      mfma_epilogue_fast<T, EPI, MI, LDS_STATS>(a, acc, m0, n0, wr, wc, lane, epi, ln_rows, gidx);
       return;
     }
   }
@@ -609,7 +653,7 @@ __device__ __forceinline__ void mfma_epilogue_band(const LinArgs& a, f32x4 (&acc
           ln_mu[it] = ln_rows[2 * rl];
           ln_rs[it] = ln_rows[2 * rl + 1];
         } else {
-          ln_row_stats<T>(a, m0 + rl, ln_mu[it], ln_rs[it]);
+          ln_row_stats<T>(a, m0 + rl, cp, ln_mu[it], ln_rs[it]);
         }
       }
     }
@@ -1369,8 +1413,8 @@ __global__ __launch_bounds__(512, 1) void linear_mfma_bigtile_kernel(LinArgs a, 
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     const bool interior = (m0 + TBM <= a.n_rows) && (n0 + TBN <= a.O);
-    mfma_epilogue_band<T, EPI, MI>(a, acc, m0, n0, wr, wc, lane, smem + ((g - 1) % STAGES) * kStageBytes + wave * 4096, interior, ln_rows,
-                                   gidx_p);
+    mfma_epilogue_band<T, EPI, MI, true>(a, acc, m0, n0, wr, wc, lane, smem + ((g - 1) % STAGES) * kStageBytes + wave * 4096, interior, ln_rows,
+                                         gidx_p);
     counted_stores = interior && (EPI & EPI_PRE) == 0;  // exactly kStores stores per wave, issued after the DMAs of the next K-tile
   }
 }
@@ -1629,6 +1673,9 @@ static int launch_lnfold_consumer(const LinArgs& a, hipStream_t st) {
         return gelu ? launch_splitwave<T, EPI_LNFOLD | EPI_GELU>(a, st) : launch_splitwave<T, EPI_LNFOLD>(a, st);
       return gelu ? launch_persistent_wm<T, EPI_LNFOLD | EPI_GELU, 1, false, 2>(a, st) : launch_persistent_wm<T, EPI_LNFOLD, 1, false, 2>(a, st);
     }
+    // in between (a few thousand rows: the res-4 mesh, 2 562): the 192 x 128 kernel of the plain GEMM of the shape, lock-step schedule (the ping-pong one spills 80 registers with the fold)
+    const bool gelu = a.act == ANEMOI_ACT_GELU;
+    return gelu ? launch_persistent_wm<T, EPI_LNFOLD | EPI_GELU, 3, false, 2>(a, st) : launch_persistent_wm<T, EPI_LNFOLD, 3, false, 2>(a, st);
   }
   // 160-row tiles also beyond one round (40 320-row mapper GEMMs): the fold's epilogue has no registers to spare at 160
   // accumulators per lane (MI = 10: +7 us on [40320 x 512] -> 1024), at 80 it is free; ANEMOI_LNFOLD_MI5=0 restores the rule

@@ -34,10 +34,11 @@ ANEMOI_DEBUG_SHARDING = os.environ.get("ANEMOI_DEBUG_SHARDING", "") != ""
 # time in same-box A/Bs; it was neutral with the generic epilogue: DESIGN.md section 5).  ANEMOI_LN_FOLD=0: LayerNorm + GEMM.
 _FUSED_EDGE_BWD = os.environ.get("ANEMOI_FUSED_EDGE_BWD", "1") == "1"  # 0: train through the materialised-E op (reference op boundary)
 _LN_FOLD = os.environ.get("ANEMOI_LN_FOLD", "1") == "1"
-# ... for tall operands only: the fold's consumer is the big-tile kernel (160 x 256 tiles), which leaves most of the chip idle
-# when there are few rows - measured per forward: 642 hidden nodes 1.72 ms without / 2.53 ms with the fold, 2 562 nodes 1.96 /
-# 2.05 ms, 10 242 nodes 3.09 / 3.00 ms.  Below this row count (one rank's rows of a sharded mesh, small meshes): LayerNorm + GEMM.
-_LN_FOLD_MIN_ROWS = int(os.environ.get("ANEMOI_LN_FOLD_MIN_ROWS", "4096"))
+# Below ~4k rows the fold's consumer runs in the 64 x 128 / 192 x 128 kernels (statistics from the producer's strip sums, read through
+# L1).  Per forward, LayerNorm + GEMM / folded: 642 hidden nodes 1.75 / 1.68 ms, 2 562 nodes 1.94 / 1.91 ms, one rank's 1 281 rows of an
+# 8-way sharded mesh 1.50 / 1.50 ms, 10 242 nodes 3.09 / 3.00 ms.  (Until late round 3 the small-tile consumer lost 60 us per launch to
+# ONE lane walking a tail row load by load, which had made the fold look slower below 4 096 rows.)  Not below 512 rows: not measured.
+_LN_FOLD_MIN_ROWS = int(os.environ.get("ANEMOI_LN_FOLD_MIN_ROWS", "512"))
 
 
 _IDENTITY: dict = {}

@@ -300,10 +300,10 @@ def test_layer_kernels_plugins_run_standalone(dtype):
 
 
 def test_layernorm_fold_is_gated_by_row_count_and_equals_unfused(golden, monkeypatch):
-    """The LayerNorm fold (statistics from the producing GEMM, normalisation in the consuming big-tile GEMM) is taken for tall
-    operands only (layers/block.py: _LN_FOLD_MIN_ROWS; it is slower below a few thousand rows).  Forced on for the tiny
-    fixture model in bf16 it must agree with the unfused path at the bf16 rounding level, and by default it must not be
-    taken at this size (bit-equal to ANEMOI_LN_FOLD off)."""
+    """The LayerNorm fold (statistics from the producing GEMM, normalisation in the consuming GEMM's epilogue) is taken for operands of
+    at least layers/block.py:_LN_FOLD_MIN_ROWS rows.  With the threshold above the tiny fixture model's 642 hidden nodes it must not
+    be taken (bit-equal to ANEMOI_LN_FOLD off); forced on (the 64-row consumer kernels, incl. the two tail rows beyond 640 whose
+    statistics come from the rows themselves) it must agree with the unfused path at the bf16 rounding level."""
     from anemoi_core_amd.layers import block as B
 
     case = golden("model_tiny.pt")["gt"]
@@ -316,12 +316,14 @@ def test_layernorm_fold_is_gated_by_row_count_and_equals_unfused(golden, monkeyp
         with torch.inference_mode():
             return model(x)["data"].float()
 
-    default = run()
+    monkeypatch.setattr(B, "_LN_FOLD_MIN_ROWS", 4096)
+    gated = run()
     monkeypatch.setattr(B, "_LN_FOLD", False)
     unfused = run()
-    assert torch.equal(default, unfused)  # 642 hidden nodes: below the row threshold, the fold is not taken
+    assert torch.equal(gated, unfused)  # 642 hidden nodes: below that row threshold, the fold is not taken
     monkeypatch.setattr(B, "_LN_FOLD", True)
     monkeypatch.setattr(B, "_LN_FOLD_MIN_ROWS", 0)
     folded = run()
+    assert not torch.equal(folded, unfused)  # ... and here it is
     s = max(1.0, float(unfused.abs().max()))
     assert float((folded - unfused).abs().max()) <= 3e-2 * s and float((folded - unfused).abs().mean()) <= 5e-3
