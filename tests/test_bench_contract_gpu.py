@@ -33,8 +33,11 @@ def test_default_bench_line_contract():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0.05 < rf["frac"] < 1.0
     assert rf["frac"] <= rf["frac_overhead_subtracted"]  # the raw brackets are the lower bound
     assert rf["traffic"] is None or rf["traffic"] > 0.5 * rf["algorithmic_bytes_per_launch"]
-    # the dominant family's time is part of the step, and its algorithmic work cannot beat the peaks
-    assert rf["calls_per_step"] * rf["avg_launch_us"] <= 1.1 * d["ms_per_step"] * 1e3
+    # the dominant family's time is part of the step.  `avg_launch_us` is the RAW bracket (kernel + the gaps to its two markers, which
+    # grow when the box's host cannot keep the launch queue backed up): compared after the calibrated marker overhead is taken off, and
+    # with room for a slow host - the claim checked is "a part of the step", not a timing
+    net_us = rf["calls_per_step"] * max(rf["avg_launch_us"] - rf["bracket_overhead_us"], 0.0)
+    assert net_us <= 1.25 * d["ms_per_step"] * 1e3, (net_us, d["ms_per_step"], rf)
     gs = rf["gather_scatter"]
     assert gs["bound"] == "hbm" and 0.05 < gs["frac"] < 1.0
     cpu = d["cpu_baseline"]
