@@ -19,7 +19,7 @@ LIBPATH = os.path.join(LIBDIR, "libanemoi_hip.so")
 EXT_PATH = os.path.join(LIBDIR, "libanemoi_torch.so")
 INCLUDE = os.path.join(REPO, "include")
 
-SOURCES = ["lib.cpp", "gt_attention.hip", "gt_attention_bwd.hip", "rowwise.hip", "rowwise_bwd.hip", "linear.hip", "wgrad.hip", "peer.hip"]
+SOURCES = ["lib.cpp", "gt_attention.hip", "gt_attention_bwd.hip", "rowwise.hip", "rowwise_bwd.hip", "linear.hip", "wgrad.hip", "peer.hip", "gt_chain.hip"]
 ARCH = "gfx950"
 
 
@@ -73,7 +73,14 @@ def build_torch_extension(hipcc: str, force: bool = False, verbose: bool = True)
     import torch
 
     src = os.path.join(CSRC, "torch_binding.cpp")
-    if not force and _newer(EXT_PATH, [src, os.path.join(INCLUDE, "anemoi_hip.h"), LIBPATH]):
+    # the extension links against the libtorch of the interpreter that built it: a stamp with torch's version next to the .so makes
+    # a torch upgrade a rebuild instead of an undefined-symbol error at load time
+    stamp = EXT_PATH + ".torch_version"
+    stamped = open(stamp).read().strip() if os.path.exists(stamp) else None
+    # (a .so without a stamp is one built before the stamp existed, by this image's torch: adopt it)
+    if not force and stamped in (None, torch.__version__) and _newer(EXT_PATH, [src, os.path.join(INCLUDE, "anemoi_hip.h"), LIBPATH]):
+        if stamped is None:
+            open(stamp, "w").write(torch.__version__)
         return EXT_PATH
     troot = os.path.dirname(torch.__file__)
     rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
@@ -85,6 +92,7 @@ def build_torch_extension(hipcc: str, force: bool = False, verbose: bool = True)
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    open(stamp, "w").write(torch.__version__)
     return EXT_PATH
 
 

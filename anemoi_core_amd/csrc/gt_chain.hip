@@ -1,0 +1,637 @@
+// Row-resident layer chain for gfx950: everything of a GraphTransformer block that is LOCAL TO A NODE ROW, in ONE launch -
+//
+//     x1 = attn W_p^T + b_p + x                      (projection + skip,            layers/block.py:1263-1266 of the reference)
+//     h  = GELU(LN_mlp(x1) W_1^T + b_1)               (node_dst_mlp, first Linear,   layers/block.py:1268-1271, layers/mlp.py:158-169)
+//     x2 = h W_2^T + b_2 + x1 [+ latent skip]        (second Linear + skip;         encoder_processor_decoder.py:295-296 for the skip)
+//     qkvs' = LN_attn'(x2) [W_q; W_k; W_v; W_s]'^T + b' (the NEXT block's fused projections, layers/block.py:1237-1245)
+//
+// instead of four GEMM launches (each with its launch, cold first K-tile, epilogue and write tail: half of their time at
+// 10 242 rows) plus the LayerNorm statistics hand-off between them.
+//
+// Structure.  A workgroup (8 waves, one per CU) owns a panel of <= 48 node rows for the whole chain.  The panel's activations
+// never leave the CU: three [48][512] 16-bit buffers in LDS (A operand of the running GEMM, the next A operand, the residual),
+// 16-byte slots XOR-swizzled by the row so that both the 8-byte epilogue writes and the fragment ds_read_b128 are conflict-free.
+// What streams is the WEIGHTS: every wave owns a 64-column slab of each GEMM's output and reads its B fragments straight from
+// L2 into registers - the weights are pre-packed fragment-major on the host (ops.pack_weight_frag: one contiguous KiB per
+// 16 columns x 32 k), so a fragment is ONE fully coalesced global_load_dwordx4 and never touches LDS.  A register ring of
+// 4 K-steps x 4 fragments (16 loads = 16 KiB per wave, 128 KiB per CU in flight) covers the L2 latency; no barrier inside a
+// 16-step segment, the two waves of a SIMD interleave MFMA and load issue by themselves.  tools/weight_stream_probe.hip
+// measured this loop on MI355X: 6.5 MiB of weights per CU and layer at 97 GB/s per CU next to 1.2 PFLOP/s of MFMAs = 70 us
+// per layer for all four GEMMs, against 112 us for the four launches.  The hidden activations [rows x 2048] never exist:
+// MLP-1 is produced in 512-column chunks that are consumed at once as K-chunks of MLP-2 (two accumulator sets in registers).
+// LayerNorm is the real thing (fp32 statistics of the rounded 16-bit rows, per-wave (mean, M2) partials merged with Chan's
+// formula: no E[x^2] - mean^2 cancellation), its output rounded to the model dtype as the reference's autocast does.
+#include "common.h"
+
+namespace anemoi {
+
+using frag8 = __attribute__((ext_vector_type(8))) short;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+template <typename T>
+__device__ __forceinline__ f32x4 cmfma(frag8 a, frag8 b, f32x4 c);
+template <>
+__device__ __forceinline__ f32x4 cmfma<bf16_t>(frag8 a, frag8 b, f32x4 c) {
+  using bf8 = __attribute__((ext_vector_type(8))) __bf16;
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x4 cmfma<f16_t>(frag8 a, frag8 b, f32x4 c) {
+  using h8 = __attribute__((ext_vector_type(8))) _Float16;
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+}
+
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+
+// four 16-bit values travel as two dwords (plain registers: a struct of four halves tempts the compiler into scratch)
+template <typename T>
+__device__ __forceinline__ void unpack4(u32x2 p, float (&o)[4]);
+template <>
+__device__ __forceinline__ void unpack4<bf16_t>(u32x2 p, float (&o)[4]) {
+  o[0] = __uint_as_float(p[0] << 16);
+  o[1] = __uint_as_float(p[0] & 0xffff0000u);
+  o[2] = __uint_as_float(p[1] << 16);
+  o[3] = __uint_as_float(p[1] & 0xffff0000u);
+}
+template <>
+__device__ __forceinline__ void unpack4<f16_t>(u32x2 p, float (&o)[4]) {
+  // (element-wise through 16-bit integers: with a bit_cast of each dword to a 2-vector of halves hipcc 7.2 dropped the second
+  // dword and converted the first one twice - found by the f16 parity tests)
+  const unsigned lo = p[0], hi = p[1];
+  o[0] = (float)__builtin_bit_cast(_Float16, (unsigned short)(lo & 0xffffu));
+  o[1] = (float)__builtin_bit_cast(_Float16, (unsigned short)(lo >> 16));
+  o[2] = (float)__builtin_bit_cast(_Float16, (unsigned short)(hi & 0xffffu));
+  o[3] = (float)__builtin_bit_cast(_Float16, (unsigned short)(hi >> 16));
+}
+template <typename T>
+__device__ __forceinline__ u32x2 pack4(const float (&v)[4]) {
+  const T a = from_float<T>(v[0]), b = from_float<T>(v[1]), c = from_float<T>(v[2]), d = from_float<T>(v[3]);
+  return u32x2{(unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16),
+               (unsigned)__builtin_bit_cast(unsigned short, c) | ((unsigned)__builtin_bit_cast(unsigned short, d) << 16)};
+}
+// this lane's 4 values of each of the wave's 4 column blocks of a parameter vector (bias, gamma, beta), loaded EARLY - before
+// the GEMM whose epilogue uses them: vmcnt retires in order, so a load issued behind the weight ring's prefetches could only be
+// waited for together with them (a full L2 latency exposed at every epilogue)
+template <typename T>
+__device__ __forceinline__ void load_cols(const T* __restrict__ p, int wave, int g, u32x2 (&o)[4]) {
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) o[ni] = *reinterpret_cast<const u32x2*>(p + wave * 64 + ni * 16 + g * 4);
+}
+
+constexpr int kCh = 512;                    // channels of the residual stream (8 waves x 64 columns)
+constexpr int kPanel = 48;                  // panel rows (3 MFMA row bands)
+constexpr int kRowBytes = kCh * 2;          // one 16-bit row in LDS
+constexpr int kBufBytes = kPanel * kRowBytes;
+constexpr int kSlab = 16 * 4096;            // one segment of a wave's weight stream: 16 K-steps x (4 fragments x 1 KiB)
+constexpr int kRedOff = 3 * kBufBytes;      // [48][8][2] fp32 LayerNorm partials
+constexpr int kChainSmem = kRedOff + kPanel * 8 * 2 * 4;
+constexpr int kTlOff = kChainSmem;          // instrumented instantiation only: [8 waves][kTlSlots] stamps, copied out at the end
+
+struct ChainArgs {
+  const void* attn;  int64_t ld_attn;       // [n_rows, 512]  attention output + self term
+  const void* xres;  int64_t ld_x;          // [n_rows, 512]  the block's input (skip)
+  const char* wp;    const void* bp;        // projection, fragment-major / [512]
+  const void* ln1_g; const void* ln1_b; float ln1_eps;
+  const char* w1;    const void* b1;  int hc;   // MLP-1 [hidden, 512] fragment-major, hidden = 512 hc
+  const char* w2;    const void* b2;        // MLP-2 [512, hidden] fragment-major
+  const void* extra; int64_t ld_extra;      // optional second residual of x2
+  void* xout;        int64_t ld_out;        // [n_rows, 512]  x2
+  const void* lnq_g; const void* lnq_b; float lnq_eps;
+  const char* wq;    const void* bq;  int qc;   // trailing projection [512 qc, 512] fragment-major; qc = 0: none
+  void* qout;        int64_t ld_q;          // [n_rows, 512 qc]
+  int n_rows, rows_per_tile, n_tiles;
+  int prio_young;                           // experiment: s_setprio of waves 4-7 (0: none)
+  int dbg;                                  // experiment (timing only, results are garbage): bit 0 skip the MLP epilogues, 1 skip LayerNorms, 2 skip q stores, 3 skip x1/x2 epilogues
+  unsigned long long* timeline;             // developer aid (TL instantiation only): [workgroups][8 waves][kTlSlots] s_memtime stamps
+};
+constexpr int kTlSlots = 48;
+
+// a pointer the compiler must keep in scalar registers (it is wave-uniform by construction): the loads then take the
+// "SGPR base + 32-bit VGPR offset + immediate" form instead of a 64-bit VGPR address per fragment group
+typedef const __attribute__((address_space(1))) char* gptr_t;  // a GLOBAL pointer: an integer round trip must not degrade the loads to flat_load
+__device__ __forceinline__ gptr_t uniform_ptr(const char* p) {
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return reinterpret_cast<gptr_t>(((uint64_t)hi << 32) | lo);
+}
+typedef const __attribute__((address_space(1))) frag8* gfrag_t;
+
+// 16 K-steps (K = 512) of this wave's 48 x 64 tile: A fragments from the swizzled LDS panel, B fragments from the register
+// ring (filled 4 K-steps ago), the ring slot refilled right behind its MFMAs with the fragments of 4 K-steps ahead - of this
+// segment or, in its last group, of the NEXT segment (`nxt`), so the stream never drains across the epilogues.
+// sched_barrier pins the issue order: left alone the scheduler sinks all 16 loads to the end of the loop body and the
+// waitcnt pass then drains the queue at the top (measured with tools/weight_stream_probe.hip).
+template <typename T>
+__device__ __forceinline__ void gemm_seg(const unsigned char* abuf, int lane, frag8 (&bq)[4][4], const char* cur, const char* nxt,
+                                         uint32_t loff, f32x4 (&acc)[3][4]) {  // cur / nxt: wave-uniform (SGPR) bases, loff = lane * 16
+  asm volatile("" : "+v"(lane));
+  const int x = lane & 15, ks = lane >> 4;
+  const unsigned char* arow = abuf + x * kRowBytes;
+  // the A fragments of K-step st+1 are requested BEFORE the MFMAs of step st (12 more registers): with one set of fragment
+  // registers every step exposed three LDS round trips in front of its MFMAs (a third of a segment's time, in-kernel timeline)
+  frag8 fa[3];
+#pragma unroll
+  for (int mi = 0; mi < 3; ++mi) fa[mi] = *reinterpret_cast<const frag8*>(arow + mi * 16 * kRowBytes + ((ks ^ x) << 4));
+#pragma unroll 1
+  for (int q = 0; q < 4; ++q) {
+    const char* pfg = q < 3 ? cur + (q + 1) * 16384 : nxt;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int st = q * 4 + j;
+      const int sn = st < 15 ? st + 1 : 15;  // (the last step re-reads its own fragments: no branch in the stream)
+      frag8 fn[3];
+#pragma unroll
+      for (int mi = 0; mi < 3; ++mi) fn[mi] = *reinterpret_cast<const frag8*>(arow + mi * 16 * kRowBytes + (((sn * 4 + ks) ^ x) << 4));
+      __builtin_amdgcn_sched_barrier(0);  // (else the scheduler sinks these reads behind the MFMAs, into the registers they free)
+#pragma unroll
+      for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = cmfma<T>(bq[j][ni], fa[mi], acc[mi][ni]);  // D^T: lane = row x, 4 consecutive columns
+      {
+        const gptr_t pj = uniform_ptr(pfg + j * 4096);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) bq[j][ni] = *reinterpret_cast<gfrag_t>(pj + loff + ni * 1024);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 3; ++mi) fa[mi] = fn[mi];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+__device__ __forceinline__ void lds_barrier() {  // LDS writes of all waves visible; global loads in flight (the weight ring) stay in flight
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// Per-lane coordinates, re-derived from an OPAQUE copy of the lane id at the start of every phase: the epilogues' address
+// arithmetic (a few dozen registers of LDS / global offsets per phase) is invariant over the panel loop, LICM hoists all of it
+// to the kernel's entry, and the allocator then spills it around the GEMM segments (scratch reloads retire in order behind the
+// weight ring: every reload would drain it).  Behind the barrier the values are computed where they are used.
+struct LaneCtx {
+  int x, g;
+  int coff[4];  // LDS byte offset (inside a panel row) of this lane's 4 columns of column block ni: slot = wave*8 + ni*2 + (g>>1), swizzled by the row
+};
+__device__ __forceinline__ LaneCtx lane_ctx(int lane, int wave) {
+  asm volatile("" : "+v"(lane));
+  LaneCtx c;
+  c.x = lane & 15;
+  c.g = lane >> 4;
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) c.coff[ni] = (((wave * 8 + ni * 2 + (c.g >> 1)) ^ c.x) << 4) + (c.g & 1) * 8;
+  return c;
+}
+
+template <typename T>
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[3][4]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// LayerNorm of the panel rows held as v[mi][ni][r] (fp32 images of the ROUNDED row values; lane = row mi*16 + x, columns
+// wave*64 + ni*16 + g*4 + r) and store of the normalised rows (model dtype) into the LDS panel `dst`.  gm / bt: this lane's
+// gamma / beta (packed, loaded before the GEMM).  One barrier inside (the partials), one after (the panel is complete).
+template <typename T>
+__device__ __forceinline__ void panel_layernorm(f32x4 (&v)[3][4], const u32x2 (&gm)[4], const u32x2 (&bt)[4], float eps, unsigned char* dst,
+                                                float* red, int wave, int lane) {
+  const LaneCtx lc = lane_ctx(lane, wave);
+  const int x = lc.x, g = lc.g;
+#pragma unroll
+  for (int mi = 0; mi < 3; ++mi) {
+    float s = 0.f;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) s += (v[mi][ni][0] + v[mi][ni][1]) + (v[mi][ni][2] + v[mi][ni][3]);
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    const float mw = s * (1.0f / 64.0f);  // mean of this wave's 64 columns of the row
+    float q = 0.f;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = v[mi][ni][r] - mw;
+        q = fmaf(d, d, q);
+      }
+    q += __shfl_xor(q, 16, 64);
+    q += __shfl_xor(q, 32, 64);
+    if (g == 0) *reinterpret_cast<float2*>(red + ((mi * 16 + x) * 8 + wave) * 2) = make_float2(mw, q);
+  }
+  lds_barrier();
+#pragma unroll
+  for (int mi = 0; mi < 3; ++mi) {
+    // the 8 waves' (mean, M2) of the row, merged in wave order (Chan et al.): M2 = sum M2_w + 64 sum (mean_w - mean)^2
+    const f32x4* pr = reinterpret_cast<const f32x4*>(red + (mi * 16 + x) * 16);
+    const f32x4 p0 = pr[0], p1 = pr[1], p2 = pr[2], p3 = pr[3];
+    const float mean = (((p0[0] + p0[2]) + (p1[0] + p1[2])) + ((p2[0] + p2[2]) + (p3[0] + p3[2]))) * 0.125f;
+    float m2 = ((p0[1] + p0[3]) + (p1[1] + p1[3])) + ((p2[1] + p2[3]) + (p3[1] + p3[3]));
+    const float d0 = p0[0] - mean, d1 = p0[2] - mean, d2 = p1[0] - mean, d3 = p1[2] - mean;
+    const float d4 = p2[0] - mean, d5 = p2[2] - mean, d6 = p3[0] - mean, d7 = p3[2] - mean;
+    const float dm = ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) + ((d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7));
+    m2 = fmaf(64.0f, dm, m2);
+    const float rstd = rsqrtf(m2 * (1.0f / (float)kCh) + eps);
+    unsigned char* drow = dst + (mi * 16 + x) * kRowBytes;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      float gv[4], bv[4], o[4];
+      unpack4<T>(gm[ni], gv);
+      unpack4<T>(bt[ni], bv);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = fmaf((v[mi][ni][r] - mean) * rstd, gv[r], bv[r]);
+      *reinterpret_cast<u32x2*>(drow + lc.coff[ni]) = pack4<T>(o);
+    }
+  }
+  lds_barrier();
+}
+
+// TL: a second instantiation that stamps s_memtime at the phase boundaries of each workgroup's FIRST panel (every wave, lane 0)
+// into a.timeline - tools/chain_timeline.py; the production instantiation carries none of it.
+//
+// Schedule of one panel (what the in-kernel timeline of the first version asked for: the two waves of a SIMD do not progress
+// evenly - the older one takes a 16-step segment in ~5.7 us, the younger in 7.5-9 us - so every barrier right behind a GEMM
+// segment exposes that skew, and an epilogue behind a barrier runs with the matrix cores idle):
+//   panel loads are issued BEFORE the weight ring's (the ring's first use comes later);
+//   P GEMM -> x1 epilogue (skip rows preloaded into registers; x1 parked in the OUTPUT rows in global memory, read back by the
+//     same lane before the last MLP-2 segment) -> LayerNorm (2 barriers: the partials, the panel);
+//   MLP software-pipelined over the hidden chunks, h double-buffered in LDS (bufA / bufC):
+//       M1(0) w(h0) | M1(1) B w(h1) M2(0) | M1(2) B w(h2) M2(1) | M1(3) B w(h3) M2(2) | B M2(3)
+//     ONE barrier per chunk, between a wave's M1(c) segment (+ its GELU, done in registers BEFORE the barrier) and its write of
+//     h_c: behind it every wave has finished M2(c-2) (so h_c may overwrite h_(c-2)) and w(h_(c-1)) (so M2(c-1) may read it) -
+//     and every wave arrives with a whole segment of slack;
+//   x2 epilogue -> LayerNorm' (2 barriers) -> the trailing projection's chunks without barriers, outputs transposed through a
+//     wave-private LDS strip into whole 128-byte lines (16-byte stores).
+template <typename T, bool TL = false>
+__global__ __launch_bounds__(512, 1) void gt_chain_kernel(ChainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const bufA = smem;                  // A operand: attention rows, then the even hidden chunks
+  unsigned char* const bufB = smem + kBufBytes;      // A operand: LayerNorm'd rows (MLP-1, trailing projection)
+  unsigned char* const bufC = smem + 2 * kBufBytes;  // the odd hidden chunks; staging strips of the trailing projection's stores
+  float* const red = reinterpret_cast<float*>(smem + kRedOff);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4;
+
+  // this wave's weight stream: wave-uniform bases (scalar registers) + the lane's 16 bytes of every fragment
+  const uint32_t loff = lane * 16;
+  const char* const wp0 = a.wp + (int64_t)wave * kSlab;
+  const char* const w10 = a.w1 + (int64_t)wave * kSlab;                 // + c * 8 slabs
+  const char* const w20 = a.w2 + (int64_t)wave * a.hc * kSlab;          // + c slabs
+  const char* const wq0 = a.qc > 0 ? a.wq + (int64_t)wave * kSlab : wp0;  // + c * 8 slabs
+
+  [[maybe_unused]] int tl_n = 0;
+  // stamps go to LDS (a global store per stamp sits in the vmcnt queue of the weight ring and distorts what it measures)
+  auto stamp = [&]() {
+    if constexpr (TL) {
+      if (tl_n < kTlSlots) {
+        const unsigned long long now = __builtin_readcyclecounter();
+        if (lane == 0) reinterpret_cast<unsigned long long*>(smem + kTlOff)[wave * kTlSlots + tl_n] = now;
+      }
+      ++tl_n;
+    }
+  };
+  stamp();  // 0: kernel entry
+  if (wave >= 4) {
+    if (a.prio_young == 1) __builtin_amdgcn_s_setprio(1);
+    else if (a.prio_young == 2) __builtin_amdgcn_s_setprio(2);
+    else if (a.prio_young == 3) __builtin_amdgcn_s_setprio(3);
+  }
+  const u32x4 zero4 = u32x4{0u, 0u, 0u, 0u};
+
+  int tile = blockIdx.x;
+  if (tile >= a.n_tiles) return;
+  // the first panel's attention rows (coalesced 16-byte loads), requested ahead of the weight ring
+  u32x4 va[6];
+  auto request_panel = [&](int t) {
+    const int r0 = t * a.rows_per_tile;
+    const int nr = min(a.rows_per_tile, a.n_rows - r0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int idx = tid + 512 * i;
+      const int rr = min(idx >> 6, nr - 1), slot = idx & 63;
+      va[i] = *reinterpret_cast<const u32x4*>((const T*)a.attn + (int64_t)(r0 + rr) * a.ld_attn + slot * 8);
+    }
+  };
+  request_panel(tile);
+  __builtin_amdgcn_sched_barrier(0);
+  frag8 bq[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      bq[j][ni] = *reinterpret_cast<gfrag_t>(uniform_ptr(wp0 + j * 4096) + loff + ni * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+  for (;;) {
+    const int r0 = tile * a.rows_per_tile;
+    const int nr = min(a.rows_per_tile, a.n_rows - r0);
+    // ---- the panel: attention rows -> bufA (rows beyond the panel are zero).  The skip rows and the epilogue's parameter columns are
+    // requested BEHIND the panel's barrier: 46 loads per lane in front of it took 5-8 us just to issue (in-kernel timeline)
+    stamp();  // loads issued
+    if constexpr (TL) {
+      asm volatile("" : "+v"(va[5]));
+      __builtin_amdgcn_sched_barrier(0);
+      stamp();  // panel rows arrived
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int idx = tid + 512 * i;
+      const int row = idx >> 6, slot = idx & 63;
+      *reinterpret_cast<u32x4*>(bufA + row * kRowBytes + ((slot ^ (row & 15)) << 4)) = row < nr ? va[i] : zero4;
+    }
+    lds_barrier();
+    stamp();  // 1: panel in LDS
+    u32x2 xr[3][4];  // this lane's skip values (P epilogue), later x1 (MLP-2 epilogue)
+    u32x2 pb[4], pg[4], pt[4];  // packed parameter columns of the coming epilogue (see load_cols)
+    {
+      const LaneCtx lc = lane_ctx(lane, wave);
+#pragma unroll
+      for (int mi = 0; mi < 3; ++mi) {
+        const T* xrow = (const T*)a.xres + (int64_t)(r0 + min(mi * 16 + lc.x, nr - 1)) * a.ld_x + wave * 64 + lc.g * 4;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) xr[mi][ni] = *reinterpret_cast<const u32x2*>(xrow + ni * 16);
+      }
+    }
+    load_cols<T>((const T*)a.bp, wave, g, pb);
+    load_cols<T>((const T*)a.ln1_g, wave, g, pg);
+    if (a.ln1_b != nullptr) {
+      load_cols<T>((const T*)a.ln1_b, wave, g, pt);
+    } else {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) pt[ni] = u32x2{0u, 0u};
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    f32x4 acc[3][4], acc2[3][4];
+    // ---- projection + skip -> x1 (parked in the output rows), LayerNorm_mlp(x1) -> bufB
+    zero_acc<T>(acc);
+    gemm_seg<T>(bufA, lane, bq, wp0, w10, loff, acc);
+    stamp();  // 2: projection GEMM done
+    if (!(a.dbg & 8)) {
+      const LaneCtx lc = lane_ctx(lane, wave);
+#pragma unroll
+      for (int mi = 0; mi < 3; ++mi) {
+        const int m = mi * 16 + lc.x;
+        T* orow = (T*)a.xout + (int64_t)(r0 + min(m, nr - 1)) * a.ld_out + wave * 64 + lc.g * 4;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          float bias[4], res[4], o[4];
+          unpack4<T>(pb[ni], bias);
+          unpack4<T>(xr[mi][ni], res);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (acc[mi][ni][r] + bias[r]) + res[r];
+          const u32x2 pk = pack4<T>(o);
+          if (m < nr) *reinterpret_cast<u32x2*>(orow + ni * 16) = pk;  // x1, read back by this same lane as MLP-2's skip
+          unpack4<T>(pk, o);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[mi][ni][r] = o[r];
+        }
+      }
+    }
+    if (!(a.dbg & 2)) panel_layernorm<T>(acc, pg, pt, a.ln1_eps, bufB, red, wave, lane);
+    else { lds_barrier(); lds_barrier(); }
+    stamp();  // 3: x1 + LayerNorm done
+
+    // ---- MLP, software-pipelined over the hidden chunks (see the schedule above)
+    zero_acc<T>(acc2);
+    for (int c = 0; c < a.hc; ++c) {
+      load_cols<T>((const T*)a.b1 + c * kCh, wave, g, pb);
+      __builtin_amdgcn_sched_barrier(0);
+      zero_acc<T>(acc);
+      // the segment behind M1(c) is M2(c-1) (c > 0), else M1(1) - or M2(0) when there is a single chunk
+      const char* nx1 = c > 0 ? w20 + (int64_t)(c - 1) * kSlab : (a.hc > 1 ? w10 + (int64_t)8 * kSlab : w20);
+      gemm_seg<T>(bufB, lane, bq, w10 + (int64_t)c * 8 * kSlab, nx1, loff, acc);
+      stamp();  // MLP-1 chunk GEMM done
+      u32x2 hp[3][4];
+      if (a.dbg & 1) {
+#pragma unroll
+        for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) hp[mi][ni] = u32x2{__float_as_uint(acc[mi][ni][0]), __float_as_uint(acc[mi][ni][1])};
+      } else
+#pragma unroll
+      for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          float bias[4], t[4];
+          unpack4<T>(pb[ni], bias);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) t[r] = acc[mi][ni][r] + bias[r];
+          gelu_fast2(t[0], t[1]);
+          gelu_fast2(t[2], t[3]);
+          hp[mi][ni] = pack4<T>(t);
+        }
+      stamp();  // GELU in registers
+      if (c > 0) lds_barrier();  // all waves: M2(c-2) read and h_(c-1) written (c = 0: bufA was last read by the projection, two barriers ago)
+      stamp();  // barrier passed
+      {
+        const LaneCtx lc = lane_ctx(lane, wave);
+        unsigned char* const hb = (c & 1) ? bufC : bufA;
+#pragma unroll
+        for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) *reinterpret_cast<u32x2*>(hb + (mi * 16 + lc.x) * kRowBytes + lc.coff[ni]) = hp[mi][ni];
+      }
+      if (c > 0) {
+        // M2(c-1); behind it M1(c+1), or the last MLP-2 segment
+        const char* nx2 = c + 1 < a.hc ? w10 + (int64_t)(c + 1) * 8 * kSlab : w20 + (int64_t)c * kSlab;
+        gemm_seg<T>(((c - 1) & 1) ? bufC : bufA, lane, bq, w20 + (int64_t)(c - 1) * kSlab, nx2, loff, acc2);
+        stamp();  // MLP-2 K-chunk done
+      }
+    }
+    // the epilogue behind the last MLP-2 segment: its parameters and this lane's x1 values, requested ahead of the segment
+    load_cols<T>((const T*)a.b2, wave, g, pb);
+    if (a.qc > 0) {
+      load_cols<T>((const T*)a.lnq_g, wave, g, pg);
+      if (a.lnq_b != nullptr) {
+        load_cols<T>((const T*)a.lnq_b, wave, g, pt);
+      } else {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) pt[ni] = u32x2{0u, 0u};
+      }
+    }
+    {
+      const LaneCtx lc = lane_ctx(lane, wave);
+#pragma unroll
+      for (int mi = 0; mi < 3; ++mi) {
+        const T* orow = (const T*)a.xout + (int64_t)(r0 + min(mi * 16 + lc.x, nr - 1)) * a.ld_out + wave * 64 + lc.g * 4;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) xr[mi][ni] = *reinterpret_cast<const u32x2*>(orow + ni * 16);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();  // the last hidden chunk is complete
+    stamp();
+    gemm_seg<T>(((a.hc - 1) & 1) ? bufC : bufA, lane, bq, w20 + (int64_t)(a.hc - 1) * kSlab, a.qc > 0 ? wq0 : wp0, loff, acc2);
+    stamp();  // last MLP-2 K-chunk done
+    // ---- x2 = h W2^T + b2 + x1 [+ extra] -> global; LayerNorm_attn'(x2) -> bufB
+    if (!(a.dbg & 8)) {
+      const LaneCtx lc = lane_ctx(lane, wave);
+#pragma unroll
+      for (int mi = 0; mi < 3; ++mi) {
+        const int m = mi * 16 + lc.x;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          const int n = wave * 64 + ni * 16 + lc.g * 4;
+          float bias[4], res[4], t[4];
+          unpack4<T>(pb[ni], bias);
+          unpack4<T>(xr[mi][ni], res);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) t[r] = (acc2[mi][ni][r] + bias[r]) + res[r];
+          u32x2 pk = pack4<T>(t);
+          if (a.extra != nullptr && m < nr) {
+            // the latent skip rides on the last block's output, added to the block's ROUNDED output as `x + skip` does
+            float e[4];
+            unpack4<T>(pk, t);
+            unpack4<T>(*reinterpret_cast<const u32x2*>((const T*)a.extra + (int64_t)(r0 + m) * a.ld_extra + n), e);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[r] += e[r];
+            pk = pack4<T>(t);
+          }
+          if (m < nr) *reinterpret_cast<u32x2*>((T*)a.xout + (int64_t)(r0 + m) * a.ld_out + n) = pk;
+          unpack4<T>(pk, t);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc2[mi][ni][r] = t[r];
+        }
+      }
+    }
+    stamp();  // x2 epilogue done
+    const int next_tile = tile + (int)gridDim.x;
+    const bool more = next_tile < a.n_tiles;
+    if (a.qc > 0) {
+      if (!(a.dbg & 2)) panel_layernorm<T>(acc2, pg, pt, a.lnq_eps, bufB, red, wave, lane);
+      else { lds_barrier(); lds_barrier(); }
+      stamp();  // LayerNorm' done
+      // behind LayerNorm's barriers no wave reads bufA / bufC any more: they stage the stores (a 48 x 128-byte strip per wave)
+      unsigned char* const strip = ((wave & 4) ? bufC : bufA) + (wave & 3) * (kPanel * 128);
+      for (int c = 0; c < a.qc; ++c) {
+        load_cols<T>((const T*)a.bq + c * kCh, wave, g, pb);
+        __builtin_amdgcn_sched_barrier(0);
+        zero_acc<T>(acc);
+        const char* nxt = c + 1 < a.qc ? wq0 + (int64_t)(c + 1) * 8 * kSlab : wp0;  // (the next panel's projection; after the last panel: a harmless re-read)
+        gemm_seg<T>(bufB, lane, bq, wq0 + (int64_t)c * 8 * kSlab, nxt, loff, acc);
+        if (!(a.dbg & 4)) {
+          // strip row m, 16-byte slot s (8 per row) at m*128 + ((s ^ ((m >> 1) & 7)) << 4): conflict-free for the 8-byte writes in
+          // the MFMA layout and for the 16-byte row-major read-back (8 lanes per row, 8 rows per instruction)
+          const LaneCtx lc = lane_ctx(lane, wave);
+#pragma unroll
+          for (int mi = 0; mi < 3; ++mi) {
+            const int m = mi * 16 + lc.x;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+              float bias[4], o[4];
+              unpack4<T>(pb[ni], bias);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) o[r] = acc[mi][ni][r] + bias[r];
+              *reinterpret_cast<u32x2*>(strip + m * 128 + (((ni * 2 + (lc.g >> 1)) ^ ((m >> 1) & 7)) << 4) + (lc.g & 1) * 8) = pack4<T>(o);
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private strip: the wave's own LDS operations are ordered, no barrier
+          const int rl = (lc.g << 1) | (lc.x >> 3);  // lane >> 3: row within a group of 8
+          const int sl = lane & 7;
+#pragma unroll
+          for (int it = 0; it < 6; ++it) {
+            const int m = it * 8 + rl;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(strip + m * 128 + ((sl ^ ((m >> 1) & 7)) << 4));
+            if (m < nr) *reinterpret_cast<u32x4*>((T*)a.qout + (int64_t)(r0 + m) * a.ld_q + c * kCh + wave * 64 + sl * 8) = v;
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the strip is rewritten by the next chunk
+        }
+        stamp();  // trailing projection chunk c done (GEMM + stores issued)
+      }
+    }
+    if constexpr (TL) {
+      if (tile == (int)blockIdx.x) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane < kTlSlots && lane < tl_n)
+          a.timeline[((size_t)blockIdx.x * 8 + wave) * kTlSlots + lane] = reinterpret_cast<const unsigned long long*>(smem + kTlOff)[wave * kTlSlots + lane];
+      }
+    }
+    if (!more) break;
+    tile = next_tile;
+    request_panel(tile);
+    __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();  // every wave is done with this panel's LDS (bufA: staging strips / the last hidden chunk's buffer)
+  }
+}
+
+template <typename T>
+static int launch_chain(const ChainArgs& a, hipStream_t st) {
+  static PerDeviceOnce attr_once;
+  attr_once.run([&] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gt_chain_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, kChainSmem);
+  });
+  const int grid = a.n_tiles < 256 ? a.n_tiles : 256;
+  if (a.timeline != nullptr) {
+    static PerDeviceOnce tl_once;
+    tl_once.run([&] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gt_chain_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kChainSmem + 8 * kTlSlots * 8);
+    });
+    hipLaunchKernelGGL((gt_chain_kernel<T, true>), dim3(grid), dim3(512), kChainSmem + 8 * kTlSlots * 8, st, a);
+    return check_launch("gt_chain_kernel<timeline>");
+  }
+  hipLaunchKernelGGL((gt_chain_kernel<T>), dim3(grid), dim3(512), kChainSmem, st, a);
+  return check_launch("gt_chain_kernel");
+}
+
+}  // namespace anemoi
+
+using namespace anemoi;
+
+extern "C" int anemoi_gt_chain_rows_per_tile(int32_t n_rows) {
+  // whole rounds of panels over the 256 CUs, panels as even as the 48-row limit allows (10 242 rows: 250 panels of 41)
+  static const int forced = env_int(getenv("ANEMOI_CHAIN_ROWS"), 0, 0, kPanel);
+  if (forced > 0) return forced;
+  if (n_rows <= 0) return kPanel;
+  const int64_t rounds = ((int64_t)n_rows + 256 * kPanel - 1) / (256 * kPanel);
+  const int64_t r = ((int64_t)n_rows + 256 * rounds - 1) / (256 * rounds);
+  return (int)(r < 1 ? 1 : (r > kPanel ? kPanel : r));
+}
+
+extern "C" int anemoi_gt_chain_fwd(const anemoi_gt_chain_args_t* p, anemoi_dtype_t dtype, void* stream) {
+  ANEMOI_REQUIRE(p != nullptr, "gt_chain_fwd: null argument block");
+  ANEMOI_REQUIRE(dtype == ANEMOI_BF16 || dtype == ANEMOI_F16, "gt_chain_fwd: 16-bit model dtypes only");
+  ANEMOI_REQUIRE(p->n_rows >= 0 && p->channels == kCh, "gt_chain_fwd: channels=%d (this kernel is built for %d)", p->channels, kCh);
+  if (p->n_rows == 0) return ANEMOI_OK;
+  ANEMOI_REQUIRE(p->hidden > 0 && p->hidden % kCh == 0 && p->q_out_features >= 0 && p->q_out_features % kCh == 0,
+                 "gt_chain_fwd: hidden=%d and q_out_features=%d must be multiples of %d", p->hidden, p->q_out_features, kCh);
+  ANEMOI_REQUIRE(p->attn && p->x_res && p->wp && p->bp && p->ln1_w && p->w1 && p->b1 && p->w2 && p->b2 && p->x_out, "gt_chain_fwd: null operand");
+  ANEMOI_REQUIRE(p->q_out_features == 0 || (p->lnq_w && p->wq && p->bq && p->q_out), "gt_chain_fwd: the trailing projection needs lnq_w, wq, bq, q_out");
+  const auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  ANEMOI_REQUIRE(al16(p->attn) && al16(p->x_res) && al16(p->wp) && al16(p->w1) && al16(p->w2) && al16(p->x_out) && al16(p->wq) && al16(p->q_out) &&
+                     al16(p->extra) && (reinterpret_cast<uintptr_t>(p->bp) & 7) == 0 && (reinterpret_cast<uintptr_t>(p->b1) & 7) == 0 &&
+                     (reinterpret_cast<uintptr_t>(p->b2) & 7) == 0 && (reinterpret_cast<uintptr_t>(p->bq) & 7) == 0 &&
+                     (reinterpret_cast<uintptr_t>(p->ln1_w) & 7) == 0 && (reinterpret_cast<uintptr_t>(p->ln1_b) & 7) == 0 &&
+                     (reinterpret_cast<uintptr_t>(p->lnq_w) & 7) == 0 && (reinterpret_cast<uintptr_t>(p->lnq_b) & 7) == 0,
+                 "gt_chain_fwd: operands must be 16-byte aligned (vectors: 8-byte)");
+  ANEMOI_REQUIRE(p->ld_attn >= kCh && p->ld_x >= kCh && p->ld_out >= kCh && p->ld_attn % 8 == 0 && p->ld_x % 8 == 0 && p->ld_out % 4 == 0 &&
+                     (p->extra == nullptr || (p->ld_extra >= kCh && p->ld_extra % 4 == 0)) &&
+                     (p->q_out_features == 0 || (p->ld_q >= p->q_out_features && p->ld_q % 4 == 0)),
+                 "gt_chain_fwd: leading dimensions too small or not vector-aligned");
+  ChainArgs a{};
+  a.attn = p->attn; a.ld_attn = p->ld_attn;
+  a.xres = p->x_res; a.ld_x = p->ld_x;
+  a.wp = (const char*)p->wp; a.bp = p->bp;
+  a.ln1_g = p->ln1_w; a.ln1_b = p->ln1_b; a.ln1_eps = p->ln1_eps;
+  a.w1 = (const char*)p->w1; a.b1 = p->b1; a.hc = p->hidden / kCh;
+  a.w2 = (const char*)p->w2; a.b2 = p->b2;
+  a.extra = p->extra; a.ld_extra = p->ld_extra;
+  a.xout = p->x_out; a.ld_out = p->ld_out;
+  a.lnq_g = p->lnq_w; a.lnq_b = p->lnq_b; a.lnq_eps = p->lnq_eps;
+  a.wq = (const char*)p->wq; a.bq = p->bq; a.qc = p->q_out_features / kCh;
+  a.qout = p->q_out; a.ld_q = p->ld_q;
+  a.timeline = reinterpret_cast<unsigned long long*>(p->timeline);
+  static const int prio_young = env_int(getenv("ANEMOI_CHAIN_PRIO_YOUNG"), 0, 0, 3);
+  a.prio_young = prio_young;
+  static const int dbg = env_int(getenv("ANEMOI_CHAIN_DBG"), 0, 0, 255);
+  a.dbg = dbg;
+  a.n_rows = p->n_rows;
+  a.rows_per_tile = p->rows_per_tile > 0 ? p->rows_per_tile : anemoi_gt_chain_rows_per_tile(p->n_rows);
+  ANEMOI_REQUIRE(a.rows_per_tile <= kPanel, "gt_chain_fwd: rows_per_tile=%d exceeds the %d-row panel", a.rows_per_tile, kPanel);
+  a.n_tiles = (a.n_rows + a.rows_per_tile - 1) / a.rows_per_tile;
+  hipStream_t st = as_stream(stream);
+  return dtype == ANEMOI_BF16 ? launch_chain<bf16_t>(a, st) : launch_chain<f16_t>(a, st);
+}

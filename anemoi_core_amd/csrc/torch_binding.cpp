@@ -167,6 +167,13 @@ std::tuple<Tensor, Tensor> gt_attention_fused_edge(const Tensor& q, const Tensor
                         w_packed.is_contiguous(),
                     "w_packed must be contiguous fp32 [", D, ", ", fe_pad, "]");
   TORCH_CHECK_VALUE(colptr.size(0) == n_dst + 1 && k.size(0) == n_src && v.size(0) == n_src, "node counts do not match the graph");
+  // a CPU csc.row or a narrower k would end in a GPU memory fault instead of an error (the ctypes path checks through _dev())
+  TORCH_CHECK_VALUE(row.device() == dev && colptr.device() == dev && edge_feat.device() == dev && w_packed.device() == dev &&
+                        (!order.has_value() || !order->defined() || order->device() == dev),
+                    "row / colptr / order / edge_feat / w_packed must be on q's device");
+  TORCH_CHECK_VALUE(k.dim() == 2 && v.dim() == 2 && k.size(1) == D && v.size(1) == D, "k and v must have ", D, " columns like q");
+  TORCH_CHECK_VALUE(!addend.has_value() || !addend->defined() || (addend->dim() == 2 && addend->size(0) == n_dst && addend->size(1) == D),
+                    "addend must be [", n_dst, ", ", D, "]");
   TORCH_CHECK_VALUE(row.scalar_type() == at::kInt && colptr.scalar_type() == at::kInt && row.is_contiguous() && colptr.is_contiguous(),
                     "row / colptr must be contiguous int32");
   const int32_t* ord = nullptr;

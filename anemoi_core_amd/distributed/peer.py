@@ -266,7 +266,9 @@ class PeerWire:
             raise PeerWireError(f"peer exchange: {src.shape[0]} packed rows, the plan sends {ch.send_rows}")
         self._launch(ch, src, src.stride(0) * es, send_index)
         if not direct and ch.recv_rows:
-            recv.reshape(ch.recv_rows, -1).copy_(ch.region.view(recv.dtype).view(ch.recv_rows, -1))
+            if not recv.is_contiguous():  # reshape() of a strided tensor is a temporary: the received rows would be dropped silently
+                raise PeerWireError("peer exchange: a staged receive buffer must be contiguous")
+            recv.view(ch.recv_rows, -1).copy_(ch.region.view(recv.dtype).view(ch.recv_rows, -1))
 
     def all_gather(self, out: Tensor, inp: Tensor) -> None:
         """out[W * n, ...] <- every rank's inp[n, ...] (equal shards).  Shards whose rows are not 16-byte multiples (84 bf16
@@ -286,7 +288,9 @@ class PeerWire:
         if ch.index is None:  # every peer gets the SAME n rows: the packed send order repeats them W times
             ch.index = torch.arange(n, dtype=torch.int32, device=self.device).repeat(self.world)
         self._launch(ch, src, src.stride(0) * src.element_size(), ch.index)
-        out.reshape(-1).view(torch.uint8).copy_(ch.region)
+        if not out.is_contiguous():  # reshape() of a strided tensor is a temporary: the rows would be dropped silently
+            raise PeerWireError("peer all_gather: the output tensor must be contiguous")
+        out.view(-1).view(torch.uint8).copy_(ch.region)
 
     def selftest(self) -> None:
         """Collective: a small all-gather and a variable-count exchange over the wire, every word checked, verdict agreed by all
@@ -346,7 +350,10 @@ def install(group, **kwargs) -> PeerWire:
     fallback = (P._all_to_all_single, P._all_gather_into_tensor)
 
     def mine(g, *tensors) -> bool:
-        return g is wire.group and not (torch.is_grad_enabled() and any(t.requires_grad for t in tensors))
+        # ONE predicate for all five hooks: the wire carries the inference forward only (grad mode off).  With grad mode on every
+        # exchange - also one whose rows happen not to require grad, e.g. the encoder's raw input rows in a training step - stays on
+        # RCCL: outside a forward scope the channel sequence is never rewound, and every step would create new channels.
+        return g is wire.group and not torch.is_grad_enabled()
 
     def a2a(recv, send, recv_counts, send_counts, g):
         if mine(g, send) and (send.shape[1:].numel() * send.element_size()) % 16 == 0:
@@ -364,12 +371,12 @@ def install(group, **kwargs) -> PeerWire:
         return fallback[1](out, inp, g)
 
     def recv_buffer(head_rows, send_counts, recv_counts, width, dtype, device, g):
-        if g is wire.group and not torch.is_grad_enabled() and (width * torch.empty((), dtype=dtype).element_size()) % 16 == 0:
+        if mine(g) and (width * torch.empty((), dtype=dtype).element_size()) % 16 == 0:
             return wire.recv_buffer(head_rows, send_counts, recv_counts, width, dtype)
         return torch.empty((head_rows + sum(recv_counts), width), dtype=dtype, device=device)
 
     def scope(g):
-        return wire.forward_scope() if g is wire.group and not torch.is_grad_enabled() else contextlib.nullcontext()
+        return wire.forward_scope() if mine(g) else contextlib.nullcontext()
 
     wire._saved = (P._all_to_all_single, P._all_gather_into_tensor, P._push_rows, P.recv_buffer, P.forward_scope)
     P._all_to_all_single, P._all_gather_into_tensor, P._push_rows, P.recv_buffer, P.forward_scope = a2a, allgather, push, recv_buffer, scope

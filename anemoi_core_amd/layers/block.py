@@ -39,6 +39,14 @@ _LN_FOLD = os.environ.get("ANEMOI_LN_FOLD", "1") == "1"
 # 8-way sharded mesh 1.50 / 1.50 ms, 10 242 nodes 3.09 / 3.00 ms.  (Until late round 3 the small-tile consumer lost 60 us per launch to
 # ONE lane walking a tail row load by load, which had made the fold look slower below 4 096 rows.)  Not below 512 rows: not measured.
 _LN_FOLD_MIN_ROWS = int(os.environ.get("ANEMOI_LN_FOLD_MIN_ROWS", "512"))
+# Round 4: the row-local part of a block (projection + skip, LayerNorm, MLP, the NEXT block's LayerNorm + q|k|v|self projection)
+# as ONE launch that keeps a 48-row panel in LDS and streams the weights (ops.gt_layer_chain, csrc/gt_chain.hip) instead of four
+# GEMM launches with the LayerNorm fold between them.  Built, parity-green and MEASURED: 105-115 us per launch against 108 us for
+# the four launches it replaces, O96 forward 3.01 against 2.955 ms (at 40 rows per CU every CU streams all
+# 6.5 MB of a layer's weights through its own L1, 106 k cycles at 64 B/clk before any epilogue) - so it is OPT-IN
+# (ANEMOI_LAYER_CHAIN=1), kept under test with its in-kernel timeline (tools/chain_timeline.py).
+_LAYER_CHAIN = os.environ.get("ANEMOI_LAYER_CHAIN", "0") == "1"
+_LAYER_CHAIN_MIN_ROWS = int(os.environ.get("ANEMOI_LAYER_CHAIN_MIN_ROWS", "0"))
 
 
 _IDENTITY: dict = {}
@@ -92,6 +100,20 @@ class _FusedWeights:
             d = (b if ln.bias is None else w @ ln.bias.float() + b).contiguous()
         self._cache["ln:" + tag] = (sig, (ws, c, d))
         return ws, c, d
+
+    def frag(self, tag: str, linears: list) -> tuple[Tensor, Tensor]:
+        """(fragment-major image of cat[W...], cat[b...]) for ops.gt_layer_chain; rebuilt only when a parameter changes."""
+        ps = [p for lin in linears for p in (lin.weight, lin.bias) if p is not None]
+        sig = tuple((p.data_ptr(), version(p), p.dtype, str(p.device)) for p in ps)
+        hit = self._cache.get("frag:" + tag)
+        if hit is not None and hit[0] == sig:
+            return hit[1], hit[2]
+        with torch.no_grad():
+            w = torch.cat([lin.weight for lin in linears], dim=0) if len(linears) > 1 else linears[0].weight
+            b = torch.cat([lin.bias if lin.bias is not None else lin.weight.new_zeros(lin.out_features) for lin in linears]).contiguous()
+            wf = ops.pack_weight_frag(w)
+        self._cache["frag:" + tag] = (sig, wf, b)
+        return wf, b
 
     def packed_edge(self, lin_edge) -> Tensor:
         """fp32 [D, fe_pad] image of lin_edge for the fused attention, rebuilt only when the parameters change."""
@@ -307,8 +329,28 @@ class GraphTransformerBaseBlock(BaseBlock):
                 and x.dtype != torch.float32 and x.is_cuda
                 and not (torch.is_grad_enabled() and (x.requires_grad or ln.weight.requires_grad)))
 
+    def _chain_ok(self, ln, x: Tensor) -> bool:
+        """The row-resident chain kernel takes this block's projection / LayerNorm / MLP: inference, 16-bit, 512 channels, plain
+        affine LayerNorm, Linear-GELU-Linear MLP with a hidden width that is a multiple of 512."""
+        mlp = self.node_dst_mlp
+        return (_LAYER_CHAIN and x.is_cuda and x.dtype != torch.float32 and x.shape[0] >= _LAYER_CHAIN_MIN_ROWS
+                and type(ln).__name__ in ("LayerNorm", "AutocastLayerNorm") and ln.weight is not None
+                and mlp.mlp_implementation == "mlp" and len(mlp.mlp) == 3 and mlp.layer_norm is None
+                and self.projection.weight.shape == (ops.CHAIN_CHANNELS, ops.CHAIN_CHANNELS) and self.projection.bias is not None
+                and mlp.mlp[0].weight.shape[1] == ops.CHAIN_CHANNELS and mlp.mlp[0].weight.shape[0] % ops.CHAIN_CHANNELS == 0
+                and mlp.mlp[2].weight.shape[0] == ops.CHAIN_CHANNELS and mlp.mlp[0].bias is not None and mlp.mlp[2].bias is not None
+                and not (torch.is_grad_enabled() and (x.requires_grad or ln.weight.requires_grad or self.projection.weight.requires_grad)))
+
+    def _qkvs_chain_ok(self, x: Tensor) -> bool:
+        """This block's layer_norm_attention + fused [q|k|v|self] projection can ride at the end of the PREVIOUS block's chain launch."""
+        ln = self.layer_norm_attention
+        A = self.attn_channels
+        return (type(ln).__name__ in ("LayerNorm", "AutocastLayerNorm") and ln.weight is not None and not self.qk_norm
+                and x.shape[1] == ops.CHAIN_CHANNELS and (4 * A) % ops.CHAIN_CHANNELS == 0 and self.lin_query.weight.shape[1] == ops.CHAIN_CHANNELS
+                and not (torch.is_grad_enabled() and (ln.weight.requires_grad or self.lin_query.weight.requires_grad)))
+
     def _post_attention(self, attn_plus_self: Tensor, x_skip: Tensor, cond: Optional[Tensor] = None, chain: Optional[dict] = None,
-                        extra: Optional[Tensor] = None) -> Tensor:
+                        extra: Optional[Tensor] = None, next_block=None) -> Tensor:
         """projection + residual, LayerNorm, MLP + residual.  Inference: the projection GEMM also emits the row statistics of
         its output and the MLP's first GEMM applies the LayerNorm from them (no LayerNorm launch); with ``chain`` the last
         GEMM does the same for the NEXT block's first LayerNorm.  ``extra`` (last block of a processor): the model's latent
@@ -317,6 +359,21 @@ class GraphTransformerBaseBlock(BaseBlock):
             return self._post_attention(attn_plus_self, x_skip, cond, chain) + extra
         ln, mlp = self.layer_norm_mlp_dst, self.node_dst_mlp
         plain_mlp = mlp.mlp_implementation == "mlp" and len(mlp.mlp) == 3 and mlp.layer_norm is None
+        if cond is None and self._chain_ok(ln, attn_plus_self) and attn_plus_self.shape == x_skip.shape and (extra is None or extra.shape == x_skip.shape):
+            wp, bp = self._fused.frag("proj", [self.projection])
+            w1, b1 = self._fused.frag("mlp1", [mlp.mlp[0]])
+            w2, b2 = self._fused.frag("mlp2", [mlp.mlp[2]])
+            kw = {}
+            if next_block is not None and chain is not None and extra is None and next_block._qkvs_chain_ok(x_skip):
+                nb = next_block
+                kw["wq"], kw["bq"] = nb._fused.frag("qkvs", [nb.lin_query, nb.lin_key, nb.lin_value, nb.lin_self])
+                lnq = nb.layer_norm_attention
+                kw["lnq_w"], kw["lnq_b"], kw["lnq_eps"] = lnq.weight, lnq.bias, lnq.eps
+            res = ops.gt_layer_chain(attn_plus_self, x_skip, wp, bp, ln.weight, ln.bias, ln.eps, w1, b1, w2, b2, extra=extra, **kw)
+            if kw:
+                chain["qkvs_x"], chain["qkvs"] = res  # the next block's projections, already computed from ITS LayerNorm of our output
+                return res[0]
+            return res
         if plain_mlp and self._ln_fold_ok(ln, attn_plus_self):
             r = ops.linear_with_row_stats(attn_plus_self, self.projection.weight, self.projection.bias, x_skip)
             if r is not None:
@@ -404,7 +461,8 @@ class GraphTransformerMapperBlock(GraphTransformerBaseBlock):
         else:
             out = self._attention(qs[:, :A], kv[:, :A], kv[:, A:], qs[:, A:], edge_attr, csc,
                                   fused=dict(bufs=(qs, kv), q=(0, 0), s=(0, A), k=(1, 0), v=(1, A)))
-        nodes_new_dst = self._post_attention(out, x_dst, cond_dst, layer_kwargs.get("ln_chain"))  # chain: statistics for the processor's first LayerNorm
+        ch = layer_kwargs.get("ln_chain")  # chain: statistics (or the ready projections) for the processor's first block
+        nodes_new_dst = self._post_attention(out, x_dst, cond_dst, ch, next_block=None if ch is None else ch.pop("next_block", None))
         if self.update_src_nodes:
             ln = self.layer_norm_mlp_src
             nodes_new_src = self.node_src_mlp(apply_layer_norm(ln, x_src, cond_src), residual=x_src)
@@ -454,9 +512,13 @@ class GraphTransformerProcessorBlock(GraphTransformerBaseBlock):
         A = self.attn_channels
         ln = self.layer_norm_attention
         chain = kwargs.get("ln_chain")
-        if not model_is_distributed(model_comm_group) and chain is not None and self._ln_fold_ok(ln, x):
+        nxt = None if chain is None else chain.pop("next_block", None)
+        if (not model_is_distributed(model_comm_group) and chain is not None and cond is None
+                and (self._ln_fold_ok(ln, x) or chain.get("qkvs_x") is x or self._chain_ok(self.layer_norm_mlp_dst, x))):
             qkvs = None
-            if chain.get("x") is x:  # the previous block's last GEMM left the row statistics of x
+            if chain.get("qkvs_x") is x:  # the previous block's chain launch computed this block's projections already
+                qkvs = chain["qkvs"]
+            elif chain.get("x") is x and self._ln_fold_ok(ln, x):  # the previous block's last GEMM left the row statistics of x
                 ws, c, d = self._fused.ln_folded("qkvs", [self.lin_query, self.lin_key, self.lin_value, self.lin_self], ln)
                 qkvs = ops.linear_ln_folded(x, ws, c, d, chain["stats"], ln.eps)
             if qkvs is None:
@@ -466,7 +528,7 @@ class GraphTransformerProcessorBlock(GraphTransformerBaseBlock):
             q, k, v, x_r = qkvs[:, :A], qkvs[:, A:2 * A], qkvs[:, 2 * A:3 * A], qkvs[:, 3 * A:]
             csc = get_csc(edge_index, (x.shape[0], x.shape[0]), edges_are_dst_sorted)
             out = self._attention(q, k, v, x_r, edge_attr, csc)
-            return self._post_attention(out, x, cond, chain, kwargs.get("extra_residual")), edge_attr
+            return self._post_attention(out, x, cond, chain, kwargs.get("extra_residual"), next_block=nxt), edge_attr
         sharded = model_is_distributed(model_comm_group) and self.shard_strategy != "heads"
         x_plus_halo = None
         if (sharded and cond is None and not isinstance(ln, ConditionalLayerNorm) and not ops._needs_grad(x, ln.weight)):

@@ -37,8 +37,11 @@ class BaseProcessor(nn.Module):
         self.proc = nn.ModuleList([layer_class(*layer_args, **layer_kwargs) for _ in range(self.num_layers)])
 
     def run_layers(self, data: tuple, *args, last_layer_kwargs: Optional[dict] = None, **kwargs) -> tuple:
+        chain = kwargs.get("ln_chain")
         for i, layer in enumerate(self.proc):
             extra = last_layer_kwargs if (last_layer_kwargs and i == len(self.proc) - 1) else {}
+            if chain is not None:  # a block's chain launch may compute the NEXT block's LayerNorm + projections (layers/block.py)
+                chain["next_block"] = self.proc[i + 1] if i + 1 < len(self.proc) else None
             data = layer(*data, *args, **kwargs, **extra)
         return data
 

@@ -274,8 +274,10 @@ class AnemoiModelEncProcDec(nn.Module):
         from ..layers.mapper import GraphTransformerForwardMapper
         from ..layers.processor import GraphTransformerProcessor
 
-        chain_kw = ({"ln_chain": {}} if len(names) == 1 and isinstance(self.encoder[names[0]], GraphTransformerForwardMapper)
-                    and isinstance(self.processor, GraphTransformerProcessor) else {})
+        chain_kw = ({"ln_chain": {"next_block": self.processor.proc[0]}} if len(names) == 1 and isinstance(self.encoder[names[0]], GraphTransformerForwardMapper)
+                    and isinstance(self.processor, GraphTransformerProcessor) and model_comm_group is None else
+                    ({"ln_chain": {}} if len(names) == 1 and isinstance(self.encoder[names[0]], GraphTransformerForwardMapper)
+                     and isinstance(self.processor, GraphTransformerProcessor) else {}))
         for ds in names:
             shard_sizes_data = grid_shard_sizes[ds] if in_out_sharded[ds] else None
             norm_in, norm_out = (_fused_norm or {}).get(ds, (None, None))

@@ -130,6 +130,16 @@ def kernel_cases(model, g, args, dtype, device):
         "linear_mlp1(512->2048)+gelu": (lambda: ops.linear(x, blk.node_dst_mlp.mlp[0].weight, blk.node_dst_mlp.mlp[0].bias, act="gelu"), "mfma", 2.0 * N * D * hid),
         "linear_mlp2(2048->512)+res": (lambda: ops.linear(h, blk.node_dst_mlp.mlp[2].weight, blk.node_dst_mlp.mlp[2].bias, residual=x), "mfma", 2.0 * N * hid * D),
     }
+    if D == ops.CHAIN_CHANNELS and hid % ops.CHAIN_CHANNELS == 0 and dtype != torch.float32:
+        # the row-resident chain: projection + LayerNorm + MLP + the next block's LayerNorm and q|k|v|self projection in ONE launch
+        mlp, lnm = blk.node_dst_mlp, blk.layer_norm_mlp_dst
+        wp, bp = blk._fused.frag("proj", [blk.projection])
+        w1, b1 = blk._fused.frag("mlp1", [mlp.mlp[0]])
+        w2, b2 = blk._fused.frag("mlp2", [mlp.mlp[2]])
+        wq, bq = blk._fused.frag("qkvs", [blk.lin_query, blk.lin_key, blk.lin_value, blk.lin_self])
+        cases["gt_layer_chain(proj+mlp+next qkvs)"] = (
+            lambda: ops.gt_layer_chain(x, x, wp, bp, lnm.weight, lnm.bias, lnm.eps, w1, b1, w2, b2, lnq_w=ln.weight, lnq_b=ln.bias, lnq_eps=ln.eps, wq=wq, bq=bq),
+            "mfma", 2.0 * N * (D * D + 2 * D * hid + D * 4 * D))
     return cases
 
 
@@ -227,6 +237,16 @@ def profile_forward(step, dtype, host_ms: float = 12.0):
         N, K, O = x.shape[0], w.shape[1], w.shape[0]
         return "linear_mfma_*", 2.0 * N * K * O, es * (N * K + O * K + N * O)
 
+    def chain_work(res_, a_, kw):
+        # the row-resident layer chain (csrc/gt_chain.hip): projection + MLP-1 + MLP-2 [+ the next block's q|k|v|self projection];
+        # compulsory bytes: attention rows and skip in, x2 [and the projections] out, every weight once (the hidden activations
+        # and the two LayerNorms never touch memory)
+        attn, b1 = a_[0], a_[8]
+        N, D, Hd = attn.shape[0], attn.shape[1], b1.shape[0]
+        Oq = kw["bq"].shape[0] if kw.get("bq") is not None else 0
+        extra = 1 if kw.get("extra") is not None else 0
+        return "gt_chain_kernel", 2.0 * N * (D * D + 2 * D * Hd + D * Oq), es * (N * D * (3 + extra) + N * Oq + D * D + 2 * D * Hd + D * Oq)
+
     def segsum_work(res_, a_, kw):
         z, csc = a_[0], a_[5]  # read z, e_old; write e_new, agg (2(3 M D + N D))
         M, D = z.shape
@@ -240,6 +260,7 @@ def profile_forward(step, dtype, host_ms: float = 12.0):
 
     table = {"linear": ("linear", lin_work), "gt_attention_fused_edge": ("attn", attn_work), "layer_norm": ("ln", ln_work),
              "linear_with_row_stats": ("linear_stats", gemm_work), "linear_ln_folded": ("linear_lnfold", gemm_work),
+             "gt_layer_chain": ("chain", chain_work),
              "edge_ln_residual_segment_sum": ("segsum", segsum_work), "gather_rows": ("gather", rows_work("gather_rows_kernel")),
              "gather_add_rows": ("gather_add", rows_work("gather_add_rows_kernel"))}
     saved = {n: getattr(ops, n) for n in table}

@@ -1,0 +1,210 @@
+"""Row-resident layer chain (anemoi_gt_chain_fwd, csrc/gt_chain.hip): one launch for a GraphTransformer block's projection + skip,
+LayerNorm, MLP + skip and the NEXT block's LayerNorm + fused q|k|v|self projection (reference layers/block.py:1237-1273).
+
+Checked against (a) a torch fp32 restatement with the reference's rounding points (x1, LayerNorm output, hidden, x2 in the model
+dtype - what autocast produces), (b) the launch-per-GEMM path of this package on the same inputs, and (c) under OFFSET rows
+(|row mean| / sigma up to 64: a trained residual stream need not be centred), next to the LayerNorm-fold path."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+D, HD = 512, 2048
+
+
+def _params(gen, dtype, q_out=2048, beta=True):
+    r = lambda *s: torch.randn(*s, generator=gen)  # noqa: E731
+    p = dict(
+        wp=(r(D, D) / 22).to(dtype), bp=(0.1 * r(D)).to(dtype),
+        g1=(1 + 0.2 * r(D)).to(dtype), be1=(0.1 * r(D)).to(dtype) if beta else None,
+        w1=(r(HD, D) / 22).to(dtype), b1=(0.1 * r(HD)).to(dtype),
+        w2=(r(D, HD) / 45).to(dtype), b2=(0.1 * r(D)).to(dtype),
+        gq=(1 + 0.2 * r(D)).to(dtype), beq=(0.1 * r(D)).to(dtype) if beta else None,
+        wq=(r(q_out, D) / 22).to(dtype) if q_out else None, bq=(0.1 * r(q_out)).to(dtype) if q_out else None,
+    )
+    return p
+
+
+def _reference(attn, x, p, dtype, extra=None, eps=1e-5):
+    """fp32 arithmetic on the 16-bit operands, rounded to the model dtype where the reference's autocast forward rounds."""
+    f = lambda t: None if t is None else t.float()  # noqa: E731
+    rnd = lambda t: t.to(dtype).float()  # noqa: E731
+    x1 = rnd(F.linear(f(attn), f(p["wp"]), f(p["bp"])) + f(x))
+    n1 = rnd(F.layer_norm(x1, (D,), f(p["g1"]), f(p["be1"]), eps))
+    h = rnd(F.gelu(F.linear(n1, f(p["w1"]), f(p["b1"]))))
+    x2 = rnd(F.linear(h, f(p["w2"]), f(p["b2"])) + x1)
+    if extra is not None:
+        x2 = rnd(x2 + f(extra))
+    q = None
+    if p["wq"] is not None:
+        nq = rnd(F.layer_norm(x2, (D,), f(p["gq"]), f(p["beq"]), eps))
+        q = F.linear(nq, f(p["wq"]), f(p["bq"]))
+    return x2, q
+
+
+def _run_chain(ops, attn, x, p, extra=None, rows_per_tile=0):
+    d = lambda t: None if t is None else t.to(DEV)  # noqa: E731
+    kw = {}
+    if p["wq"] is not None:
+        kw = dict(lnq_w=d(p["gq"]), lnq_b=d(p["beq"]), lnq_eps=1e-5, wq=ops.pack_weight_frag(d(p["wq"])), bq=d(p["bq"]))
+    return ops.gt_layer_chain(d(attn), d(x), ops.pack_weight_frag(d(p["wp"])), d(p["bp"]), d(p["g1"]), d(p["be1"]), 1e-5,
+                              ops.pack_weight_frag(d(p["w1"])), d(p["b1"]), ops.pack_weight_frag(d(p["w2"])), d(p["b2"]), extra=d(extra),
+                              rows_per_tile=rows_per_tile, **kw)
+
+
+def _close(got, want, what, tol=2e-2):
+    got, want = got.float().cpu(), want.float().cpu()
+    scale = float(want.abs().max())
+    err = (got - want).abs()
+    bound = tol * max(scale, 1e-3) + tol * want.abs()
+    assert bool((err <= bound).all()), f"{what}: max err {float(err.max()):.3e} at scale {scale:.3g}, mean {float(err.mean()):.3e}"
+    return float(err.max()), float(err.mean())
+
+
+def test_pack_weight_frag_layout():
+    """element (slab, ks, ni, kslot, row, e) of the image = W[slab*64 + ni*16 + row][ks*32 + kslot*8 + e] (include/anemoi_hip.h)."""
+    from anemoi_core_amd import ops
+
+    O, K = 128, 64
+    w = torch.arange(O * K, dtype=torch.float32).reshape(O, K).to(DEV)
+    img = ops.pack_weight_frag(w).reshape(O // 64, K // 32, 4, 4, 16, 8).cpu()
+    for slab, ks, ni, kslot, row, e in [(0, 0, 0, 0, 0, 0), (1, 1, 3, 2, 15, 7), (0, 1, 2, 3, 5, 4), (1, 0, 1, 1, 9, 2)]:
+        assert float(img[slab, ks, ni, kslot, row, e]) == float((slab * 64 + ni * 16 + row) * K + ks * 32 + kslot * 8 + e)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,rows_per_tile", [(41, 0), (7, 0), (1000, 0), (10242, 0), (10242, 48), (12345, 17), (40962, 0)])
+def test_chain_vs_fp32_restatement(dtype, N, rows_per_tile):
+    """every output row of x2 and of the trailing projection, ragged last panels, several panels per workgroup (40 962 rows =
+    4 rounds), panel heights that are no multiple of the 16-row MFMA band."""
+    from anemoi_core_amd import ops
+
+    gen = torch.Generator().manual_seed(N + rows_per_tile)
+    p = _params(gen, dtype)
+    attn = torch.randn(N, D, generator=gen).to(dtype)
+    x = (2.0 * torch.randn(N, D, generator=gen) + 0.5).to(dtype)
+    x2, q = _run_chain(ops, attn, x, p, rows_per_tile=rows_per_tile)
+    ref2, refq = _reference(attn, x, p, dtype)
+    _close(x2, ref2, f"x2 N={N}")
+    _close(q, refq, f"qkvs N={N}")
+    x2b, qb = _run_chain(ops, attn, x, p, rows_per_tile=rows_per_tile)
+    assert torch.equal(x2, x2b) and torch.equal(q, qb)  # deterministic
+
+
+@pytest.mark.parametrize("variant", ["no_q", "extra", "no_beta", "q1024"])
+def test_chain_variants(variant):
+    from anemoi_core_amd import ops
+
+    dtype, N = torch.bfloat16, 3000
+    gen = torch.Generator().manual_seed(7)
+    p = _params(gen, dtype, q_out={"no_q": 0, "extra": 0, "q1024": 1024}.get(variant, 2048), beta=variant != "no_beta")
+    attn = torch.randn(N, D, generator=gen).to(dtype)
+    x = torch.randn(N, D, generator=gen).to(dtype)
+    extra = (3.0 * torch.randn(N, D, generator=gen)).to(dtype) if variant == "extra" else None
+    res = _run_chain(ops, attn, x, p, extra=extra)
+    ref2, refq = _reference(attn, x, p, dtype, extra=extra)
+    if p["wq"] is None:
+        assert isinstance(res, torch.Tensor)
+        _close(res, ref2, variant)
+    else:
+        _close(res[0], ref2, variant)
+        _close(res[1], refq, variant + " q")
+
+
+def test_chain_equals_launch_per_gemm_path():
+    """the same block through this package's four-launch path (plain LayerNorm kernels between the GEMMs): equal to bf16 rounding."""
+    from anemoi_core_amd import ops
+
+    dtype, N = torch.bfloat16, 10242
+    gen = torch.Generator().manual_seed(3)
+    p = _params(gen, dtype)
+    d = lambda t: t.to(DEV)  # noqa: E731
+    attn, x = d(torch.randn(N, D, generator=gen).to(dtype)), d(torch.randn(N, D, generator=gen).to(dtype))
+    x1 = ops.linear(attn, d(p["wp"]), d(p["bp"]), residual=x)
+    h = ops.linear(ops.layer_norm(x1, d(p["g1"]), d(p["be1"]), 1e-5), d(p["w1"]), d(p["b1"]), act="gelu")
+    x2 = ops.linear(h, d(p["w2"]), d(p["b2"]), residual=x1)
+    q = ops.linear(ops.layer_norm(x2, d(p["gq"]), d(p["beq"]), 1e-5), d(p["wq"]), d(p["bq"]))
+    c2, cq = _run_chain(ops, attn.cpu(), x.cpu(), p)
+    e2 = (c2.float() - x2.float()).abs()
+    eq = (cq.float() - q.float()).abs()
+    # different accumulation order + one-ulp flips of intermediate roundings: a few ulps of the output scale, mean far below one
+    assert float(e2.max()) <= 2e-2 * float(x2.float().abs().max()) and float(e2.mean()) <= 2e-3 * float(x2.float().abs().mean() + 1)
+    assert float(eq.max()) <= 3e-2 * float(q.float().abs().max()) and float(eq.mean()) <= 4e-3 * float(q.float().abs().mean() + 1)
+
+
+@pytest.mark.parametrize("offset_over_sigma", [0.0, 4.0, 16.0, 64.0])
+def test_layernorm_under_offset_rows(offset_over_sigma):
+    """A residual stream whose rows sit at mu0 = k sigma.  The chain kernel's LayerNorm merges per-wave (mean, M2)
+    partials (no E[x^2] - mean^2), so its error against the exact-LayerNorm restatement must not grow with the offset beyond the
+    16-bit representation of the rows themselves (the reference's own operand: ulp(x) ~ |mu0| 2^-8).  The LayerNorm-FOLD path
+    (stats producer + folding consumer, still used by the mappers' source / destination sides) is measured beside it: its
+    c = row sums of the ROUNDED W gamma make rstd (x (W gamma)^T - mean c) algebraically exact in the offset; what is left is
+    the fp32 cancellation of var = E[x^2] - mean^2 (relative 2^-23 (1 + mu0^2 / sigma^2))."""
+    from anemoi_core_amd import ops
+
+    dtype, N = torch.bfloat16, 4000
+    gen = torch.Generator().manual_seed(11)
+    p = _params(gen, dtype)
+    attn = torch.randn(N, D, generator=gen).to(dtype)
+    mu0 = offset_over_sigma * (torch.rand(N, 1, generator=gen) * 2 - 1)  # per-row offsets in [-k, k] sigma
+    x = (torch.randn(N, D, generator=gen) + mu0).to(dtype)
+    x2, q = _run_chain(ops, attn, x, p)
+    ref2, refq = _reference(attn, x, p, dtype)
+    # x2 carries the offset (its scale grows with it); the projections see LayerNorm'd rows: their scale does not
+    e2 = _close(x2, ref2, f"x2 offset {offset_over_sigma}")
+    eq = _close(q, refq, f"qkvs offset {offset_over_sigma}", tol=2.5e-2)
+    # the fold path on the same rows: x1 with statistics, then LN folded into the MLP-1 GEMM
+    d = lambda t: t.to(DEV)  # noqa: E731
+    r = ops.linear_with_row_stats(d(attn), d(p["wp"]), d(p["bp"]), d(x))
+    assert r is not None
+    x1, stats = r
+    ws = (p["w1"].float() * p["g1"].float()).to(dtype)
+    c, dd = ws.float().sum(1).contiguous(), (p["w1"].float() @ p["be1"].float() + p["b1"].float()).contiguous()
+    hf = ops.linear_ln_folded(x1, d(ws), d(c), d(dd), stats, 1e-5, "gelu")
+    hu = ops.linear(ops.layer_norm(x1, d(p["g1"]), d(p["be1"]), 1e-5), d(p["w1"]), d(p["b1"]), act="gelu")
+    x1f = x1.float().cpu()
+    href = F.gelu(F.linear(F.layer_norm(x1f, (D,), p["g1"].float(), p["be1"].float(), 1e-5), p["w1"].float(), p["b1"].float()))
+    scale = float(href.abs().max())
+    ef, eu = float((hf.float().cpu() - href).abs().max()) / scale, float((hu.float().cpu() - href).abs().max()) / scale
+    print(f"offset {offset_over_sigma:5.1f} sigma: chain x2 max {e2[0]:.3e} qkvs max {eq[0]:.3e} | MLP-1 fold {ef:.3e} unfused {eu:.3e} (of scale)")
+    # bound, as a function of |mean| / sigma: both paths within 2e-2 of the output scale up to 64 sigma (the fold's extra term,
+    # 2^-23 (mu0 / sigma)^2 relative in rstd, is 5e-4 at 64 sigma: below one bf16 ulp)
+    assert ef <= 2e-2 and eu <= 2e-2
+
+
+def test_model_with_chain_equals_model_without():
+    """AnemoiModelEncProcDec at 512 channels: chain launches (encoder -> processor hand-over of the first block's projections, block
+    -> block, last block with the latent skip, decoder) against the launch-per-GEMM path of the same model, and both against the
+    fp32 CPU oracle within the full-model bf16 bound (tests/test_fullsize_parity_gpu.py)."""
+    import anemoi_core_amd.layers.block as B
+    from anemoi_core_amd.graphs.synthetic import build_synthetic_graph
+    from anemoi_core_amd.models import AnemoiModelEncProcDec
+    from anemoi_core_amd.models.configs import make_data_indices, model_config
+    from oracle import gt_oracle as O
+
+    g = build_synthetic_graph("o16", 3)
+    torch.manual_seed(0)
+    cfg = dict(kind="gt", num_channels=512, num_layers=3, num_heads=16, trainable=8, n_vars=6, n_step_input=2)
+    model = AnemoiModelEncProcDec(model_config=model_config("gt", 512, 3, 16, 8), data_indices=make_data_indices(6, 6),
+                                  statistics={"data": None}, n_step_input=2, n_step_output=1, graph_data=g).eval()
+    params = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    x = torch.randn(1, 2, 1, g.num_data, 6)
+    want = O.enc_proc_dec_forward(params, cfg, g, x)
+    m = model.to(DEV).to(torch.bfloat16)
+    xb = x.to(DEV).to(torch.bfloat16)
+    outs = {}
+    launches = {}
+    for flag in (True, False):
+        B._LAYER_CHAIN = flag
+        try:
+            with torch.no_grad():
+                outs[flag] = m({"data": xb})["data"].float().cpu()
+        finally:
+            B._LAYER_CHAIN = True
+    a, b = outs[True], outs[False]
+    scale = float(want.abs().max())
+    assert float((a - b).abs().max()) <= 3e-2 * scale and float((a - b).abs().mean()) <= 4e-3 * scale, (float((a - b).abs().max()), scale)
+    for name, y in (("chain", a), ("launch-per-GEMM", b)):
+        err = (y - want).abs()
+        assert float(err.max()) <= 6e-2 * max(scale, 1.0) and float(err.mean()) <= 1e-2 * max(scale, 1.0), (name, float(err.max()), float(err.mean()), scale)
