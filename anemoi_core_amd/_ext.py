@@ -36,5 +36,46 @@ def ops():
                 raise _lib.HipLibraryError(f"{EXT_PATH} not found: build it with `python -m anemoi_core_amd.build` "
                                            "(or set ANEMOI_TORCH_EXT=0 to stay on the ctypes binding). anemoi_core_amd has no CPU / eager fallback.")
             torch.ops.load_library(EXT_PATH)
+            _register_fakes()
             _ops = torch.ops.anemoi_hip
     return _ops
+
+
+def _register_fakes() -> None:
+    """Meta / FakeTensor kernels of ``torch.ops.anemoi_hip.*`` (shapes and dtypes only): the module path traces under
+    ``torch.compile`` / ``torch.export`` / FakeTensorMode with the ops as opaque leaves - what the reference does for its Triton op
+    with ``register_fake`` (models/src/anemoi/models/triton/gt.py:431-447, 553-556).  Output shapes are exactly those of
+    csrc/torch_binding.cpp; the two LayerNorm-fold ops report the 'shape not eligible' sentinel (1-D empty) by the same shape rule."""
+    fake = torch.library.register_fake
+
+    @fake("anemoi_hip::linear")
+    def _(x, weight, bias, act, residual, x2, g1, idx1, g2, idx2):
+        return x.new_empty((x.shape[0], weight.shape[0]))
+
+    @fake("anemoi_hip::linear_out")
+    def _(x, weight, bias, act, residual, x2, g1, idx1, g2, idx2, out):
+        return None
+
+    @fake("anemoi_hip::layer_norm")
+    def _(x, weight, bias, eps, residual):
+        return x.new_empty(x.shape)
+
+    @fake("anemoi_hip::layer_norm_out")
+    def _(x, weight, bias, eps, residual, out):
+        return None
+
+    @fake("anemoi_hip::gt_attention_fused_edge")
+    def _(q, k, v, edge_feat, w_packed, row, colptr, order, n_src, num_heads, addend, return_lse):
+        n_dst = q.shape[0]
+        return q.new_empty((n_dst, q.shape[1])), q.new_empty((n_dst if return_lse else 0, num_heads), dtype=torch.float32)
+
+    @fake("anemoi_hip::linear_with_row_stats")
+    def _(x, weight, bias, residual):
+        N, K, O = x.shape[0], x.shape[1], weight.shape[0]
+        if x.dtype == torch.float32 or O % 64 or K % 64:
+            return x.new_empty((0,)), x.new_empty((0,), dtype=torch.float32)
+        return x.new_empty((N, O)), x.new_empty((N, O // 64, 2), dtype=torch.float32)
+
+    @fake("anemoi_hip::linear_ln_folded")
+    def _(x, w_scaled, c, d, stats, eps, act):
+        return x.new_empty((x.shape[0], w_scaled.shape[0]))

@@ -1,0 +1,465 @@
+// Row-resident chains of the GraphConv (GNN) processor block for gfx950 - the two MLPs of reference layers/conv.py:29-81 and
+// layers/block.py:361-395, each as ONE launch on the machinery of chain_core.h (a 48-row panel in LDS, fragment-major weights
+// streamed into MFMA operand registers):
+//
+//  edge chain   e' = LayerNorm(W_2 gelu(W_1 gelu(W_e e + (x W_i^T)[dst] + (x W_j^T)[src] + b_0) + b_1) + b_2) + e
+//      = GraphConv's edge MLP on cat[x_i, x_j, e] in its gather-add form (the two node-level terms are precomputed rows, gathered in
+//      the first epilogue) + the trailing LayerNorm and residual.  Replaces three edge-level [M x 512] -> 512 GEMM launches and
+//      the LayerNorm half of edge_ln_res_segsum: 251 us per processor layer at M = 81 840, of which the GEMMs' intermediates are
+//      4 x 84 MB of HBM round trips.  Here only e is read and e' written; the segment sum over e' is anemoi_segment_sum_rows.
+//  node chain   x' = LayerNorm(W_c gelu(W_b gelu(W_a [x | agg] + b_a) + b_b) + b_c) + x, and optionally the NEXT block's stacked
+//      node-level projection [x' W_i'^T | x' W_j'^T] (the gather operands of its edge chain).
+//
+// Why the row-resident form pays HERE when it did not for the GraphTransformer block: a panel needs 1.5 MB
+// (edge chain) / 2.5-3.5 MB (node chain) of weights through its CU's L1 instead of 6.5 MB, against launches whose K = N = 512
+// GEMMs sit on their fixed costs and on HBM round trips of the [M, 512] intermediates.
+#include "chain_core.h"
+
+namespace anemoi {
+
+struct EdgeChainArgs {
+  const void* e;   int64_t ld_e;            // [M, 512] edge features (A operand of the first GEMM and the residual)
+  const void* g1;  int64_t ld_g1; const int32_t* idx1;  // rows added in the first epilogue: g1[idx1[m]] (x W_i^T by destination)
+  const void* g2;  int64_t ld_g2; const int32_t* idx2;  //                                  g2[idx2[m]] (x W_j^T by source)
+  const char* w0;  const void* b0;          // fragment-major [512, 512] each
+  const char* w1;  const void* b1;
+  const char* w2;  const void* b2;
+  const void* ln_g; const void* ln_b; float ln_eps;
+  void* e_new;     int64_t ld_o;
+  int n_rows, rows_per_tile, n_tiles;
+};
+
+template <typename T>
+__global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const bufA = smem;                  // e panel: operand of GEMM 1, residual of the LayerNorm
+  unsigned char* const bufB = smem + kBufBytes;      // h1; later the staging strips of the stores
+  unsigned char* const bufC = smem + 2 * kBufBytes;  // h2
+  float* const red = reinterpret_cast<float*>(smem + kRedOff);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4;
+  const uint32_t loff = lane * 16;
+  const char* const w0 = a.w0 + (int64_t)wave * kSlab;
+  const char* const w1 = a.w1 + (int64_t)wave * kSlab;
+  const char* const w2 = a.w2 + (int64_t)wave * kSlab;
+  const u32x4 zero4 = u32x4{0u, 0u, 0u, 0u};
+
+  int tile = blockIdx.x;
+  if (tile >= a.n_tiles) return;
+  u32x4 va[6];
+  auto request_panel = [&](int t) {
+    const int r0 = t * a.rows_per_tile;
+    const int nr = min(a.rows_per_tile, a.n_rows - r0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int idx = tid + 512 * i;
+      const int rr = min(idx >> 6, nr - 1), slot = idx & 63;
+      va[i] = *reinterpret_cast<const u32x4*>((const T*)a.e + (int64_t)(r0 + rr) * a.ld_e + slot * 8);
+    }
+  };
+  request_panel(tile);
+  __builtin_amdgcn_sched_barrier(0);
+  frag8 bq[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      bq[j][ni] = *reinterpret_cast<gfrag_t>(uniform_ptr(w0 + j * 4096) + loff + ni * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+  for (;;) {
+    const int r0 = tile * a.rows_per_tile;
+    const int nr = min(a.rows_per_tile, a.n_rows - r0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int idx = tid + 512 * i;
+      const int row = idx >> 6, slot = idx & 63;
+      *reinterpret_cast<u32x4*>(bufA + row * kRowBytes + ((slot ^ (row & 15)) << 4)) = row < nr ? va[i] : zero4;
+    }
+    lds_barrier();
+    // the gathered node-level rows of this lane's 3 panel rows (index, then 2 x 4 x 8 bytes per row) and the first bias: in flight
+    // under the first GEMM
+    u32x2 ga[3][4], gb[3][4], pb[4];
+    {
+      const LaneCtx lc = lane_ctx(lane, wave);
+#pragma unroll
+      for (int mi = 0; mi < 3; ++mi) {
+        const int m = r0 + min(mi * 16 + lc.x, nr - 1);
+        const T* r1 = (const T*)a.g1 + (int64_t)a.idx1[m] * a.ld_g1 + wave * 64 + lc.g * 4;
+        const T* r2 = (const T*)a.g2 + (int64_t)a.idx2[m] * a.ld_g2 + wave * 64 + lc.g * 4;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          ga[mi][ni] = *reinterpret_cast<const u32x2*>(r1 + ni * 16);
+          gb[mi][ni] = *reinterpret_cast<const u32x2*>(r2 + ni * 16);
+        }
+      }
+    }
+    load_cols<T>((const T*)a.b0, wave, g, pb);
+    __builtin_amdgcn_sched_barrier(0);
+
+    f32x4 acc[3][4];
+    // ---- h1 = gelu(e W_e^T + g1[dst] + g2[src] + b0) -> bufB
+    zero_acc<T>(acc);
+    gemm_seg<T>(bufA, lane, bq, w0, w1, loff, acc);
+    {
+      const LaneCtx lc = lane_ctx(lane, wave);
+#pragma unroll
+      for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          float bias[4], t1[4], t2[4], t[4];
+          unpack4<T>(pb[ni], bias);
+          unpack4<T>(ga[mi][ni], t1);
+          unpack4<T>(gb[mi][ni], t2);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) t[r] = (acc[mi][ni][r] + bias[r]) + (t1[r] + t2[r]);  // the association of linear.hip's gather-add epilogue
+          gelu_fast2(t[0], t[1]);
+          gelu_fast2(t[2], t[3]);
+          *reinterpret_cast<u32x2*>(bufB + (mi * 16 + lc.x) * kRowBytes + lc.coff[ni]) = pack4<T>(t);
+        }
+    }
+    load_cols<T>((const T*)a.b1, wave, g, pb);
+    __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();
+    // ---- h2 = gelu(h1 W_1^T + b1) -> bufC
+    zero_acc<T>(acc);
+    gemm_seg<T>(bufB, lane, bq, w1, w2, loff, acc);
+    {
+      const LaneCtx lc = lane_ctx(lane, wave);
+#pragma unroll
+      for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          float bias[4], t[4];
+          unpack4<T>(pb[ni], bias);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) t[r] = acc[mi][ni][r] + bias[r];
+          gelu_fast2(t[0], t[1]);
+          gelu_fast2(t[2], t[3]);
+          *reinterpret_cast<u32x2*>(bufC + (mi * 16 + lc.x) * kRowBytes + lc.coff[ni]) = pack4<T>(t);
+        }
+    }
+    u32x2 pg[4], pt[4];
+    load_cols<T>((const T*)a.b2, wave, g, pb);
+    load_cols<T>((const T*)a.ln_g, wave, g, pg);
+    if (a.ln_b != nullptr) {
+      load_cols<T>((const T*)a.ln_b, wave, g, pt);
+    } else {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) pt[ni] = u32x2{0u, 0u};
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();
+    // ---- z = h2 W_2^T + b2 (rounded, as the Linear's output is); e' = LayerNorm(z) + e -> global
+    zero_acc<T>(acc);
+    gemm_seg<T>(bufC, lane, bq, w2, w0, loff, acc);  // (behind it: the next panel's first segment; after the last panel a harmless re-read)
+    const int next_tile = tile + (int)gridDim.x;
+    const bool more = next_tile < a.n_tiles;
+    if (more) request_panel(next_tile);  // the next panel's rows travel under this panel's LayerNorm and stores
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const LaneCtx lc = lane_ctx(lane, wave);
+#pragma unroll
+      for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          float bias[4], t[4];
+          unpack4<T>(pb[ni], bias);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) t[r] = acc[mi][ni][r] + bias[r];
+          unpack4<T>(pack4<T>(t), t);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[mi][ni][r] = t[r];
+        }
+      float mean[3], rstd[3];
+      panel_row_stats<T>(acc, a.ln_eps, red, wave, lc.x, lc.g, mean, rstd);  // (one barrier: behind it no wave reads bufB / bufC)
+      u32x2 pk[3][4];
+#pragma unroll
+      for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          float gv[4], bv[4], ev[4], o[4];
+          unpack4<T>(pg[ni], gv);
+          unpack4<T>(pt[ni], bv);
+          unpack4<T>(*reinterpret_cast<const u32x2*>(bufA + (mi * 16 + lc.x) * kRowBytes + lc.coff[ni]), ev);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = fmaf((acc[mi][ni][r] - mean[mi]) * rstd[mi], gv[r], bv[r]) + ev[r];  // edge_ln_res_segsum's arithmetic
+          pk[mi][ni] = pack4<T>(o);
+        }
+      store_block_via_strip<T>(pk, bufB + wave * (kPanel * 128), (T*)a.e_new + (int64_t)r0 * a.ld_o + wave * 64, a.ld_o, nr, lane, wave);
+    }
+    if (!more) break;
+    tile = next_tile;
+    lds_barrier();  // every wave has read its residual values from bufA and emptied its strip
+  }
+}
+
+struct NodeChainArgs {
+  const void* x;    int64_t ld_x;           // [N, 512] node rows (first K half of the first GEMM; the residual)
+  const void* agg;  int64_t ld_a;           // [N, 512] aggregated messages (second K half)
+  const char* wa;   const void* ba;         // fragment-major [512, 1024]
+  const char* wb;   const void* bb;         // fragment-major [512, 512]
+  const char* wc;   const void* bc;
+  const void* ln_g; const void* ln_b; float ln_eps;
+  void* x_out;      int64_t ld_o;
+  const char* wt;   const void* bt; int tc;  // optional trailing projection [512 tc, 512] of x_out (bt may be null: no bias); tc = 0: none
+  void* t_out;      int64_t ld_t;
+  int n_rows, rows_per_tile, n_tiles;
+};
+
+template <typename T>
+__global__ __launch_bounds__(512, 1) void gnn_node_chain_kernel(NodeChainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const bufA = smem;                  // x panel: operand of GEMM 1a, residual of the LayerNorm
+  unsigned char* const bufB = smem + kBufBytes;      // h1; later x' as the trailing projection's operand
+  unsigned char* const bufC = smem + 2 * kBufBytes;  // agg panel (GEMM 1b), then h2, then the staging strips
+  float* const red = reinterpret_cast<float*>(smem + kRedOff);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4;
+  const uint32_t loff = lane * 16;
+  const char* const wa0 = a.wa + (int64_t)wave * 2 * kSlab;  // K = 1024: two segments per slab
+  const char* const wb0 = a.wb + (int64_t)wave * kSlab;
+  const char* const wc0 = a.wc + (int64_t)wave * kSlab;
+  const char* const wt0 = a.tc > 0 ? a.wt + (int64_t)wave * kSlab : wa0;  // + c * 8 slabs
+  const u32x4 zero4 = u32x4{0u, 0u, 0u, 0u};
+
+  int tile = blockIdx.x;
+  if (tile >= a.n_tiles) return;
+  u32x4 va[6], vb[6];
+  auto request_panel = [&](int t) {
+    const int r0 = t * a.rows_per_tile;
+    const int nr = min(a.rows_per_tile, a.n_rows - r0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int idx = tid + 512 * i;
+      const int rr = min(idx >> 6, nr - 1), slot = idx & 63;
+      va[i] = *reinterpret_cast<const u32x4*>((const T*)a.x + (int64_t)(r0 + rr) * a.ld_x + slot * 8);
+      vb[i] = *reinterpret_cast<const u32x4*>((const T*)a.agg + (int64_t)(r0 + rr) * a.ld_a + slot * 8);
+    }
+  };
+  request_panel(tile);
+  __builtin_amdgcn_sched_barrier(0);
+  frag8 bq[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      bq[j][ni] = *reinterpret_cast<gfrag_t>(uniform_ptr(wa0 + j * 4096) + loff + ni * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+  for (;;) {
+    const int r0 = tile * a.rows_per_tile;
+    const int nr = min(a.rows_per_tile, a.n_rows - r0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int idx = tid + 512 * i;
+      const int row = idx >> 6, slot = idx & 63;
+      const int off = row * kRowBytes + ((slot ^ (row & 15)) << 4);
+      *reinterpret_cast<u32x4*>(bufA + off) = row < nr ? va[i] : zero4;
+      *reinterpret_cast<u32x4*>(bufC + off) = row < nr ? vb[i] : zero4;
+    }
+    u32x2 pb[4];
+    load_cols<T>((const T*)a.ba, wave, g, pb);
+    __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();
+
+    f32x4 acc[3][4];
+    // ---- h1 = gelu([x | agg] W_a^T + b_a) -> bufB
+    zero_acc<T>(acc);
+    gemm_seg<T>(bufA, lane, bq, wa0, wa0 + kSlab, loff, acc);
+    gemm_seg<T>(bufC, lane, bq, wa0 + kSlab, wb0, loff, acc);
+    {
+      const LaneCtx lc = lane_ctx(lane, wave);
+#pragma unroll
+      for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          float bias[4], t[4];
+          unpack4<T>(pb[ni], bias);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) t[r] = acc[mi][ni][r] + bias[r];
+          gelu_fast2(t[0], t[1]);
+          gelu_fast2(t[2], t[3]);
+          *reinterpret_cast<u32x2*>(bufB + (mi * 16 + lc.x) * kRowBytes + lc.coff[ni]) = pack4<T>(t);
+        }
+    }
+    load_cols<T>((const T*)a.bb, wave, g, pb);
+    __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();  // h1 complete; every wave is done with the agg panel
+    // ---- h2 = gelu(h1 W_b^T + b_b) -> bufC
+    zero_acc<T>(acc);
+    gemm_seg<T>(bufB, lane, bq, wb0, wc0, loff, acc);
+    {
+      const LaneCtx lc = lane_ctx(lane, wave);
+#pragma unroll
+      for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          float bias[4], t[4];
+          unpack4<T>(pb[ni], bias);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) t[r] = acc[mi][ni][r] + bias[r];
+          gelu_fast2(t[0], t[1]);
+          gelu_fast2(t[2], t[3]);
+          *reinterpret_cast<u32x2*>(bufC + (mi * 16 + lc.x) * kRowBytes + lc.coff[ni]) = pack4<T>(t);
+        }
+    }
+    u32x2 pg[4], pt[4];
+    load_cols<T>((const T*)a.bc, wave, g, pb);
+    load_cols<T>((const T*)a.ln_g, wave, g, pg);
+    if (a.ln_b != nullptr) {
+      load_cols<T>((const T*)a.ln_b, wave, g, pt);
+    } else {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) pt[ni] = u32x2{0u, 0u};
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();
+    // ---- y = h2 W_c^T + b_c (rounded); x' = LayerNorm(y) + x -> global (and bufB for the trailing projection)
+    zero_acc<T>(acc);
+    gemm_seg<T>(bufC, lane, bq, wc0, a.tc > 0 ? wt0 : wa0, loff, acc);
+    const int next_tile = tile + (int)gridDim.x;
+    const bool more = next_tile < a.n_tiles;
+    unsigned char* const strip = bufC + wave * (kPanel * 128);  // behind the statistics' barrier no wave reads bufC any more
+    {
+      const LaneCtx lc = lane_ctx(lane, wave);
+#pragma unroll
+      for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          float bias[4], t[4];
+          unpack4<T>(pb[ni], bias);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) t[r] = acc[mi][ni][r] + bias[r];
+          unpack4<T>(pack4<T>(t), t);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[mi][ni][r] = t[r];
+        }
+      float mean[3], rstd[3];
+      panel_row_stats<T>(acc, a.ln_eps, red, wave, lc.x, lc.g, mean, rstd);
+      u32x2 pk[3][4];
+#pragma unroll
+      for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          float gv[4], bv[4], xv[4], o[4];
+          unpack4<T>(pg[ni], gv);
+          unpack4<T>(pt[ni], bv);
+          unpack4<T>(*reinterpret_cast<const u32x2*>(bufA + (mi * 16 + lc.x) * kRowBytes + lc.coff[ni]), xv);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = fmaf((acc[mi][ni][r] - mean[mi]) * rstd[mi], gv[r], bv[r]) + xv[r];  // layernorm_fwd's arithmetic (+ residual)
+          pk[mi][ni] = pack4<T>(o);
+          if (a.tc > 0) *reinterpret_cast<u32x2*>(bufB + (mi * 16 + lc.x) * kRowBytes + lc.coff[ni]) = pk[mi][ni];
+        }
+      store_block_via_strip<T>(pk, strip, (T*)a.x_out + (int64_t)r0 * a.ld_o + wave * 64, a.ld_o, nr, lane, wave);
+    }
+    if (a.tc > 0) {
+      lds_barrier();  // x' panel complete
+      for (int c = 0; c < a.tc; ++c) {
+        if (a.bt != nullptr) {
+          load_cols<T>((const T*)a.bt + c * kCh, wave, g, pb);
+        } else {
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) pb[ni] = u32x2{0u, 0u};
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        zero_acc<T>(acc);
+        gemm_seg<T>(bufB, lane, bq, wt0 + (int64_t)c * 8 * kSlab, c + 1 < a.tc ? wt0 + (int64_t)(c + 1) * 8 * kSlab : wa0, loff, acc);
+        u32x2 pk[3][4];
+#pragma unroll
+        for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) {
+            float bias[4], o[4];
+            unpack4<T>(pb[ni], bias);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = acc[mi][ni][r] + bias[r];
+            pk[mi][ni] = pack4<T>(o);
+          }
+        store_block_via_strip<T>(pk, strip, (T*)a.t_out + (int64_t)r0 * a.ld_t + c * kCh + wave * 64, a.ld_t, nr, lane, wave);
+      }
+    }
+    if (!more) break;
+    tile = next_tile;
+    request_panel(tile);
+    __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();  // every wave is done with this panel's buffers
+  }
+}
+
+static int chain_rows_per_tile(int n_rows) {
+  static const int forced = env_int(getenv("ANEMOI_CHAIN_ROWS"), 0, 0, kPanel);
+  if (forced > 0) return forced;
+  const int64_t rounds = ((int64_t)n_rows + 256 * kPanel - 1) / (256 * kPanel);
+  const int64_t r = ((int64_t)n_rows + 256 * rounds - 1) / (256 * rounds);
+  return (int)(r < 1 ? 1 : (r > kPanel ? kPanel : r));
+}
+
+}  // namespace anemoi
+
+using namespace anemoi;
+
+static bool al(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+
+extern "C" int anemoi_gnn_edge_chain_fwd(const void* e, int64_t ld_e, const void* g1, int64_t ld_g1, const int32_t* idx1, const void* g2,
+                                         int64_t ld_g2, const int32_t* idx2, const void* w0, const void* b0, const void* w1, const void* b1,
+                                         const void* w2, const void* b2, const void* ln_w, const void* ln_b, float eps, void* e_new,
+                                         int64_t ld_o, int32_t n_rows, int32_t channels, anemoi_dtype_t dtype, void* stream) {
+  ANEMOI_REQUIRE(dtype == ANEMOI_BF16 || dtype == ANEMOI_F16, "gnn_edge_chain_fwd: 16-bit model dtypes only");
+  ANEMOI_REQUIRE(n_rows >= 0 && channels == kCh, "gnn_edge_chain_fwd: channels=%d (this kernel is built for %d)", channels, kCh);
+  if (n_rows == 0) return ANEMOI_OK;
+  ANEMOI_REQUIRE(e && g1 && idx1 && g2 && idx2 && w0 && b0 && w1 && b1 && w2 && b2 && ln_w && e_new, "gnn_edge_chain_fwd: null operand");
+  ANEMOI_REQUIRE(al(e, 16) && al(e_new, 16) && al(w0, 16) && al(w1, 16) && al(w2, 16) && al(g1, 8) && al(g2, 8) && al(b0, 8) && al(b1, 8) && al(b2, 8) &&
+                     al(ln_w, 8) && al(ln_b, 8) && ld_e % 8 == 0 && ld_o % 8 == 0 && ld_g1 % 4 == 0 && ld_g2 % 4 == 0 && ld_e >= kCh && ld_o >= kCh &&
+                     ld_g1 >= kCh && ld_g2 >= kCh,
+                 "gnn_edge_chain_fwd: operand alignment / leading dimensions");
+  EdgeChainArgs a{e, ld_e, g1, ld_g1, idx1, g2, ld_g2, idx2, (const char*)w0, b0, (const char*)w1, b1, (const char*)w2, b2, ln_w, ln_b, eps, e_new, ld_o,
+                  n_rows, chain_rows_per_tile(n_rows), 0};
+  a.n_tiles = (n_rows + a.rows_per_tile - 1) / a.rows_per_tile;
+  const int grid = a.n_tiles < 256 ? a.n_tiles : 256;
+  hipStream_t st = as_stream(stream);
+  if (dtype == ANEMOI_BF16) {
+    static PerDeviceOnce once;
+    once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gnn_edge_chain_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, kChainSmem); });
+    hipLaunchKernelGGL((gnn_edge_chain_kernel<bf16_t>), dim3(grid), dim3(512), kChainSmem, st, a);
+  } else {
+    static PerDeviceOnce once;
+    once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gnn_edge_chain_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, kChainSmem); });
+    hipLaunchKernelGGL((gnn_edge_chain_kernel<f16_t>), dim3(grid), dim3(512), kChainSmem, st, a);
+  }
+  return check_launch("gnn_edge_chain_kernel");
+}
+
+extern "C" int anemoi_gnn_node_chain_fwd(const void* x, int64_t ld_x, const void* agg, int64_t ld_a, const void* wa, const void* ba, const void* wb,
+                                         const void* bb, const void* wc, const void* bc, const void* ln_w, const void* ln_b, float eps, void* x_out,
+                                         int64_t ld_o, const void* wt, const void* bt, int32_t t_out_features, void* t_out, int64_t ld_t,
+                                         int32_t n_rows, int32_t channels, anemoi_dtype_t dtype, void* stream) {
+  ANEMOI_REQUIRE(dtype == ANEMOI_BF16 || dtype == ANEMOI_F16, "gnn_node_chain_fwd: 16-bit model dtypes only");
+  ANEMOI_REQUIRE(n_rows >= 0 && channels == kCh, "gnn_node_chain_fwd: channels=%d (this kernel is built for %d)", channels, kCh);
+  if (n_rows == 0) return ANEMOI_OK;
+  ANEMOI_REQUIRE(x && agg && wa && ba && wb && bb && wc && bc && ln_w && x_out, "gnn_node_chain_fwd: null operand");
+  ANEMOI_REQUIRE(t_out_features >= 0 && t_out_features % kCh == 0 && (t_out_features == 0 || (wt && t_out && ld_t >= t_out_features && ld_t % 8 == 0 && al(t_out, 16) && al(wt, 16))),
+                 "gnn_node_chain_fwd: the trailing projection needs wt, t_out and t_out_features %% %d == 0", kCh);
+  ANEMOI_REQUIRE(al(x, 16) && al(agg, 16) && al(x_out, 16) && al(wa, 16) && al(wb, 16) && al(wc, 16) && al(ba, 8) && al(bb, 8) && al(bc, 8) && al(bt, 8) &&
+                     al(ln_w, 8) && al(ln_b, 8) && ld_x % 8 == 0 && ld_a % 8 == 0 && ld_o % 8 == 0 && ld_x >= kCh && ld_a >= kCh && ld_o >= kCh,
+                 "gnn_node_chain_fwd: operand alignment / leading dimensions");
+  NodeChainArgs a{x, ld_x, agg, ld_a, (const char*)wa, ba, (const char*)wb, bb, (const char*)wc, bc, ln_w, ln_b, eps, x_out, ld_o,
+                  (const char*)wt, bt, t_out_features / kCh, t_out, ld_t, n_rows, chain_rows_per_tile(n_rows), 0};
+  a.n_tiles = (n_rows + a.rows_per_tile - 1) / a.rows_per_tile;
+  const int grid = a.n_tiles < 256 ? a.n_tiles : 256;
+  hipStream_t st = as_stream(stream);
+  if (dtype == ANEMOI_BF16) {
+    static PerDeviceOnce once;
+    once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gnn_node_chain_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, kChainSmem); });
+    hipLaunchKernelGGL((gnn_node_chain_kernel<bf16_t>), dim3(grid), dim3(512), kChainSmem, st, a);
+  } else {
+    static PerDeviceOnce once;
+    once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gnn_node_chain_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, kChainSmem); });
+    hipLaunchKernelGGL((gnn_node_chain_kernel<f16_t>), dim3(grid), dim3(512), kChainSmem, st, a);
+  }
+  return check_launch("gnn_node_chain_kernel");
+}

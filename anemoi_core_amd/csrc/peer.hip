@@ -95,6 +95,7 @@ __global__ __launch_bounds__(kPeerThreads) void peer_exchange_kernel(PeerArgs a)
   // ---- last workgroup: every workgroup's rows are released; signal the peers, wait for theirs
   const uint32_t epoch = s_epoch;
   if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the other workgroups' releases, through their tickets
+  const uint64_t t_released = wall_clock64();
   __syncthreads();
   if ((int)threadIdx.x < a.P) {
     const int p = threadIdx.x;
@@ -120,6 +121,13 @@ __global__ __launch_bounds__(kPeerThreads) void peer_exchange_kernel(PeerArgs a)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // pairs with the peers' releases; the rows themselves are read by LATER kernels
     __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(seq, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // diagnostics in the status block (words 2-4; exchanges of a stream are serialised, one writer): how many exchanges ran, the
+    // 100 MHz ticks between "all my rows released" and "every expected peer's flag seen" summed over them, and the longest one -
+    // what a first run on real xGMI links needs next to the time-out word (bench.py prints them per rank)
+    const uint32_t dt = (uint32_t)(wall_clock64() - t_released);
+    a.status[2] += 1u;
+    a.status[3] += dt;
+    if (dt > a.status[4]) a.status[4] = dt;
   }
 }
 

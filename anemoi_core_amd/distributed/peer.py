@@ -95,6 +95,7 @@ class PeerWire:
         self._agree((None, None, os.getpid(), err), "opening the peers' arenas")
         self.payload = _view(self.payload_ptr, self.arena_bytes, self.device, self)
         self.status = _view(self.flag_ptr, 4, self.device, self).view(torch.int32)
+        self._diag = _view(self.flag_ptr, 4 * _HDR_WORDS, self.device, self).view(torch.int32)  # words 2-4: exchange diagnostics (csrc/peer.hip)
         self._bump = 0
         self._channels: list = []
         self._seq = 0
@@ -321,6 +322,18 @@ class PeerWire:
         bad = [(p, e) for p, e in enumerate(everyone) if e is not None]
         if bad:
             raise PeerWireError("hipIpc wire self-test failed: " + "; ".join(f"rank {p}: {m}" for p, m in bad))
+
+    def stats(self, reset: bool = True) -> dict:
+        """Exchange diagnostics since the last reset (synchronises): exchanges run, the time between "my rows released" and "every
+        expected peer's flag seen" summed over them and the longest one [us], and the peer of a time-out (None: none)."""
+        torch.cuda.synchronize()
+        w = [int(v) & 0xFFFFFFFF for v in self._diag[:5].tolist()]
+        if reset:
+            self._diag[2:5].zero_()
+            torch.cuda.synchronize()
+        us = 1e6 / _TICKS_PER_S
+        return {"exchanges": w[2], "wait_us_total": round(w[3] * us, 1), "wait_us_max": round(w[4] * us, 1),
+                "timeout_peer": (w[0] & 0xFFFF) if w[0] else None}
 
     def check(self) -> None:
         """Raise if a wait of this rank timed out (synchronises)."""

@@ -47,6 +47,10 @@ _LN_FOLD_MIN_ROWS = int(os.environ.get("ANEMOI_LN_FOLD_MIN_ROWS", "512"))
 # (ANEMOI_LAYER_CHAIN=1), kept under test with its in-kernel timeline (tools/chain_timeline.py).
 _LAYER_CHAIN = os.environ.get("ANEMOI_LAYER_CHAIN", "0") == "1"
 _LAYER_CHAIN_MIN_ROWS = int(os.environ.get("ANEMOI_LAYER_CHAIN_MIN_ROWS", "0"))
+# The GraphConv (GNN) processor block's edge MLP + LayerNorm + residual and its node MLP + LayerNorm + skip (+ the next block's stacked
+# node-level projection) as ONE launch each (ops.gnn_edge_chain / gnn_node_chain, csrc/gnn_chain.hip).  ANEMOI_GNN_CHAIN=0: the
+# launch-per-GEMM path (same-box A/Bs).
+_GNN_CHAIN = os.environ.get("ANEMOI_GNN_CHAIN", "1") == "1"
 
 
 _IDENTITY: dict = {}
@@ -114,6 +118,18 @@ class _FusedWeights:
             wf = ops.pack_weight_frag(w)
         self._cache["frag:" + tag] = (sig, wf, b)
         return wf, b
+
+    def derived(self, tag: str, params: list, builder):
+        """``builder()`` cached until one of ``params`` changes (fragment-major images of weight slices / stacks)."""
+        ps = [p for p in params if p is not None]
+        sig = tuple((p.data_ptr(), version(p), p.dtype, str(p.device)) for p in ps)
+        hit = self._cache.get("der:" + tag)
+        if hit is not None and hit[0] == sig:
+            return hit[1]
+        with torch.no_grad():
+            val = builder()
+        self._cache["der:" + tag] = (sig, val)
+        return val
 
     def packed_edge(self, lin_edge) -> Tensor:
         """fp32 [D, fe_pad] image of lin_edge for the fused attention, rebuilt only when the parameters change."""
@@ -626,10 +642,75 @@ class GraphConvBaseBlock(BaseBlock):
 
 
 class GraphConvProcessorBlock(GraphConvBaseBlock):
+    def _chain_ok(self, x: Tensor, edge_attr: Tensor) -> bool:
+        """The row-resident chain kernels take this block: inference, 16-bit, 512 channels, both MLPs Linear-GELU-Linear-GELU-Linear
+        with a plain affine LayerNorm (mlp_extra_layers = 0, mlp_implementation = "mlp")."""
+        D = ops.CHAIN_CHANNELS
+        em, nm = self.conv.edge_mlp, self.node_mlp
+
+        def mlp_ok(m, k_in):
+            return (m.mlp_implementation == "mlp" and len(m.mlp) == 5 and m.layer_norm is not None
+                    and type(m.layer_norm).__name__ in ("LayerNorm", "AutocastLayerNorm") and m.layer_norm.weight is not None
+                    and m.mlp[0].weight.shape == (D, k_in) and m.mlp[2].weight.shape == (D, D) and m.mlp[4].weight.shape == (D, D)
+                    and all(m.mlp[i].bias is not None for i in (0, 2, 4)))
+
+        return (_GNN_CHAIN and x.is_cuda and x.dtype != torch.float32 and x.shape[1] == D and edge_attr.shape[1] == D and edge_attr.dtype == x.dtype
+                and mlp_ok(em, 3 * D) and mlp_ok(nm, 2 * D)
+                and not (torch.is_grad_enabled() and (x.requires_grad or edge_attr.requires_grad or em.mlp[0].weight.requires_grad)))
+
+    def _stacked_frag(self) -> Tensor:
+        """fragment-major image of [W_i; W_j] (the node-level halves of the edge MLP's first Linear): the trailing projection of the
+        PREVIOUS block's node chain."""
+        w = self.conv.edge_mlp.mlp[0].weight
+        D = w.shape[0]
+        return self._fw().derived("stacked", [w], lambda: ops.pack_weight_frag(torch.cat([w[:, :D], w[:, D:2 * D]], dim=0)))
+
+    def _fw(self) -> "_FusedWeights":
+        fw = self.__dict__.get("_fused_w")
+        if fw is None:
+            fw = self.__dict__["_fused_w"] = _FusedWeights()
+        return fw
+
+    def _forward_chain(self, x: Tensor, edge_attr: Tensor, edge_index: Tensor, chain: Optional[dict], next_block):
+        D = ops.CHAIN_CHANNELS
+        n = x.shape[0]
+        csc = get_csc(edge_index, (n, n), True)
+        em, nm, fw = self.conv.edge_mlp, self.node_mlp, self._fw()
+        p = None
+        if chain is not None and chain.get("p_x") is x:  # the previous block's node chain computed this block's stacked node-level terms
+            p = chain["p"]
+        if chain is not None:
+            chain.clear()
+        if p is None:
+            p = ops.linear(x, self.conv._stacked_node_weight(em.mlp[0].weight, D))
+        w0 = fw.derived("w0e", [em.mlp[0].weight], lambda: ops.pack_weight_frag(em.mlp[0].weight[:, 2 * D:]))
+        w1 = fw.derived("e1", [em.mlp[2].weight], lambda: ops.pack_weight_frag(em.mlp[2].weight))
+        w2 = fw.derived("e2", [em.mlp[4].weight], lambda: ops.pack_weight_frag(em.mlp[4].weight))
+        ln = em.layer_norm
+        e_new = ops.gnn_edge_chain(edge_attr, p[:, :D], csc.dst, p[:, D:], csc.row, w0, em.mlp[0].bias, w1, em.mlp[2].bias, w2, em.mlp[4].bias,
+                                   ln.weight, ln.bias, ln.eps)
+        agg = ops.segment_sum_rows(e_new, csc.colptr)
+        wa = fw.derived("na", [nm.mlp[0].weight], lambda: ops.pack_weight_frag(nm.mlp[0].weight))
+        wb = fw.derived("nb", [nm.mlp[2].weight], lambda: ops.pack_weight_frag(nm.mlp[2].weight))
+        wc = fw.derived("nc", [nm.mlp[4].weight], lambda: ops.pack_weight_frag(nm.mlp[4].weight))
+        ln = nm.layer_norm
+        kw = {}
+        if chain is not None and isinstance(next_block, GraphConvProcessorBlock) and next_block._chain_ok(x, e_new):
+            kw = dict(wt=next_block._stacked_frag(), t_out_features=2 * D)
+        res = ops.gnn_node_chain(x, agg, wa, nm.mlp[0].bias, wb, nm.mlp[2].bias, wc, nm.mlp[4].bias, ln.weight, ln.bias, ln.eps, **kw)
+        if kw:
+            chain["p_x"], chain["p"] = res
+            return res[0], e_new
+        return res, e_new
+
     def forward(self, x: Tensor, edge_attr: Tensor, edge_index: Tensor, shard_info: GraphShardInfo, model_comm_group=None,
                 size=None, **layer_kwargs):
         if self.emb_edges is not None:
             edge_attr = self.emb_edges(edge_attr)
+        chain = layer_kwargs.get("gnn_chain")
+        nxt = None if chain is None else chain.pop("next_block", None)
+        if not model_is_distributed(model_comm_group) and self._chain_ok(x, edge_attr):
+            return self._forward_chain(x, edge_attr, edge_index, chain, nxt)
         if model_is_distributed(model_comm_group):  # block.py:375: all node rows are needed as sources
             x_in = comm.gather_tensor(x, 0, shard_info.nodes, model_comm_group, reduce_in_backward=True)
             n_loc = x.shape[0]

@@ -38,6 +38,8 @@ class BaseProcessor(nn.Module):
 
     def run_layers(self, data: tuple, *args, last_layer_kwargs: Optional[dict] = None, **kwargs) -> tuple:
         chain = kwargs.get("ln_chain")
+        if chain is None:
+            chain = kwargs.get("gnn_chain")
         for i, layer in enumerate(self.proc):
             extra = last_layer_kwargs if (last_layer_kwargs and i == len(self.proc) - 1) else {}
             if chain is not None:  # a block's chain launch may compute the NEXT block's LayerNorm + projections (layers/block.py)
@@ -131,5 +133,5 @@ class GNNProcessor(BaseProcessor):
             perm, rows, edge_index, edge_shard_sizes = self._shard_cache[1]
             edge_attr = take_edge_rows(edge_attr, perm, rows)
             shard_info = GraphShardInfo(nodes=shard_info.nodes, edges=edge_shard_sizes)
-        x, _ = self.run_layers((x, edge_attr), edge_index, shard_info, model_comm_group, local_edge_cache=self._local_edge_cache, **kwargs)
+        x, _ = self.run_layers((x, edge_attr), edge_index, shard_info, model_comm_group, local_edge_cache=self._local_edge_cache, gnn_chain={}, **kwargs)
         return x

@@ -813,6 +813,60 @@ def gt_layer_chain(attn: Tensor, x_res: Tensor, wp: Tensor, bp: Tensor, ln1_w: T
     return x_out if q_out is None else (x_out, q_out)
 
 
+def gnn_edge_chain(e: Tensor, g1: Tensor, idx1: Tensor, g2: Tensor, idx2: Tensor, w0: Tensor, b0: Tensor, w1: Tensor, b1: Tensor, w2: Tensor,
+                   b2: Tensor, ln_w: Tensor, ln_b: Optional[Tensor], eps: float) -> Tensor:
+    """GraphConv's edge MLP (three Linears, gather-add form) + LayerNorm + residual in ONE launch (anemoi_gnn_edge_chain_fwd):
+    ``LayerNorm(W2 gelu(W1 gelu(W0e e + g1[idx1] + g2[idx2] + b0) + b1) + b2) + e``.  ``w0, w1, w2``: fragment-major images
+    (``pack_weight_frag``) of [512, 512] weights; ``idx1 / idx2`` int32.  Inference only."""
+    _dev(e, g1, idx1, g2, idx2, w0, b0, w1, b1, w2, b2, ln_w, ln_b)
+    M, D = e.shape
+    dt = e.dtype
+    if D != CHAIN_CHANNELS or dt not in (torch.bfloat16, torch.float16):
+        raise NotImplementedError(f"gnn_edge_chain: {D} channels / {dt} (built for {CHAIN_CHANNELS} channels, 16-bit dtypes)")
+    for name, w in (("w0", w0), ("w1", w1), ("w2", w2)):
+        if w.dim() != 1 or w.numel() != D * D or w.dtype != dt or not w.is_contiguous():
+            raise ValueError(f"gnn_edge_chain: {name} must be the fragment-major image of a [{D}, {D}] weight (pack_weight_frag)")
+    for name, ix in (("idx1", idx1), ("idx2", idx2)):
+        if ix.dtype != torch.int32 or ix.dim() != 1 or ix.shape[0] != M or not ix.is_contiguous():
+            raise ValueError(f"gnn_edge_chain: {name} must be contiguous int32 [{M}]")
+    if g1.shape[1] != D or g2.shape[1] != D:
+        raise ValueError("gnn_edge_chain: the gathered tables must have 512 columns")
+    out = torch.empty((M, D), dtype=dt, device=e.device)
+    (ep, lde), (p1, ld1), (p2, ld2) = _rows(e, "e", dt), _rows(g1, "g1", dt), _rows(g2, "g2", dt)
+    _lib.check(_lib.load().anemoi_gnn_edge_chain_fwd(ep, lde, p1, ld1, idx1.data_ptr(), p2, ld2, idx2.data_ptr(), w0.data_ptr(), _vec(b0, "b0", D, dt),
+                                                     w1.data_ptr(), _vec(b1, "b1", D, dt), w2.data_ptr(), _vec(b2, "b2", D, dt), _vec(ln_w, "ln_w", D, dt),
+                                                     _vec(ln_b, "ln_b", D, dt), float(eps), out.data_ptr(), D, M, D, _dt(e), _stream()), "gnn_edge_chain_fwd")
+    return out
+
+
+def gnn_node_chain(x: Tensor, agg: Tensor, wa: Tensor, ba: Tensor, wb: Tensor, bb: Tensor, wc: Tensor, bc: Tensor, ln_w: Tensor,
+                   ln_b: Optional[Tensor], eps: float, wt: Optional[Tensor] = None, bt: Optional[Tensor] = None, t_out_features: int = 0):
+    """A GraphConv block's node MLP + LayerNorm + skip in ONE launch (anemoi_gnn_node_chain_fwd):
+    ``x_out = LayerNorm(Wc gelu(Wb gelu(Wa [x | agg] + ba) + bb) + bc) + x`` and optionally ``t_out = x_out Wt^T [+ bt]``.
+    Weights are fragment-major images (``pack_weight_frag``).  Returns ``x_out`` or ``(x_out, t_out)``.  Inference only."""
+    _dev(x, agg, wa, ba, wb, bb, wc, bc, ln_w, ln_b, wt, bt)
+    N, D = x.shape
+    dt = x.dtype
+    if D != CHAIN_CHANNELS or dt not in (torch.bfloat16, torch.float16):
+        raise NotImplementedError(f"gnn_node_chain: {D} channels / {dt} (built for {CHAIN_CHANNELS} channels, 16-bit dtypes)")
+    if tuple(agg.shape) != (N, D):
+        raise ValueError("gnn_node_chain: x and agg must have the same [N, 512] shape")
+    for name, w, numel in (("wa", wa, 2 * D * D), ("wb", wb, D * D), ("wc", wc, D * D)):
+        if w.dim() != 1 or w.numel() != numel or w.dtype != dt or not w.is_contiguous():
+            raise ValueError(f"gnn_node_chain: {name} must be a contiguous fragment-major image of {numel} elements (pack_weight_frag)")
+    if wt is not None and (t_out_features % D or wt.dim() != 1 or wt.numel() != t_out_features * D or wt.dtype != dt or not wt.is_contiguous()):
+        raise ValueError("gnn_node_chain: wt must be the fragment-major image of a [t_out_features, 512] weight, t_out_features % 512 == 0")
+    x_out = torch.empty((N, D), dtype=dt, device=x.device)
+    tf = t_out_features if wt is not None else 0
+    t_out = torch.empty((N, tf), dtype=dt, device=x.device) if tf else None
+    (xp, ldx), (ap, lda) = _rows(x, "x", dt), _rows(agg, "agg", dt)
+    _lib.check(_lib.load().anemoi_gnn_node_chain_fwd(xp, ldx, ap, lda, wa.data_ptr(), _vec(ba, "ba", D, dt), wb.data_ptr(), _vec(bb, "bb", D, dt), wc.data_ptr(),
+                                                     _vec(bc, "bc", D, dt), _vec(ln_w, "ln_w", D, dt), _vec(ln_b, "ln_b", D, dt), float(eps), x_out.data_ptr(), D,
+                                                     0 if wt is None else wt.data_ptr(), _vec(bt, "bt", tf, dt) if (bt is not None and tf) else 0, tf,
+                                                     0 if t_out is None else t_out.data_ptr(), tf, N, D, _dt(x), _stream()), "gnn_node_chain_fwd")
+    return x_out if t_out is None else (x_out, t_out)
+
+
 GLU_KINDS = {"glu": 0, "swiglu": 1, "geglu": 2, "reglu": 3}
 
 

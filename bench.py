@@ -562,7 +562,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    group, wire, wire_note = None, None, None
+    group, wire, wire_note, wire_check = None, None, None, None
     if world > 1:
         import torch.distributed as dist
 
@@ -612,31 +612,43 @@ def main():
             out = step()
         sync_all()
         if wire is not None:
-            # the device-initiated wire has to EARN its place: every rank's sharded output must match rank 0's unsharded forward
-            # (bf16: 2e-2 of the output scale, the bound of the sharded parity tests) and no wait may have timed out
+            # the device-initiated wire has to EARN its place before anything is timed: THREE different inputs and a repeat of the
+            # first go through the same receive buffers, every rank's sharded output must match rank 0's unsharded forward of that
+            # input (bf16: 2e-2 of the output scale, the bound of the sharded parity tests) and no wait may have timed out - a
+            # rank that reads halo rows of the PREVIOUS forward (a release / acquire hole between two devices) fails here
             ok, why = 1, ""
-            try:
-                wire.check()
-            except Exception as e:  # noqa: BLE001
-                ok, why = 0, f"{type(e).__name__}: {str(e)[:200]}"
-            # every collective of this check is issued by EVERY rank whatever happened to it above
+            checks = [x_dev, torch.roll(x_dev, 1, dims=3).contiguous(), (0.5 * x_dev.flip(3)).contiguous()]
             holder = [None]
             if rank == 0:
                 try:  # on a COPY: the model's static caches (rank-local graphs, collectively built plans) stay sharded
                     import copy
 
-                    holder = [copy.deepcopy(model)(inp)["data"].float().cpu()]
+                    ref_model = copy.deepcopy(model)
+                    holder = [[ref_model({"data": xi})["data"].float().cpu() for xi in checks]]
+                    del ref_model
                 except Exception as e:  # noqa: BLE001
                     ok, why = 0, f"unsharded reference forward failed: {type(e).__name__}: {str(e)[:200]}"
+            # every collective of this check is issued by EVERY rank whatever happened to it above
             torch.distributed.broadcast_object_list(holder, src=0)
-            if ok and holder[0] is not None:
-                err = float((out.float().cpu() - holder[0]).abs().max())
-                scale = max(1.0, float(holder[0].abs().max()))
-                if not err <= (2e-5 if dtype == torch.float32 else 2e-2) * scale:
-                    ok, why = 0, f"sharded output differs from the unsharded forward by {err:.3e} (scale {scale:.2f})"
-            elif holder[0] is None:
+            refs = holder[0]
+            worst = 0.0
+            for j in (0, 1, 2, 0):
+                try:
+                    oj = model({"data": checks[j]}, model_comm_group=group)["data"]
+                    wire.check()
+                    if refs is not None:
+                        err = float((oj.float().cpu() - refs[j]).abs().max())
+                        scale = max(1.0, float(refs[j].abs().max()))
+                        worst = max(worst, err / scale)
+                        if ok and not err <= (2e-5 if dtype == torch.float32 else 2e-2) * scale:
+                            ok, why = 0, f"input {j}: sharded output differs from the unsharded forward by {err:.3e} (scale {scale:.2f})"
+                except Exception as e:  # noqa: BLE001  (a time-out; the other ranks keep issuing their exchanges, which no longer wait)
+                    if ok:
+                        ok, why = 0, f"input {j}: {type(e).__name__}: {str(e)[:200]}"
+            if refs is None:
                 ok = 0
-            holder = None
+            holder = refs = None
+            wire_check = {"inputs": 3, "forwards": 4, "max_err_over_scale": round(worst, 6)}
             flag = torch.tensor([ok], device="cpu" if host_transport else device, dtype=torch.int32)
             torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
             if int(flag.item()) == 0:
@@ -644,11 +656,15 @@ def main():
                     raise SystemExit(f"bench.py: rank {rank}: hipIpc wire failed its check: {why or 'another rank failed'}")
                 from anemoi_core_amd.distributed import peer
 
+                whys: list = [None] * world
+                torch.distributed.all_gather_object(whys, why)
                 peer.uninstall()
-                wire, wire_note = None, f"hipIpc wire failed its check on some rank ({why or 'see other ranks'}); RCCL chain"
+                wire, wire_note = None, "hipIpc wire failed its check (" + "; ".join(f"rank {r}: {w}" for r, w in enumerate(whys) if w)[:600] + "); RCCL chain"
                 for _ in range(2):
                     out = step()
                 sync_all()
+            else:
+                wire.stats(reset=True)  # the timed region's exchange diagnostics start from zero
             torch.cuda.empty_cache()
         # N = 1: the whole forward is ONE hipGraph.  N > 1: RCCL collectives cannot be captured on this stack (the capture
         # aborts through the ProcessGroupNCCL watchdog or hangs; tools/nccl_capture_probe.py), so the forward becomes a
@@ -716,10 +732,80 @@ def main():
         if sentinel:
             torch.cuda._sleep(100)
             torch.cuda.synchronize()
+    rank_diag, rccl_leg = None, None
     if world > 1:
         tt = torch.tensor([elapsed], device="cpu" if host_transport else device, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
+        # per-rank diagnostics of the timed region (every rank contributes; rank 0 prints): halo rows, what the exchange kernels
+        # spent waiting for the peers' flags, a time-out's peer id
+        mine = {"rank": rank}
+        try:
+            plan = getattr(model.processor, "_halo_cache", {}).get("plan")
+            if plan is not None:
+                mine.update({"local_rows": int(plan.info.num_local_nodes), "n_halo": int(sum(plan.recv_counts)), "n_send": int(sum(plan.send_counts))})
+            if wire is not None:
+                st = wire.stats(reset=True)
+                n_fwd = args.steps + args.warmup
+                mine.update({"exchanges_per_forward": round(st["exchanges"] / max(n_fwd, 1), 2), "exchange_wait_us_per_forward": round(st["wait_us_total"] / max(n_fwd, 1), 1),
+                             "exchange_wait_us_max": st["wait_us_max"], "timeout_peer": st["timeout_peer"]})
+        except Exception as e:  # noqa: BLE001
+            mine["error"] = f"{type(e).__name__}: {str(e)[:200]}"
+        rank_diag = [None] * world
+        torch.distributed.all_gather_object(rank_diag, mine)
+        if wire is not None:
+            # ONE driver run yields the comparison: the same forward over the RCCL chain (19 hipGraph segments + host-issued
+            # collectives), timed like the headline region.  A failure here is reported, never fatal: `value` is the wire's.
+            ok_all = 1
+            try:
+                wire.check()
+            except Exception:  # noqa: BLE001
+                ok_all = 0
+            flag = torch.tensor([ok_all], device="cpu" if host_transport else device, dtype=torch.int32)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)  # the verdict is agreed BEFORE the collective uninstall
+            from anemoi_core_amd.distributed import peer
+
+            ipc_segments = getattr(graph, "num_graphs", 1) if graph is not None else 0
+            n_channels = len(wire._channels)
+            peer.uninstall()
+            wire_was, wire = "ok" if int(flag.item()) else "a wait timed out during the timed region", None
+            rccl_leg = {"ms_per_step_ipc": elapsed / args.steps * 1e3, "graph_segments_ipc": ipc_segments, "ipc_status": wire_was, "peer_channels": n_channels}
+            if transport != "ipc" or os.environ.get("ANEMOI_BENCH_RCCL_LEG", "1") == "1":
+                try:
+                    with torch.inference_mode():
+                        for _ in range(2):
+                            step()
+                        sync_all()
+                        g2 = None
+                        if not args.no_graph:
+                            from anemoi_core_amd.utils.segments import SegmentedGraph
+
+                            ok2 = 1
+                            try:
+                                g2 = SegmentedGraph()
+                                g2.capture(step)
+                                g2.replay()
+                                torch.cuda.synchronize()
+                            except Exception:  # noqa: BLE001
+                                ok2 = 0
+                            f2 = torch.tensor([ok2], device="cpu" if host_transport else device, dtype=torch.int32)
+                            torch.distributed.all_reduce(f2, op=torch.distributed.ReduceOp.MIN)
+                            if int(f2.item()) == 0:
+                                g2 = None
+                        run2 = g2.replay if g2 is not None else step
+                        for _ in range(args.warmup):
+                            run2()
+                        sync_all()
+                        t1 = time.perf_counter()
+                        for _ in range(args.steps):
+                            run2()
+                        sync_all()
+                        e2 = torch.tensor([time.perf_counter() - t1], device="cpu" if host_transport else device, dtype=torch.float64)
+                        torch.distributed.all_reduce(e2, op=torch.distributed.ReduceOp.MAX)
+                    rccl_leg.update({"ms_per_step_rccl": float(e2.item()) / args.steps * 1e3, "graph_segments_rccl": getattr(g2, "num_graphs", 0) if g2 is not None else 0,
+                                     "collectives_per_forward_rccl": getattr(g2, "num_collectives", None) if g2 is not None else None})
+                except Exception as e:  # noqa: BLE001
+                    rccl_leg["rccl_leg_error"] = f"{type(e).__name__}: {str(e)[:300]}"
     ms = elapsed / args.steps * 1e3
     value = g.num_data * args.channels / (ms * 1e-3)
 
@@ -741,10 +827,14 @@ def main():
         }
         if world > 1:
             res["rccl"] = rccl_block(model, group, world, graph)
-            res["rccl"]["wire"] = ("hipIpc device-initiated exchange (peer stores + epoch flags inside the rank's hipGraph)" if wire is not None
+            res["rccl"]["wire"] = ("hipIpc device-initiated exchange (peer stores + epoch flags inside the rank's hipGraph)" if rccl_leg is not None
                                    else "RCCL all_to_all_single between hipGraph segments")
-            if wire is not None:
-                res["rccl"]["peer_channels"] = len(wire._channels)
+            if rccl_leg is not None:
+                res["rccl"].update(rccl_leg)
+            if wire_check is not None:
+                res["rccl"]["wire_check"] = wire_check
+            if rank_diag is not None:
+                res["rccl"]["ranks"] = rank_diag
             if wire_note:
                 res["rccl"]["wire_note"] = wire_note
             if host_transport:
@@ -808,8 +898,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(params_fp32, cfg, g, x, budget_s=float(os.environ.get("ANEMOI_BENCH_CPU_BUDGET_S", "150")))
         print(json.dumps(res), flush=True)
     if world > 1:
-        if wire is not None:
-            wire.check()
+        if wire is not None:  # (only when the RCCL leg did not run: it uninstalls the wire itself, verdict agreed first)
             from anemoi_core_amd.distributed import peer
 
             peer.uninstall()

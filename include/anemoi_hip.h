@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ANEMOI_HIP_ABI_VERSION 9
+#define ANEMOI_HIP_ABI_VERSION 10
 
 typedef enum { ANEMOI_F32 = 0, ANEMOI_BF16 = 1, ANEMOI_F16 = 2 } anemoi_dtype_t;
 typedef enum { ANEMOI_ACT_NONE = 0, ANEMOI_ACT_GELU = 1 } anemoi_act_t;
@@ -330,7 +330,9 @@ int anemoi_peer_close(void* ptr);
  * send_count (rows of the packed order for peer p), signal (1: publish the epoch to p), expect (1: wait for p's epoch).
  * local_flags = this rank's words of the channel: [n_peers flags | seq | ticket] (uint32, ANEMOI_PEER_MEM_UNCACHED).  total_rows
  * may be 0 (signal / expect only: the forward-level barrier).  A peer that does not show up within timeout_ticks (100 MHz
- * wall clock) sets *status = 0x80000000 | peer instead of hanging the device. */
+ * wall clock) sets *status = 0x80000000 | peer instead of hanging the device.  `status` points at a block of >= 5 words:
+ * [0] the time-out word, [2] exchanges run, [3] ticks summed over them between "my rows released" and "every expected flag
+ * seen", [4] the longest such wait (diagnostics; the caller may zero them between forwards). */
 int anemoi_peer_exchange_rows(const void* src, int64_t ld_src_bytes, const int32_t* send_index, const int64_t* table,
                               int32_t n_peers, int32_t row_bytes, int32_t total_rows, uint32_t* local_flags, uint32_t* status,
                               int64_t timeout_ticks, void* stream);
@@ -372,6 +374,27 @@ typedef struct anemoi_gt_chain_args {
 } anemoi_gt_chain_args_t;
 int anemoi_gt_chain_fwd(const anemoi_gt_chain_args_t* args, anemoi_dtype_t dtype, void* stream);
 int anemoi_gt_chain_rows_per_tile(int32_t n_rows);
+
+/* ---- row-resident chains of the GraphConv (GNN) processor block (round 4; csrc/gnn_chain.hip) ------------------------------------
+ * GraphConv (layers/conv.py:29-81) in its gather-add form, with an edge MLP of three Linears (mlp_extra_layers = 0):
+ *     e_new = LayerNorm(W_2 gelu(W_1 gelu(W_e e + g1[idx1] + g2[idx2] + b_0) + b_1) + b_2; ln) + e
+ * where g1 = x_dst W_i^T and g2 = x_src W_j^T are node-level rows gathered by the edge's destination / source, W_e = the edge
+ * columns of the first Linear's weight.  ONE launch instead of three edge-level GEMMs + the LayerNorm / residual half of
+ * anemoi_edge_ln_residual_segment_sum_fwd (whose arithmetic and rounding points it keeps: the GEMM outputs rounded to the model
+ * dtype, one rounding of LayerNorm(z) + e); the scatter-sum over e_new is anemoi_segment_sum_rows.  w0 / w1 / w2 are fragment-major
+ * images (see anemoi_gt_chain_fwd) of [512, 512] weights. */
+int anemoi_gnn_edge_chain_fwd(const void* e, int64_t ld_e, const void* g1, int64_t ld_g1, const int32_t* idx1, const void* g2, int64_t ld_g2,
+                              const int32_t* idx2, const void* w0, const void* b0, const void* w1, const void* b1, const void* w2, const void* b2,
+                              const void* ln_w, const void* ln_b, float eps, void* e_new, int64_t ld_o, int32_t n_rows, int32_t channels,
+                              anemoi_dtype_t dtype, void* stream);
+/* The node MLP of a GraphConv block (layers/block.py:392-394; MLP of three Linears + LayerNorm, layers/mlp.py:97-179) with its skip:
+ *     x_out = LayerNorm(W_c gelu(W_b gelu(W_a [x | agg] + b_a) + b_b) + b_c; ln) + x
+ * and optionally t_out = x_out W_t^T [+ b_t] - the NEXT block's stacked node-level terms [x W_i^T | x W_j^T] its edge chain gathers.
+ * wa [512, 1024], wb, wc [512, 512], wt [t_out_features, 512] fragment-major. */
+int anemoi_gnn_node_chain_fwd(const void* x, int64_t ld_x, const void* agg, int64_t ld_a, const void* wa, const void* ba, const void* wb,
+                              const void* bb, const void* wc, const void* bc, const void* ln_w, const void* ln_b, float eps, void* x_out,
+                              int64_t ld_o, const void* wt, const void* bt, int32_t t_out_features, void* t_out, int64_t ld_t, int32_t n_rows,
+                              int32_t channels, anemoi_dtype_t dtype, void* stream);
 
 #ifdef __cplusplus
 }

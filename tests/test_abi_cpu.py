@@ -102,3 +102,33 @@ def test_torch_extension_loads_and_registers_its_ops():
         assert hasattr(ext, name), name
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ext.layer_norm(torch.randn(4, 64), torch.ones(64), None, 1e-5, None)
+
+
+def test_torch_library_ops_have_fake_kernels():
+    """torch.ops.anemoi_hip.* carry Meta / FakeTensor kernels (anemoi_core_amd/_ext.py: _register_fakes), so the ops are opaque but
+    traceable leaves - the reference registers the same for its Triton op (triton/gt.py:431-447, 553-556).  Shapes / dtypes must be
+    those csrc/torch_binding.cpp produces (checked against the real kernels in tests/test_torch_ext_gpu.py)."""
+    import torch
+    from torch._subclasses.fake_tensor import FakeTensorMode
+
+    from anemoi_core_amd import _ext
+
+    o = _ext.ops()
+    assert o is not None
+    bf = torch.bfloat16
+    with FakeTensorMode():
+        x, w = torch.empty(100, 512, dtype=bf, device="cuda"), torch.empty(2048, 512, dtype=bf, device="cuda")
+        y = o.linear(x, w, None, 1, None, None, None, None, None, None)
+        assert y.shape == (100, 2048) and y.dtype == bf and y.device.type == "cuda"
+        assert o.layer_norm(x, torch.empty(512, dtype=bf, device="cuda"), None, 1e-5, None).shape == (100, 512)
+        y2, st = o.linear_with_row_stats(y, torch.empty(512, 2048, dtype=bf, device="cuda"), None, x)
+        assert y2.shape == (100, 512) and st.shape == (100, 8, 2) and st.dtype == torch.float32
+        ne = o.linear_with_row_stats(x.float(), w.float(), None, None)  # fp32: the 'not eligible' sentinel, as the kernel side
+        assert ne[0].dim() == 1 and ne[0].numel() == 0
+        c = torch.empty(2048, device="cuda")
+        assert o.linear_ln_folded(y2, w, c, c, st, 1e-5, 0).shape == (100, 2048)
+        q = torch.empty(10, 512, dtype=bf, device="cuda")
+        i32 = lambda n: torch.empty(n, dtype=torch.int32, device="cuda")  # noqa: E731
+        out, lse = o.gt_attention_fused_edge(q, q, q, torch.empty(30, 12, device="cuda"), torch.empty(512, 12, device="cuda"), i32(30), i32(11), None,
+                                             10, 16, None, True)
+        assert out.shape == (10, 512) and out.dtype == bf and lse.shape == (10, 16) and lse.dtype == torch.float32

@@ -194,17 +194,128 @@ def test_model_with_chain_equals_model_without():
     m = model.to(DEV).to(torch.bfloat16)
     xb = x.to(DEV).to(torch.bfloat16)
     outs = {}
-    launches = {}
+    saved = B._LAYER_CHAIN
     for flag in (True, False):
         B._LAYER_CHAIN = flag
         try:
             with torch.no_grad():
                 outs[flag] = m({"data": xb})["data"].float().cpu()
         finally:
-            B._LAYER_CHAIN = True
+            B._LAYER_CHAIN = saved
     a, b = outs[True], outs[False]
     scale = float(want.abs().max())
     assert float((a - b).abs().max()) <= 3e-2 * scale and float((a - b).abs().mean()) <= 4e-3 * scale, (float((a - b).abs().max()), scale)
+    for name, y in (("chain", a), ("launch-per-GEMM", b)):
+        err = (y - want).abs()
+        assert float(err.max()) <= 6e-2 * max(scale, 1.0) and float(err.mean()) <= 1e-2 * max(scale, 1.0), (name, float(err.max()), float(err.mean()), scale)
+
+
+# ------------------------------------------------------------------------------------------ GraphConv (GNN) chains
+def _gnn_params(gen, dtype):
+    r = lambda *s: torch.randn(*s, generator=gen)  # noqa: E731
+    return dict(w0=(r(D, D) / 22).to(dtype), b0=(0.1 * r(D)).to(dtype), w1=(r(D, D) / 22).to(dtype), b1=(0.1 * r(D)).to(dtype),
+                w2=(r(D, D) / 22).to(dtype), b2=(0.1 * r(D)).to(dtype), g=(1 + 0.2 * r(D)).to(dtype), be=(0.1 * r(D)).to(dtype),
+                wa=(r(D, 2 * D) / 32).to(dtype), ba=(0.1 * r(D)).to(dtype), wt=(r(2 * D, D) / 22).to(dtype))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N", [(37, 11), (5000, 700), (81840, 10242)])
+def test_gnn_edge_chain_vs_fp32_restatement(dtype, M, N):
+    """GraphConv's edge MLP in gather-add form + LayerNorm + residual (csrc/gnn_chain.hip) against fp32 torch with the rounding
+    points of the launch-per-GEMM path, and against that path itself (ops.linear with the gather-add epilogue, ops.linear x 2,
+    edge_ln_residual_segment_sum) on the same operands."""
+    from anemoi_core_amd import ops
+
+    gen = torch.Generator().manual_seed(M)
+    p = _gnn_params(gen, dtype)
+    e = torch.randn(M, D, generator=gen).to(dtype)
+    g12 = torch.randn(N, 2 * D, generator=gen).to(dtype)
+    dst = torch.sort(torch.randint(0, N, (M,), generator=gen)).values.to(torch.int32)
+    src = torch.randint(0, N, (M,), generator=gen).to(torch.int32)
+    d = lambda t: t.to(DEV)  # noqa: E731
+    P = ops.pack_weight_frag
+    got = ops.gnn_edge_chain(d(e), d(g12)[:, :D], d(dst), d(g12)[:, D:], d(src), P(d(p["w0"])), d(p["b0"]), P(d(p["w1"])), d(p["b1"]), P(d(p["w2"])),
+                             d(p["b2"]), d(p["g"]), d(p["be"]), 1e-5)
+    f = lambda t: t.float()  # noqa: E731
+    rnd = lambda t: t.to(dtype).float()  # noqa: E731
+    h1 = rnd(F.gelu(F.linear(f(e), f(p["w0"]), f(p["b0"])) + f(g12)[dst.long(), :D] + f(g12)[src.long(), D:]))
+    h2 = rnd(F.gelu(F.linear(h1, f(p["w1"]), f(p["b1"]))))
+    z = rnd(F.linear(h2, f(p["w2"]), f(p["b2"])))
+    want = rnd(F.layer_norm(z, (D,), f(p["g"]), f(p["be"]), 1e-5) + f(e))
+    _close(got, want, f"edge chain M={M}", tol=2.5e-2)
+    assert torch.equal(got, ops.gnn_edge_chain(d(e), d(g12)[:, :D], d(dst), d(g12)[:, D:], d(src), P(d(p["w0"])), d(p["b0"]), P(d(p["w1"])), d(p["b1"]),
+                                               P(d(p["w2"])), d(p["b2"]), d(p["g"]), d(p["be"]), 1e-5))
+    if M >= 5000:  # the launch-per-GEMM path of this package on the same operands (needs a CSC over the sorted destinations)
+        colptr = torch.zeros(N + 1, dtype=torch.int64)
+        colptr[1:] = torch.bincount(dst.long(), minlength=N).cumsum(0)
+        csc = ops.CSC(row=d(src), dst=d(dst), colptr=d(colptr.to(torch.int32)), n_src=N, n_dst=N)
+        h = ops.linear(d(e), d(p["w0"]), d(p["b0"]), act="gelu", g1=d(g12)[:, :D], idx1=d(dst), g2=d(g12)[:, D:], idx2=d(src))
+        zz = ops.linear(ops.linear(h, d(p["w1"]), d(p["b1"]), act="gelu"), d(p["w2"]), d(p["b2"]))
+        e_old_path, agg_path = ops.edge_ln_residual_segment_sum(zz, d(e), d(p["g"]), d(p["be"]), 1e-5, csc)
+        err = (got.float() - e_old_path.float()).abs()
+        assert float(err.max()) <= 4e-2 * float(want.abs().max()) and float(err.mean()) <= 3e-3 * float(want.abs().mean() + 1)
+        agg = ops.segment_sum_rows(got, csc.colptr)
+        ea = (agg.float() - agg_path.float()).abs()
+        assert float(ea.max()) <= 4e-2 * float(agg_path.float().abs().max()) + 1e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,trailing", [(9, True), (3000, False), (10242, True), (40962, True)])
+def test_gnn_node_chain_vs_fp32_restatement(dtype, N, trailing):
+    from anemoi_core_amd import ops
+
+    gen = torch.Generator().manual_seed(N)
+    p = _gnn_params(gen, dtype)
+    x = torch.randn(N, D, generator=gen).to(dtype)
+    agg = (3.0 * torch.randn(N, D, generator=gen)).to(dtype)
+    d = lambda t: t.to(DEV)  # noqa: E731
+    P = ops.pack_weight_frag
+    kw = dict(wt=P(d(p["wt"])), t_out_features=2 * D) if trailing else {}
+    res = ops.gnn_node_chain(d(x), d(agg), P(d(p["wa"])), d(p["ba"]), P(d(p["w1"])), d(p["b1"]), P(d(p["w2"])), d(p["b2"]), d(p["g"]), d(p["be"]), 1e-5, **kw)
+    f = lambda t: t.float()  # noqa: E731
+    rnd = lambda t: t.to(dtype).float()  # noqa: E731
+    h1 = rnd(F.gelu(F.linear(torch.cat([f(x), f(agg)], 1), f(p["wa"]), f(p["ba"]))))
+    h2 = rnd(F.gelu(F.linear(h1, f(p["w1"]), f(p["b1"]))))
+    y = rnd(F.linear(h2, f(p["w2"]), f(p["b2"])))
+    want = rnd(F.layer_norm(y, (D,), f(p["g"]), f(p["be"]), 1e-5) + f(x))
+    if trailing:
+        _close(res[0], want, f"node chain N={N}", tol=2.5e-2)
+        _close(res[1], F.linear(want, f(p["wt"])), f"node chain trailing N={N}", tol=2.5e-2)
+    else:
+        _close(res, want, f"node chain N={N}", tol=2.5e-2)
+
+
+def test_gnn_model_with_chains_equals_model_without():
+    """The 512-channel GNN model: chain launches (edge chain + segment sum + node chain with the next block's stacked projection) against
+    the launch-per-GEMM path and the fp32 CPU oracle."""
+    import anemoi_core_amd.layers.block as B
+    from anemoi_core_amd.graphs.synthetic import build_synthetic_graph
+    from anemoi_core_amd.models import AnemoiModelEncProcDec
+    from anemoi_core_amd.models.configs import make_data_indices, model_config
+    from oracle import gt_oracle as O
+
+    g = build_synthetic_graph("o16", 3)
+    torch.manual_seed(0)
+    cfg = dict(kind="gnn", num_channels=512, num_layers=3, num_heads=16, trainable=8, n_vars=6, n_step_input=2)
+    model = AnemoiModelEncProcDec(model_config=model_config("gnn", 512, 3, 16, 8), data_indices=make_data_indices(6, 6),
+                                  statistics={"data": None}, n_step_input=2, n_step_output=1, graph_data=g).eval()
+    params = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    x = torch.randn(1, 2, 1, g.num_data, 6)
+    want = O.enc_proc_dec_forward(params, cfg, g, x)
+    m = model.to(DEV).to(torch.bfloat16)
+    xb = x.to(DEV).to(torch.bfloat16)
+    outs, saved = {}, B._GNN_CHAIN
+    for flag in (True, False):
+        B._GNN_CHAIN = flag
+        try:
+            with torch.no_grad():
+                outs[flag] = m({"data": xb})["data"].float().cpu()
+        finally:
+            B._GNN_CHAIN = saved
+    a, b = outs[True], outs[False]
+    scale = float(want.abs().max())
+    assert not torch.equal(a, b)  # the chain kernels really ran
+    assert float((a - b).abs().max()) <= 4e-2 * scale and float((a - b).abs().mean()) <= 5e-3 * scale, (float((a - b).abs().max()), scale)
     for name, y in (("chain", a), ("launch-per-GEMM", b)):
         err = (y - want).abs()
         assert float(err.max()) <= 6e-2 * max(scale, 1.0) and float(err.mean()) <= 1e-2 * max(scale, 1.0), (name, float(err.max()), float(err.mean()), scale)

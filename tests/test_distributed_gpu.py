@@ -385,6 +385,103 @@ def test_peer_wire_rows_flags_and_graph_replay_under_uneven_load(world):
         assert o["bad"] == [] and o["channels"] == 1 + 3  # barrier + the three exchanges of the forward
 
 
+def _peer_soak_worker(rank, world, group, replays):
+    """The forward of _peer_wire_worker captured THREE times per rank with different sleep kernels in front of each of its
+    exchanges (rank-dependent lengths, 0-150 us), a random variant + a random pre-replay sleep every iteration: the ranks reach
+    every exchange in a different order every time.  Every word of every received row is compared after EVERY replay."""
+    import random
+
+    from anemoi_core_amd import ops
+    from anemoi_core_amd.distributed import peer, primitives as P
+
+    dev = torch.device("cuda", 0)
+    wire = peer.install(group, arena_mb=64, timeout_s=60)
+    D = 512
+    rows = [700 + 29 * q for q in range(world)]
+    plans = [_peer_plan(q, world, rows[q]) for q in range(world)]
+    send_counts, send_index = plans[rank][0], plans[rank][1].to(dev)
+    recv_counts = [plans[q][0][rank] for q in range(world)]
+    nl = rows[rank]
+    rnd = random.Random(1234 + rank)  # per-rank stream: the skews are NOT the same on the ranks
+    # cycles of torch.cuda._sleep per microsecond, measured
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    torch.cuda._sleep(2_000_000)
+    e1.record()
+    torch.cuda.synchronize()
+    per_us = 2_000_000 / (e0.elapsed_time(e1) * 1e3)
+
+    def expected(it):
+        parts = []
+        for q in range(world):
+            if recv_counts[q]:
+                b = sum(plans[q][0][:rank])
+                parts.append(_peer_inputs(q, it, rows[q], D, dev)[plans[q][1][b:b + recv_counts[q]].long().to(dev)])
+        return torch.cat(parts) if parts else torch.empty(0, D, dtype=torch.bfloat16, device=dev)
+
+    def one_forward(x, small, skew_us):
+        with P.forward_scope(group):
+            torch.cuda._sleep(int(skew_us[0] * per_us) + 1)
+            buf = P.recv_buffer(nl, send_counts, recv_counts, D, x.dtype, dev, group)
+            buf[:nl].copy_(x)
+            P.halo_exchange_into(buf, nl, send_index, send_counts, recv_counts, group, ops.gather_rows)
+            torch.cuda._sleep(int(skew_us[1] * per_us) + 1)
+            staged = torch.empty(sum(recv_counts), D, dtype=x.dtype, device=dev)
+            P._push_rows(staged, x, send_index, recv_counts, send_counts, group, ops.gather_rows)
+            torch.cuda._sleep(int(skew_us[2] * per_us) + 1)
+            gathered = P.gather_tensor(small, 0, [small.shape[0]] * world, group)
+        return buf, staged, gathered
+
+    bad = []
+    with torch.inference_mode():
+        x_static = _peer_inputs(rank, 0, nl, D, dev)
+        small_static = x_static[:40, :84].contiguous()
+        variants = []
+        for v in range(3):
+            skew = [rnd.uniform(0, 150) for _ in range(3)]
+            one_forward(x_static, small_static, skew)  # eager first: channels exist before any capture
+            torch.cuda.synchronize()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                one_forward(x_static, small_static, skew)
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                outs = one_forward(x_static, small_static, skew)
+            variants.append((g, outs))
+        wire.stats(reset=True)
+        pick = random.Random(99)  # the SAME variant index on every rank would still differ in its sleeps; a common stream keeps it simple
+        for it in range(1, replays + 1):
+            x_static.copy_(_peer_inputs(rank, it, nl, D, dev))
+            small_static.copy_(x_static[:40, :84])
+            torch.cuda._sleep(int(rnd.uniform(0, 120) * per_us) + 1)
+            g, (buf, staged, gathered) = variants[pick.randrange(3)]
+            g.replay()
+            want = expected(it)
+            want_g = torch.cat([_peer_inputs(q, it, rows[q], D, dev)[:40, :84] for q in range(world)])
+            if not (torch.equal(buf[nl:], want) and torch.equal(staged, want) and torch.equal(gathered, want_g)):
+                bad.append(it)
+        wire.check()
+        st = wire.stats()
+    torch.cuda.synchronize()
+    dist.barrier(group=group)
+    peer.uninstall()
+    return dict(bad=bad, stats=st)
+
+
+def test_peer_wire_soak_random_skew_every_replay():
+    """500 replays at world 4, random per-rank skew in front of every exchange and every replay, outputs
+    compared after every replay; the exchange diagnostics of csrc/peer.hip count every exchange and report no time-out."""
+    replays = 500
+    for o in _spawn(_peer_soak_worker, 4, replays):
+        assert o["bad"] == [], o["bad"][:10]
+        assert o["stats"]["timeout_peer"] is None
+        assert o["stats"]["exchanges"] == replays * 4  # the forward's barrier + its three exchanges
+        assert o["stats"]["wait_us_max"] < 60e6
+
+
 def _alternating_worker(rank, world, group):
     model, c = _model()
     x = {"data": c["x"].cuda()}

@@ -124,3 +124,27 @@ def test_eager_forward_host_cost_with_and_without_the_extension():
     (ya, ta), (yb, tb) = _both(run)
     print(f"[torch ext] eager O96 forward: {ta:.3f} ms through torch.ops.anemoi_hip, {tb:.3f} ms through ctypes")
     assert torch.equal(ya, yb)
+
+
+def test_ops_trace_under_torch_compile():
+    """A chain of torch.ops.anemoi_hip.* calls traces under torch.compile (aot_eager: Dynamo + AOTAutograd + the fake kernels, no code
+    generation) as ONE graph and computes what the eager calls compute."""
+    import torch._dynamo
+
+    from anemoi_core_amd import _ext
+
+    o = _ext.ops()
+    dev, bf = "cuda", torch.bfloat16
+    g = torch.Generator(device=dev).manual_seed(0)
+    x = torch.randn(1000, 512, device=dev, generator=g).to(bf)
+    w1, w2 = (torch.randn(2048, 512, device=dev, generator=g) / 22).to(bf), (torch.randn(512, 2048, device=dev, generator=g) / 45).to(bf)
+    gam, bet = torch.ones(512, device=dev, dtype=bf), torch.zeros(512, device=dev, dtype=bf)
+
+    def f(x):
+        h = o.linear(o.layer_norm(x, gam, bet, 1e-5, None), w1, None, 1, None, None, None, None, None, None)
+        return o.linear(h, w2, None, 0, x, None, None, None, None, None)
+
+    want = f(x)
+    torch._dynamo.reset()
+    got = torch.compile(f, backend="aot_eager", fullgraph=True)(x)
+    assert torch.equal(got, want)
