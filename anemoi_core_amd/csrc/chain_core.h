@@ -85,17 +85,17 @@ typedef const __attribute__((address_space(1))) frag8* gfrag_t;
 // segment or, in its last group, of the NEXT segment (`nxt`), so the stream never drains across the epilogues.
 // sched_barrier pins the issue order: left alone the scheduler sinks all 16 loads to the end of the loop body and the
 // waitcnt pass then drains the queue at the top (measured with tools/weight_stream_probe.hip).
-template <typename T>
+template <typename T, int NB = 3>
 __device__ __forceinline__ void gemm_seg(const unsigned char* abuf, int lane, frag8 (&bq)[4][4], const char* cur, const char* nxt,
-                                         uint32_t loff, f32x4 (&acc)[3][4]) {  // cur / nxt: wave-uniform (SGPR) bases, loff = lane * 16
+                                         uint32_t loff, f32x4 (&acc)[NB][4]) {  // cur / nxt: wave-uniform (SGPR) bases, loff = lane * 16
   asm volatile("" : "+v"(lane));
   const int x = lane & 15, ks = lane >> 4;
   const unsigned char* arow = abuf + x * kRowBytes;
   // the A fragments of K-step st+1 are requested BEFORE the MFMAs of step st (12 more registers): with one set of fragment
   // registers every step exposed three LDS round trips in front of its MFMAs (a third of a segment's time, in-kernel timeline)
-  frag8 fa[3];
+  frag8 fa[NB];
 #pragma unroll
-  for (int mi = 0; mi < 3; ++mi) fa[mi] = *reinterpret_cast<const frag8*>(arow + mi * 16 * kRowBytes + ((ks ^ x) << 4));
+  for (int mi = 0; mi < NB; ++mi) fa[mi] = *reinterpret_cast<const frag8*>(arow + mi * 16 * kRowBytes + ((ks ^ x) << 4));
 #pragma unroll 1
   for (int q = 0; q < 4; ++q) {
     const char* pfg = q < 3 ? cur + (q + 1) * 16384 : nxt;
@@ -103,12 +103,12 @@ __device__ __forceinline__ void gemm_seg(const unsigned char* abuf, int lane, fr
     for (int j = 0; j < 4; ++j) {
       const int st = q * 4 + j;
       const int sn = st < 15 ? st + 1 : 15;  // (the last step re-reads its own fragments: no branch in the stream)
-      frag8 fn[3];
+      frag8 fn[NB];
 #pragma unroll
-      for (int mi = 0; mi < 3; ++mi) fn[mi] = *reinterpret_cast<const frag8*>(arow + mi * 16 * kRowBytes + (((sn * 4 + ks) ^ x) << 4));
+      for (int mi = 0; mi < NB; ++mi) fn[mi] = *reinterpret_cast<const frag8*>(arow + mi * 16 * kRowBytes + (((sn * 4 + ks) ^ x) << 4));
       __builtin_amdgcn_sched_barrier(0);  // (else the scheduler sinks these reads behind the MFMAs, into the registers they free)
 #pragma unroll
-      for (int mi = 0; mi < 3; ++mi)
+      for (int mi = 0; mi < NB; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = cmfma<T>(bq[j][ni], fa[mi], acc[mi][ni]);  // D^T: lane = row x, 4 consecutive columns
       {
@@ -117,7 +117,7 @@ __device__ __forceinline__ void gemm_seg(const unsigned char* abuf, int lane, fr
         for (int ni = 0; ni < 4; ++ni) bq[j][ni] = *reinterpret_cast<gfrag_t>(pj + loff + ni * 1024);
       }
 #pragma unroll
-      for (int mi = 0; mi < 3; ++mi) fa[mi] = fn[mi];
+      for (int mi = 0; mi < NB; ++mi) fa[mi] = fn[mi];
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -147,10 +147,10 @@ __device__ __forceinline__ LaneCtx lane_ctx(int lane, int wave) {
   return c;
 }
 
-template <typename T>
-__device__ __forceinline__ void zero_acc(f32x4 (&acc)[3][4]) {
+template <typename T, int NB = 3>
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[NB][4]) {
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+  for (int i = 0; i < NB; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
@@ -158,10 +158,10 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[3][4]) {
 // Row statistics of the panel rows held as v[mi][ni][r] (fp32 images of the ROUNDED row values; lane = row mi*16 + x, columns
 // wave*64 + ni*16 + g*4 + r): per-wave (mean, M2) partials through LDS, merged in wave order with Chan's formula (no
 // E[x^2] - mean^2 cancellation).  ONE barrier inside; `red` may be reused after the NEXT barrier of the caller.
-template <typename T>
-__device__ __forceinline__ void panel_row_stats(const f32x4 (&v)[3][4], float eps, float* red, int wave, int x, int g, float (&mean)[3], float (&rstd)[3]) {
+template <typename T, int NB = 3>
+__device__ __forceinline__ void panel_row_stats(const f32x4 (&v)[NB][4], float eps, float* red, int wave, int x, int g, float (&mean)[NB], float (&rstd)[NB]) {
 #pragma unroll
-  for (int mi = 0; mi < 3; ++mi) {
+  for (int mi = 0; mi < NB; ++mi) {
     float s = 0.f;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) s += (v[mi][ni][0] + v[mi][ni][1]) + (v[mi][ni][2] + v[mi][ni][3]);
@@ -182,7 +182,7 @@ __device__ __forceinline__ void panel_row_stats(const f32x4 (&v)[3][4], float ep
   }
   lds_barrier();
 #pragma unroll
-  for (int mi = 0; mi < 3; ++mi) {
+  for (int mi = 0; mi < NB; ++mi) {
     // the 8 waves' (mean, M2) of the row, merged in wave order (Chan et al.): M2 = sum M2_w + 64 sum (mean_w - mean)^2
     const f32x4* pr = reinterpret_cast<const f32x4*>(red + (mi * 16 + x) * 16);
     const f32x4 p0 = pr[0], p1 = pr[1], p2 = pr[2], p3 = pr[3];
@@ -225,11 +225,11 @@ __device__ __forceinline__ void panel_layernorm(f32x4 (&v)[3][4], const u32x2 (&
 // lines: through a wave-private LDS strip (row m, 16-byte slot s at m*128 + ((s ^ ((m >> 1) & 7)) << 4): conflict-free for the
 // 8-byte writes in the MFMA layout and for the 16-byte row-major read-back), 6 stores of 16 bytes per lane.  `out` = address of
 // (panel row 0, the wave's first column); the wave's own LDS operations are ordered: no barrier.
-template <typename T>
-__device__ __forceinline__ void store_block_via_strip(const u32x2 (&pk)[3][4], unsigned char* strip, T* out, int64_t ld, int nr, int lane, int wave) {
+template <typename T, int NB = 3>
+__device__ __forceinline__ void store_block_via_strip(const u32x2 (&pk)[NB][4], unsigned char* strip, T* out, int64_t ld, int nr, int lane, int wave) {
   const LaneCtx lc = lane_ctx(lane, wave);
 #pragma unroll
-  for (int mi = 0; mi < 3; ++mi) {
+  for (int mi = 0; mi < NB; ++mi) {
     const int m = mi * 16 + lc.x;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
@@ -238,7 +238,7 @@ __device__ __forceinline__ void store_block_via_strip(const u32x2 (&pk)[3][4], u
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   const int rl = (lc.g << 1) | (lc.x >> 3), sl = lc.x & 7;  // lane >> 3, lane & 7
 #pragma unroll
-  for (int it = 0; it < 6; ++it) {
+  for (int it = 0; it < 2 * NB; ++it) {
     const int m = it * 8 + rl;
     const u32x4 v = *reinterpret_cast<const u32x4*>(strip + m * 128 + ((sl ^ ((m >> 1) & 7)) << 4));
     if (m < nr) *reinterpret_cast<u32x4*>(out + (int64_t)m * ld + sl * 8) = v;

@@ -29,13 +29,21 @@ struct EdgeChainArgs {
   int n_rows, rows_per_tile, n_tiles;
 };
 
+// Edge panels are 64 rows (4 MFMA row bands): the same weight stream serves a third more rows than a 48-row panel would (81 840
+// edges = 256 CUs x 5 panels of 64: five passes over the 1.5 MB of weights per CU instead of seven), and the two hidden layers
+// live IN PLACE in one LDS buffer next to the e panel (2 x 64 KiB): a barrier between a GEMM's last fragment read and the
+// epilogue's write-back replaces the third buffer.
+constexpr int kENB = 4, kERows = 16 * kENB, kEBuf = kERows * kRowBytes;
+constexpr int kERedOff = 2 * kEBuf;
+constexpr int kEdgeSmem = kERedOff + kERows * 8 * 2 * 4;
+
 template <typename T>
 __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* const bufA = smem;                  // e panel: operand of GEMM 1, residual of the LayerNorm
-  unsigned char* const bufB = smem + kBufBytes;      // h1; later the staging strips of the stores
-  unsigned char* const bufC = smem + 2 * kBufBytes;  // h2
-  float* const red = reinterpret_cast<float*>(smem + kRedOff);
+  unsigned char* const bufE = smem;          // e panel: operand of GEMM 1, residual of the LayerNorm
+  unsigned char* const bufH = smem + kEBuf;  // h1, then h2 in place, then the staging strips of the stores
+  float* const red = reinterpret_cast<float*>(smem + kERedOff);
+  constexpr int NB = kENB, kLd = 2 * NB;     // panel loads per thread
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4;
@@ -47,12 +55,12 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
 
   int tile = blockIdx.x;
   if (tile >= a.n_tiles) return;
-  u32x4 va[6];
+  u32x4 va[kLd];
   auto request_panel = [&](int t) {
     const int r0 = t * a.rows_per_tile;
     const int nr = min(a.rows_per_tile, a.n_rows - r0);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < kLd; ++i) {
       const int idx = tid + 512 * i;
       const int rr = min(idx >> 6, nr - 1), slot = idx & 63;
       va[i] = *reinterpret_cast<const u32x4*>((const T*)a.e + (int64_t)(r0 + rr) * a.ld_e + slot * 8);
@@ -73,19 +81,19 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
     const int r0 = tile * a.rows_per_tile;
     const int nr = min(a.rows_per_tile, a.n_rows - r0);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < kLd; ++i) {
       const int idx = tid + 512 * i;
       const int row = idx >> 6, slot = idx & 63;
-      *reinterpret_cast<u32x4*>(bufA + row * kRowBytes + ((slot ^ (row & 15)) << 4)) = row < nr ? va[i] : zero4;
+      *reinterpret_cast<u32x4*>(bufE + row * kRowBytes + ((slot ^ (row & 15)) << 4)) = row < nr ? va[i] : zero4;
     }
     lds_barrier();
-    // the gathered node-level rows of this lane's 3 panel rows (index, then 2 x 4 x 8 bytes per row) and the first bias: in flight
+    // the gathered node-level rows of this lane's panel rows (index, then 2 x 4 x 8 bytes per row) and the first bias: in flight
     // under the first GEMM
-    u32x2 ga[3][4], gb[3][4], pb[4];
+    u32x2 ga[NB][4], gb[NB][4], pb[4];
     {
       const LaneCtx lc = lane_ctx(lane, wave);
 #pragma unroll
-      for (int mi = 0; mi < 3; ++mi) {
+      for (int mi = 0; mi < NB; ++mi) {
         const int m = r0 + min(mi * 16 + lc.x, nr - 1);
         const T* r1 = (const T*)a.g1 + (int64_t)a.idx1[m] * a.ld_g1 + wave * 64 + lc.g * 4;
         const T* r2 = (const T*)a.g2 + (int64_t)a.idx2[m] * a.ld_g2 + wave * 64 + lc.g * 4;
@@ -99,14 +107,14 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
     load_cols<T>((const T*)a.b0, wave, g, pb);
     __builtin_amdgcn_sched_barrier(0);
 
-    f32x4 acc[3][4];
-    // ---- h1 = gelu(e W_e^T + g1[dst] + g2[src] + b0) -> bufB
-    zero_acc<T>(acc);
-    gemm_seg<T>(bufA, lane, bq, w0, w1, loff, acc);
+    f32x4 acc[NB][4];
+    // ---- h1 = gelu(e W_e^T + g1[dst] + g2[src] + b0) -> bufH
+    zero_acc<T, NB>(acc);
+    gemm_seg<T, NB>(bufE, lane, bq, w0, w1, loff, acc);
     {
       const LaneCtx lc = lane_ctx(lane, wave);
 #pragma unroll
-      for (int mi = 0; mi < 3; ++mi)
+      for (int mi = 0; mi < NB; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
           float bias[4], t1[4], t2[4], t[4];
@@ -117,29 +125,35 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
           for (int r = 0; r < 4; ++r) t[r] = (acc[mi][ni][r] + bias[r]) + (t1[r] + t2[r]);  // the association of linear.hip's gather-add epilogue
           gelu_fast2(t[0], t[1]);
           gelu_fast2(t[2], t[3]);
-          *reinterpret_cast<u32x2*>(bufB + (mi * 16 + lc.x) * kRowBytes + lc.coff[ni]) = pack4<T>(t);
+          *reinterpret_cast<u32x2*>(bufH + (mi * 16 + lc.x) * kRowBytes + lc.coff[ni]) = pack4<T>(t);
         }
     }
     load_cols<T>((const T*)a.b1, wave, g, pb);
     __builtin_amdgcn_sched_barrier(0);
     lds_barrier();
-    // ---- h2 = gelu(h1 W_1^T + b1) -> bufC
-    zero_acc<T>(acc);
-    gemm_seg<T>(bufB, lane, bq, w1, w2, loff, acc);
+    // ---- h2 = gelu(h1 W_1^T + b1), written over h1 once every wave has read its last fragment of it
+    zero_acc<T, NB>(acc);
+    gemm_seg<T, NB>(bufH, lane, bq, w1, w2, loff, acc);
+    u32x2 hp[NB][4];
+#pragma unroll
+    for (int mi = 0; mi < NB; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        float bias[4], t[4];
+        unpack4<T>(pb[ni], bias);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] = acc[mi][ni][r] + bias[r];
+        gelu_fast2(t[0], t[1]);
+        gelu_fast2(t[2], t[3]);
+        hp[mi][ni] = pack4<T>(t);
+      }
+    lds_barrier();
     {
       const LaneCtx lc = lane_ctx(lane, wave);
 #pragma unroll
-      for (int mi = 0; mi < 3; ++mi)
+      for (int mi = 0; mi < NB; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-          float bias[4], t[4];
-          unpack4<T>(pb[ni], bias);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) t[r] = acc[mi][ni][r] + bias[r];
-          gelu_fast2(t[0], t[1]);
-          gelu_fast2(t[2], t[3]);
-          *reinterpret_cast<u32x2*>(bufC + (mi * 16 + lc.x) * kRowBytes + lc.coff[ni]) = pack4<T>(t);
-        }
+        for (int ni = 0; ni < 4; ++ni) *reinterpret_cast<u32x2*>(bufH + (mi * 16 + lc.x) * kRowBytes + lc.coff[ni]) = hp[mi][ni];
     }
     u32x2 pg[4], pt[4];
     load_cols<T>((const T*)a.b2, wave, g, pb);
@@ -153,16 +167,14 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
     __builtin_amdgcn_sched_barrier(0);
     lds_barrier();
     // ---- z = h2 W_2^T + b2 (rounded, as the Linear's output is); e' = LayerNorm(z) + e -> global
-    zero_acc<T>(acc);
-    gemm_seg<T>(bufC, lane, bq, w2, w0, loff, acc);  // (behind it: the next panel's first segment; after the last panel a harmless re-read)
+    zero_acc<T, NB>(acc);
+    gemm_seg<T, NB>(bufH, lane, bq, w2, w0, loff, acc);  // (behind it: the next panel's first segment; after the last panel a harmless re-read)
     const int next_tile = tile + (int)gridDim.x;
     const bool more = next_tile < a.n_tiles;
-    if (more) request_panel(next_tile);  // the next panel's rows travel under this panel's LayerNorm and stores
-    __builtin_amdgcn_sched_barrier(0);
     {
       const LaneCtx lc = lane_ctx(lane, wave);
 #pragma unroll
-      for (int mi = 0; mi < 3; ++mi)
+      for (int mi = 0; mi < NB; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
           float bias[4], t[4];
@@ -173,26 +185,28 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[mi][ni][r] = t[r];
         }
-      float mean[3], rstd[3];
-      panel_row_stats<T>(acc, a.ln_eps, red, wave, lc.x, lc.g, mean, rstd);  // (one barrier: behind it no wave reads bufB / bufC)
-      u32x2 pk[3][4];
+      float mean[NB], rstd[NB];
+      panel_row_stats<T, NB>(acc, a.ln_eps, red, wave, lc.x, lc.g, mean, rstd);  // (one barrier: behind it no wave reads bufH)
+      u32x2 pk[NB][4];
 #pragma unroll
-      for (int mi = 0; mi < 3; ++mi)
+      for (int mi = 0; mi < NB; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
           float gv[4], bv[4], ev[4], o[4];
           unpack4<T>(pg[ni], gv);
           unpack4<T>(pt[ni], bv);
-          unpack4<T>(*reinterpret_cast<const u32x2*>(bufA + (mi * 16 + lc.x) * kRowBytes + lc.coff[ni]), ev);
+          unpack4<T>(*reinterpret_cast<const u32x2*>(bufE + (mi * 16 + lc.x) * kRowBytes + lc.coff[ni]), ev);
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[r] = fmaf((acc[mi][ni][r] - mean[mi]) * rstd[mi], gv[r], bv[r]) + ev[r];  // edge_ln_res_segsum's arithmetic
           pk[mi][ni] = pack4<T>(o);
         }
-      store_block_via_strip<T>(pk, bufB + wave * (kPanel * 128), (T*)a.e_new + (int64_t)r0 * a.ld_o + wave * 64, a.ld_o, nr, lane, wave);
+      store_block_via_strip<T, NB>(pk, bufH + wave * (kERows * 128), (T*)a.e_new + (int64_t)r0 * a.ld_o + wave * 64, a.ld_o, nr, lane, wave);
     }
     if (!more) break;
     tile = next_tile;
-    lds_barrier();  // every wave has read its residual values from bufA and emptied its strip
+    request_panel(tile);  // (requested only here: 32 more live registers across the LayerNorm epilogue spill)
+    __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();  // every wave has read its residual values from bufE and emptied its strip
   }
 }
 
@@ -391,12 +405,12 @@ __global__ __launch_bounds__(512, 1) void gnn_node_chain_kernel(NodeChainArgs a)
   }
 }
 
-static int chain_rows_per_tile(int n_rows) {
-  static const int forced = env_int(getenv("ANEMOI_CHAIN_ROWS"), 0, 0, kPanel);
-  if (forced > 0) return forced;
-  const int64_t rounds = ((int64_t)n_rows + 256 * kPanel - 1) / (256 * kPanel);
+static int chain_rows_per_tile(int n_rows, int cap = kPanel) {
+  static const int forced = env_int(getenv("ANEMOI_CHAIN_ROWS"), 0, 0, 64);
+  if (forced > 0) return forced < cap ? forced : cap;
+  const int64_t rounds = ((int64_t)n_rows + 256 * cap - 1) / (256 * cap);
   const int64_t r = ((int64_t)n_rows + 256 * rounds - 1) / (256 * rounds);
-  return (int)(r < 1 ? 1 : (r > kPanel ? kPanel : r));
+  return (int)(r < 1 ? 1 : (r > cap ? cap : r));
 }
 
 }  // namespace anemoi
@@ -418,18 +432,18 @@ extern "C" int anemoi_gnn_edge_chain_fwd(const void* e, int64_t ld_e, const void
                      ld_g1 >= kCh && ld_g2 >= kCh,
                  "gnn_edge_chain_fwd: operand alignment / leading dimensions");
   EdgeChainArgs a{e, ld_e, g1, ld_g1, idx1, g2, ld_g2, idx2, (const char*)w0, b0, (const char*)w1, b1, (const char*)w2, b2, ln_w, ln_b, eps, e_new, ld_o,
-                  n_rows, chain_rows_per_tile(n_rows), 0};
+                  n_rows, chain_rows_per_tile(n_rows, kERows), 0};
   a.n_tiles = (n_rows + a.rows_per_tile - 1) / a.rows_per_tile;
   const int grid = a.n_tiles < 256 ? a.n_tiles : 256;
   hipStream_t st = as_stream(stream);
   if (dtype == ANEMOI_BF16) {
     static PerDeviceOnce once;
-    once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gnn_edge_chain_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, kChainSmem); });
-    hipLaunchKernelGGL((gnn_edge_chain_kernel<bf16_t>), dim3(grid), dim3(512), kChainSmem, st, a);
+    once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gnn_edge_chain_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, kEdgeSmem); });
+    hipLaunchKernelGGL((gnn_edge_chain_kernel<bf16_t>), dim3(grid), dim3(512), kEdgeSmem, st, a);
   } else {
     static PerDeviceOnce once;
-    once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gnn_edge_chain_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, kChainSmem); });
-    hipLaunchKernelGGL((gnn_edge_chain_kernel<f16_t>), dim3(grid), dim3(512), kChainSmem, st, a);
+    once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gnn_edge_chain_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, kEdgeSmem); });
+    hipLaunchKernelGGL((gnn_edge_chain_kernel<f16_t>), dim3(grid), dim3(512), kEdgeSmem, st, a);
   }
   return check_launch("gnn_edge_chain_kernel");
 }

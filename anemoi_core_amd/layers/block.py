@@ -20,7 +20,8 @@ from ..distributed import primitives as comm
 from ..distributed.halo import HaloInfo, build_halo_info
 from ..distributed.partition import build_graph_partition_from_shard_info
 from ..distributed.shapes import BipartiteGraphShardInfo, GraphShardInfo, comm_rank, comm_size, model_is_distributed
-from .conv import GraphConv
+from .conv import GraphConv, mlp_chain_ok, node_mlp_chain
+from . import conv as _conv
 from .graphcache import get_csc, get_edge_features, get_reverse_csr
 from .kernels import PaddedLinear
 from .normalization import ConditionalLayerNorm, apply_layer_norm
@@ -47,10 +48,6 @@ _LN_FOLD_MIN_ROWS = int(os.environ.get("ANEMOI_LN_FOLD_MIN_ROWS", "512"))
 # (ANEMOI_LAYER_CHAIN=1), kept under test with its in-kernel timeline (tools/chain_timeline.py).
 _LAYER_CHAIN = os.environ.get("ANEMOI_LAYER_CHAIN", "0") == "1"
 _LAYER_CHAIN_MIN_ROWS = int(os.environ.get("ANEMOI_LAYER_CHAIN_MIN_ROWS", "0"))
-# The GraphConv (GNN) processor block's edge MLP + LayerNorm + residual and its node MLP + LayerNorm + skip (+ the next block's stacked
-# node-level projection) as ONE launch each (ops.gnn_edge_chain / gnn_node_chain, csrc/gnn_chain.hip).  ANEMOI_GNN_CHAIN=0: the
-# launch-per-GEMM path (same-box A/Bs).
-_GNN_CHAIN = os.environ.get("ANEMOI_GNN_CHAIN", "1") == "1"
 
 
 _IDENTITY: dict = {}
@@ -642,75 +639,12 @@ class GraphConvBaseBlock(BaseBlock):
 
 
 class GraphConvProcessorBlock(GraphConvBaseBlock):
-    def _chain_ok(self, x: Tensor, edge_attr: Tensor) -> bool:
-        """The row-resident chain kernels take this block: inference, 16-bit, 512 channels, both MLPs Linear-GELU-Linear-GELU-Linear
-        with a plain affine LayerNorm (mlp_extra_layers = 0, mlp_implementation = "mlp")."""
-        D = ops.CHAIN_CHANNELS
-        em, nm = self.conv.edge_mlp, self.node_mlp
-
-        def mlp_ok(m, k_in):
-            return (m.mlp_implementation == "mlp" and len(m.mlp) == 5 and m.layer_norm is not None
-                    and type(m.layer_norm).__name__ in ("LayerNorm", "AutocastLayerNorm") and m.layer_norm.weight is not None
-                    and m.mlp[0].weight.shape == (D, k_in) and m.mlp[2].weight.shape == (D, D) and m.mlp[4].weight.shape == (D, D)
-                    and all(m.mlp[i].bias is not None for i in (0, 2, 4)))
-
-        return (_GNN_CHAIN and x.is_cuda and x.dtype != torch.float32 and x.shape[1] == D and edge_attr.shape[1] == D and edge_attr.dtype == x.dtype
-                and mlp_ok(em, 3 * D) and mlp_ok(nm, 2 * D)
-                and not (torch.is_grad_enabled() and (x.requires_grad or edge_attr.requires_grad or em.mlp[0].weight.requires_grad)))
-
-    def _stacked_frag(self) -> Tensor:
-        """fragment-major image of [W_i; W_j] (the node-level halves of the edge MLP's first Linear): the trailing projection of the
-        PREVIOUS block's node chain."""
-        w = self.conv.edge_mlp.mlp[0].weight
-        D = w.shape[0]
-        return self._fw().derived("stacked", [w], lambda: ops.pack_weight_frag(torch.cat([w[:, :D], w[:, D:2 * D]], dim=0)))
-
-    def _fw(self) -> "_FusedWeights":
-        fw = self.__dict__.get("_fused_w")
-        if fw is None:
-            fw = self.__dict__["_fused_w"] = _FusedWeights()
-        return fw
-
-    def _forward_chain(self, x: Tensor, edge_attr: Tensor, edge_index: Tensor, chain: Optional[dict], next_block):
-        D = ops.CHAIN_CHANNELS
-        n = x.shape[0]
-        csc = get_csc(edge_index, (n, n), True)
-        em, nm, fw = self.conv.edge_mlp, self.node_mlp, self._fw()
-        p = None
-        if chain is not None and chain.get("p_x") is x:  # the previous block's node chain computed this block's stacked node-level terms
-            p = chain["p"]
-        if chain is not None:
-            chain.clear()
-        if p is None:
-            p = ops.linear(x, self.conv._stacked_node_weight(em.mlp[0].weight, D))
-        w0 = fw.derived("w0e", [em.mlp[0].weight], lambda: ops.pack_weight_frag(em.mlp[0].weight[:, 2 * D:]))
-        w1 = fw.derived("e1", [em.mlp[2].weight], lambda: ops.pack_weight_frag(em.mlp[2].weight))
-        w2 = fw.derived("e2", [em.mlp[4].weight], lambda: ops.pack_weight_frag(em.mlp[4].weight))
-        ln = em.layer_norm
-        e_new = ops.gnn_edge_chain(edge_attr, p[:, :D], csc.dst, p[:, D:], csc.row, w0, em.mlp[0].bias, w1, em.mlp[2].bias, w2, em.mlp[4].bias,
-                                   ln.weight, ln.bias, ln.eps)
-        agg = ops.segment_sum_rows(e_new, csc.colptr)
-        wa = fw.derived("na", [nm.mlp[0].weight], lambda: ops.pack_weight_frag(nm.mlp[0].weight))
-        wb = fw.derived("nb", [nm.mlp[2].weight], lambda: ops.pack_weight_frag(nm.mlp[2].weight))
-        wc = fw.derived("nc", [nm.mlp[4].weight], lambda: ops.pack_weight_frag(nm.mlp[4].weight))
-        ln = nm.layer_norm
-        kw = {}
-        if chain is not None and isinstance(next_block, GraphConvProcessorBlock) and next_block._chain_ok(x, e_new):
-            kw = dict(wt=next_block._stacked_frag(), t_out_features=2 * D)
-        res = ops.gnn_node_chain(x, agg, wa, nm.mlp[0].bias, wb, nm.mlp[2].bias, wc, nm.mlp[4].bias, ln.weight, ln.bias, ln.eps, **kw)
-        if kw:
-            chain["p_x"], chain["p"] = res
-            return res[0], e_new
-        return res, e_new
-
     def forward(self, x: Tensor, edge_attr: Tensor, edge_index: Tensor, shard_info: GraphShardInfo, model_comm_group=None,
                 size=None, **layer_kwargs):
         if self.emb_edges is not None:
             edge_attr = self.emb_edges(edge_attr)
         chain = layer_kwargs.get("gnn_chain")
         nxt = None if chain is None else chain.pop("next_block", None)
-        if not model_is_distributed(model_comm_group) and self._chain_ok(x, edge_attr):
-            return self._forward_chain(x, edge_attr, edge_index, chain, nxt)
         if model_is_distributed(model_comm_group):  # block.py:375: all node rows are needed as sources
             x_in = comm.gather_tensor(x, 0, shard_info.nodes, model_comm_group, reduce_in_backward=True)
             n_loc = x.shape[0]
@@ -719,7 +653,21 @@ class GraphConvProcessorBlock(GraphConvBaseBlock):
             out = out_full
             assert out.shape[0] == n_loc
         else:
-            out, edges_new = self.conv(x, edge_attr, edge_index, size=size)
+            # inference on the chain kernels: the previous block's node chain may have left this block's stacked node-level terms
+            p = chain["p"] if (chain is not None and chain.get("p_x") is x and self.conv.chain_ok(x, edge_attr)) else None
+            if chain is not None:
+                chain.clear()
+            out, edges_new = self.conv(x, edge_attr, edge_index, size=size, p=p)
+        if mlp_chain_ok(self.node_mlp, 2 * ops.CHAIN_CHANNELS, x) and out.dtype == x.dtype:
+            kw = {}
+            if (chain is not None and not model_is_distributed(model_comm_group) and isinstance(nxt, GraphConvProcessorBlock)
+                    and nxt.emb_edges is None and nxt.conv.chain_ok(x, edges_new)):
+                kw = dict(wt=nxt.conv.stacked_frag(), t_out_features=2 * ops.CHAIN_CHANNELS)
+            res = node_mlp_chain(self.node_mlp, x, out, **kw)
+            if kw:
+                chain["p_x"], chain["p"] = res
+                return res[0], edges_new
+            return res, edges_new
         nodes_new = self.node_mlp(x, x2=out, residual=x)
         return nodes_new, edges_new
 
@@ -751,6 +699,12 @@ class GraphConvMapperBlock(GraphConvBaseBlock):
         (the same tensor when nothing is sharded)."""
         size = (x_src_conv.shape[0], x_dst.shape[0]) if size is None else size
         out, edges_new = self.conv((x_src_conv, x_dst), edge_attr, edge_index, size=size)
-        nodes_new_dst = self.node_mlp(x_dst, x2=out, residual=x_dst)
-        nodes_new_src = self.node_mlp(x_src_update, x2=x_src_update, residual=x_src_update) if self.update_src_nodes else x_src_update
+
+        def node(xr, x2):  # LayerNorm(node_mlp([x | x2])) + x: one row-resident launch where the chain kernel takes the shapes
+            if mlp_chain_ok(self.node_mlp, 2 * ops.CHAIN_CHANNELS, xr) and x2.dtype == xr.dtype and xr.dim() == 2:
+                return node_mlp_chain(self.node_mlp, xr, x2)
+            return self.node_mlp(xr, x2=x2, residual=xr)
+
+        nodes_new_dst = node(x_dst, out)
+        nodes_new_src = node(x_src_update, x_src_update) if self.update_src_nodes else x_src_update
         return (nodes_new_src, nodes_new_dst), edges_new

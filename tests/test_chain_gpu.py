@@ -288,7 +288,7 @@ def test_gnn_node_chain_vs_fp32_restatement(dtype, N, trailing):
 def test_gnn_model_with_chains_equals_model_without():
     """The 512-channel GNN model: chain launches (edge chain + segment sum + node chain with the next block's stacked projection) against
     the launch-per-GEMM path and the fp32 CPU oracle."""
-    import anemoi_core_amd.layers.block as B
+    import anemoi_core_amd.layers.conv as B
     from anemoi_core_amd.graphs.synthetic import build_synthetic_graph
     from anemoi_core_amd.models import AnemoiModelEncProcDec
     from anemoi_core_amd.models.configs import make_data_indices, model_config
