@@ -247,6 +247,23 @@ def profile_forward(step, dtype, host_ms: float = 12.0):
         extra = 1 if kw.get("extra") is not None else 0
         return "gt_chain_kernel", 2.0 * N * (D * D + 2 * D * Hd + D * Oq), es * (N * D * (3 + extra) + N * Oq + D * D + 2 * D * Hd + D * Oq)
 
+    def edge_chain_work(res_, a_, kw):
+        # GraphConv's edge MLP (three [M x 512] -> 512 GEMMs in gather-add form) + LayerNorm + residual in one launch: e in, e' out,
+        # the two gathered node-level rows per edge, the indices, every weight once
+        e = a_[0]
+        M, D = e.shape
+        return "gnn_edge_chain_kernel", 2.0 * M * 3 * D * D, es * (4 * M * D + 3 * D * D) + 8 * M
+
+    def node_chain_work(res_, a_, kw):
+        x = a_[0]
+        N, D = x.shape
+        T = kw.get("t_out_features", 0) if kw.get("wt") is not None else 0
+        return "gnn_node_chain_kernel", 2.0 * N * (4 * D * D + D * T), es * (3 * N * D + N * T + 4 * D * D + D * T)
+
+    def segrows_work(res_, a_, kw):
+        x, ptr = a_[0], a_[1]
+        return "segment_sum_rows_kernel", 0.0, es * (x.numel() + (ptr.shape[0] - 1) * x.shape[1]) + 4 * ptr.shape[0]
+
     def segsum_work(res_, a_, kw):
         z, csc = a_[0], a_[5]  # read z, e_old; write e_new, agg (2(3 M D + N D))
         M, D = z.shape
@@ -260,7 +277,8 @@ def profile_forward(step, dtype, host_ms: float = 12.0):
 
     table = {"linear": ("linear", lin_work), "gt_attention_fused_edge": ("attn", attn_work), "layer_norm": ("ln", ln_work),
              "linear_with_row_stats": ("linear_stats", gemm_work), "linear_ln_folded": ("linear_lnfold", gemm_work),
-             "gt_layer_chain": ("chain", chain_work),
+             "gt_layer_chain": ("chain", chain_work), "gnn_edge_chain": ("edge_chain", edge_chain_work),
+             "gnn_node_chain": ("node_chain", node_chain_work), "segment_sum_rows": ("segrows", segrows_work),
              "edge_ln_residual_segment_sum": ("segsum", segsum_work), "gather_rows": ("gather", rows_work("gather_rows_kernel")),
              "gather_add_rows": ("gather_add", rows_work("gather_add_rows_kernel"))}
     saved = {n: getattr(ops, n) for n in table}
@@ -883,7 +901,7 @@ def main():
                                       "same 48 back to back, same backed-up queue: an upper bound); `rocprof_cross_check` = the family's "
                                       "duration in the committed rocprofv3 --kernel-trace summary of the timed replays (profiles/)")
             res["roofline"]["rocprof_cross_check"] = rocprof_cross_check(args.config, dom, fam[dom], "mfma" if fam[dom]["flops"] else "hbm")
-            gs = "gt_attn_fused_edge_fwd_kernel" if args.kind == "gt" else "edge_ln_res_segsum_kernel"
+            gs = "gt_attn_fused_edge_fwd_kernel" if args.kind == "gt" else ("segment_sum_rows_kernel" if "segment_sum_rows_kernel" in fam else "edge_ln_res_segsum_kernel")
             if gs in fam:
                 res["roofline"]["gather_scatter"] = roof(gs, "hbm")
                 res["roofline"]["gather_scatter"]["rocprof_cross_check"] = rocprof_cross_check(args.config, gs, fam[gs], "hbm")
