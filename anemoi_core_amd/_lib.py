@@ -9,7 +9,7 @@ import ctypes as C
 import os
 import threading
 
-ABI_VERSION = 11
+ABI_VERSION = 10
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libanemoi_hip.so")
 
 F32, BF16, F16 = 0, 1, 2
@@ -68,9 +68,7 @@ SIGNATURES = {
     "anemoi_peer_close": ([_p], C.c_int),
     "anemoi_gt_chain_fwd": ([_p, C.c_int, _p], C.c_int),
     "anemoi_gt_chain_rows_per_tile": ([_i32], C.c_int),
-    "anemoi_gnn_edge_chain_workspace_floats": ([_i32], _i64),
-    "anemoi_gnn_edge_chain_fwd": ([_p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _i64, _p, _p, _i64, _i32, _p, _i32, _i32,
-                                   C.c_int, _p], C.c_int),
+    "anemoi_gnn_edge_chain_fwd": ([_p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _i64, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_gnn_node_chain_fwd": ([_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _i64, _p, _p, _i32, _p, _i64, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_peer_exchange_rows": ([_p, _i64, _p, _p, _i32, _i32, _i32, _p, _p, _i64, _p], C.c_int),
 }

@@ -225,7 +225,7 @@ __device__ __forceinline__ void panel_layernorm(f32x4 (&v)[3][4], const u32x2 (&
 // lines: through a wave-private LDS strip (row m, 16-byte slot s at m*128 + ((s ^ ((m >> 1) & 7)) << 4): conflict-free for the
 // 8-byte writes in the MFMA layout and for the 16-byte row-major read-back), 6 stores of 16 bytes per lane.  `out` = address of
 // (panel row 0, the wave's first column); the wave's own LDS operations are ordered: no barrier.
-template <typename T, int NB = 3, bool KEEP = false>  // KEEP: the caller goes on reading the strip and waits for the LDS reads itself
+template <typename T, int NB = 3>
 __device__ __forceinline__ void store_block_via_strip(const u32x2 (&pk)[NB][4], unsigned char* strip, T* out, int64_t ld, int nr, int lane, int wave) {
   const LaneCtx lc = lane_ctx(lane, wave);
 #pragma unroll
@@ -243,7 +243,7 @@ __device__ __forceinline__ void store_block_via_strip(const u32x2 (&pk)[NB][4], 
     const u32x4 v = *reinterpret_cast<const u32x4*>(strip + m * 128 + ((sl ^ ((m >> 1) & 7)) << 4));
     if (m < nr) *reinterpret_cast<u32x4*>(out + (int64_t)m * ld + sl * 8) = v;
   }
-  if constexpr (!KEEP) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the strip may be rewritten
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the strip may be rewritten
 }
 
 }  // namespace anemoi

@@ -26,10 +26,6 @@ struct EdgeChainArgs {
   const char* w2;  const void* b2;
   const void* ln_g; const void* ln_b; float ln_eps;
   void* e_new;     int64_t ld_o;
-  // optional: the scatter-sum of e_new over the destinations (idx1 = the SORTED destination of every edge row, colptr its CSC
-  // pointer): destinations whose edges lie inside one panel are summed from the panel's staging strips and written here;
-  // those cut by a panel boundary leave fp32 partial rows in `part` [n_tiles][2][512] for gnn_segsum_fixup_kernel
-  const int32_t* colptr; void* agg; int64_t ld_agg; float* part; int n_dst;
   int n_rows, rows_per_tile, n_tiles;
 };
 
@@ -204,42 +200,7 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
           for (int r = 0; r < 4; ++r) o[r] = fmaf((acc[mi][ni][r] - mean[mi]) * rstd[mi], gv[r], bv[r]) + ev[r];  // edge_ln_res_segsum's arithmetic
           pk[mi][ni] = pack4<T>(o);
         }
-      unsigned char* const strip = bufH + wave * (kERows * 128);
-      store_block_via_strip<T, NB, true>(pk, strip, (T*)a.e_new + (int64_t)r0 * a.ld_o + wave * 64, a.ld_o, nr, lane, wave);
-      if (a.colptr != nullptr) {
-        // ---- segment sums from the strip (row m, this wave's 64 columns): the two half-waves take alternate rows of a destination,
-        // a lane 2 columns; fp32 sums of the STORED (rounded) values, as anemoi_segment_sum_rows over e_new
-        const int d_lo = __builtin_amdgcn_readfirstlane(a.idx1[r0]), d_hi = __builtin_amdgcn_readfirstlane(a.idx1[r0 + nr - 1]);
-        const int cp = lane & 31, half = lane >> 5;
-        for (int base = d_lo; base <= d_hi; base += 64) {  // (more than 64 destinations per panel only with runs of destinations without edges)
-          const int c0 = a.colptr[min(base + lane, a.n_dst)], c1 = a.colptr[min(base + lane + 1, a.n_dst)];
-          const int nj = min(64, d_hi - base + 1);
-          for (int j = 0; j < nj; ++j) {
-            const int sb = __builtin_amdgcn_readlane(c0, j), se = __builtin_amdgcn_readlane(c1, j);  // the destination's edge rows (global)
-            const int ra = max(sb, r0) - r0, rb = min(se, r0 + nr) - r0;
-            float s0 = 0.f, s1 = 0.f;
-            for (int m = ra + half; m < rb; m += 2) {
-              const unsigned w = *reinterpret_cast<const unsigned*>(strip + m * 128 + (((cp >> 2) ^ ((m >> 1) & 7)) << 4) + (cp & 3) * 4);
-              float v[4];
-              unpack4<T>(u32x2{w, 0u}, v);
-              s0 += v[0];
-              s1 += v[1];
-            }
-            s0 += __shfl_xor(s0, 32, 64);
-            s1 += __shfl_xor(s1, 32, 64);
-            if (half == 0) {
-              const int d = base + j;
-              if (sb >= r0 && se <= r0 + nr) {  // every edge of the destination is in this panel
-                const float o[4] = {s0, s1, 0.f, 0.f};
-                *reinterpret_cast<unsigned*>((T*)a.agg + (int64_t)d * a.ld_agg + wave * 64 + cp * 2) = pack4<T>(o)[0];
-              } else {  // cut by the panel's first row (slot 0) or only by its last (slot 1)
-                *reinterpret_cast<float2*>(a.part + ((size_t)tile * 2 + (sb < r0 ? 0 : 1)) * kCh + wave * 64 + cp * 2) = make_float2(s0, s1);
-              }
-            }
-          }
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the strip may be rewritten
+      store_block_via_strip<T, NB>(pk, bufH + wave * (kERows * 128), (T*)a.e_new + (int64_t)r0 * a.ld_o + wave * 64, a.ld_o, nr, lane, wave);
     }
     if (!more) break;
     tile = next_tile;
@@ -247,41 +208,6 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
     __builtin_amdgcn_sched_barrier(0);
     lds_barrier();  // every wave has read its residual values from bufE and emptied its strip
   }
-}
-
-// Destinations whose edges straddle a panel boundary of gnn_edge_chain_kernel: tile t owns the destination d of its LAST row when d's
-// first edge lies in t and its last edge beyond t; its sum = the partial of t (slot 1) + the partials (slot 0) of the following
-// tiles up to the one holding d's last edge, added in tile order (deterministic), rounded once.
-template <typename T>
-__global__ __launch_bounds__(64) void gnn_segsum_fixup_kernel(const int32_t* __restrict__ dst, const int32_t* __restrict__ colptr,
-                                                              const float* __restrict__ part, T* __restrict__ agg, int64_t ld_agg, int n_rows,
-                                                              int rows_per_tile, int n_tiles, int n_dst) {
-  const int t = blockIdx.x;
-  const int64_t row_end = min((int64_t)(t + 1) * rows_per_tile, (int64_t)n_rows);
-  const int d = dst[row_end - 1];
-  const int c = threadIdx.x * 8;
-  {
-    // destinations WITHOUT edges that lie between this tile's last destination and the next tile's first one (or behind the last
-    // tile's; in front of the first tile's): no panel meets them - their sums are zero rows
-    const int g0 = t == 0 ? 0 : d + 1, g1 = t == 0 ? dst[0] : (t + 1 < n_tiles ? dst[row_end] : n_dst);
-    const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int gd = g0; gd < g1; ++gd) store_vec<T, 8>(agg + (int64_t)gd * ld_agg + c, z);
-    if (t == 0 && n_tiles > 1)
-      for (int gd = d + 1; gd < dst[row_end]; ++gd) store_vec<T, 8>(agg + (int64_t)gd * ld_agg + c, z);
-  }
-  const int sb = colptr[d], se = colptr[d + 1];
-  if (se <= row_end || sb < (int64_t)t * rows_per_tile) return;  // not cut at this tile's end / owned by an earlier tile
-  float s[8];
-  const float* p = part + ((size_t)t * 2 + 1) * kCh + c;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) s[i] = p[i];
-  for (int u = t + 1; u < n_tiles; ++u) {
-    const float* q = part + (size_t)u * 2 * kCh + c;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s[i] += q[i];
-    if (se <= min((int64_t)(u + 1) * rows_per_tile, (int64_t)n_rows)) break;
-  }
-  store_vec<T, 8>(agg + (int64_t)d * ld_agg + c, s);
 }
 
 struct NodeChainArgs {
@@ -493,17 +419,10 @@ using namespace anemoi;
 
 static bool al(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
-extern "C" int64_t anemoi_gnn_edge_chain_workspace_floats(int32_t n_rows) {
-  if (n_rows <= 0) return 0;
-  const int r = chain_rows_per_tile(n_rows, kERows);
-  return (int64_t)((n_rows + r - 1) / r) * 2 * kCh;
-}
-
 extern "C" int anemoi_gnn_edge_chain_fwd(const void* e, int64_t ld_e, const void* g1, int64_t ld_g1, const int32_t* idx1, const void* g2,
                                          int64_t ld_g2, const int32_t* idx2, const void* w0, const void* b0, const void* w1, const void* b1,
                                          const void* w2, const void* b2, const void* ln_w, const void* ln_b, float eps, void* e_new,
-                                         int64_t ld_o, const int32_t* colptr, void* agg, int64_t ld_agg, int32_t n_dst, float* workspace,
-                                         int32_t n_rows, int32_t channels, anemoi_dtype_t dtype, void* stream) {
+                                         int64_t ld_o, int32_t n_rows, int32_t channels, anemoi_dtype_t dtype, void* stream) {
   ANEMOI_REQUIRE(dtype == ANEMOI_BF16 || dtype == ANEMOI_F16, "gnn_edge_chain_fwd: 16-bit model dtypes only");
   ANEMOI_REQUIRE(n_rows >= 0 && channels == kCh, "gnn_edge_chain_fwd: channels=%d (this kernel is built for %d)", channels, kCh);
   if (n_rows == 0) return ANEMOI_OK;
@@ -512,10 +431,8 @@ extern "C" int anemoi_gnn_edge_chain_fwd(const void* e, int64_t ld_e, const void
                      al(ln_w, 8) && al(ln_b, 8) && ld_e % 8 == 0 && ld_o % 8 == 0 && ld_g1 % 4 == 0 && ld_g2 % 4 == 0 && ld_e >= kCh && ld_o >= kCh &&
                      ld_g1 >= kCh && ld_g2 >= kCh,
                  "gnn_edge_chain_fwd: operand alignment / leading dimensions");
-  ANEMOI_REQUIRE(colptr == nullptr || (agg != nullptr && workspace != nullptr && n_dst > 0 && ld_agg >= kCh && ld_agg % 8 == 0 && al(agg, 16)),
-                 "gnn_edge_chain_fwd: the scatter-sum needs agg, a workspace (anemoi_gnn_edge_chain_workspace_floats) and n_dst");
   EdgeChainArgs a{e, ld_e, g1, ld_g1, idx1, g2, ld_g2, idx2, (const char*)w0, b0, (const char*)w1, b1, (const char*)w2, b2, ln_w, ln_b, eps, e_new, ld_o,
-                  colptr, agg, ld_agg, workspace, n_dst, n_rows, chain_rows_per_tile(n_rows, kERows), 0};
+                  n_rows, chain_rows_per_tile(n_rows, kERows), 0};
   a.n_tiles = (n_rows + a.rows_per_tile - 1) / a.rows_per_tile;
   const int grid = a.n_tiles < 256 ? a.n_tiles : 256;
   hipStream_t st = as_stream(stream);
@@ -528,15 +445,7 @@ extern "C" int anemoi_gnn_edge_chain_fwd(const void* e, int64_t ld_e, const void
     once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gnn_edge_chain_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, kEdgeSmem); });
     hipLaunchKernelGGL((gnn_edge_chain_kernel<f16_t>), dim3(grid), dim3(512), kEdgeSmem, st, a);
   }
-  const int rc = check_launch("gnn_edge_chain_kernel");
-  if (rc != ANEMOI_OK || colptr == nullptr) return rc;
-  if (dtype == ANEMOI_BF16)
-    hipLaunchKernelGGL((gnn_segsum_fixup_kernel<bf16_t>), dim3(a.n_tiles), dim3(64), 0, st, idx1, colptr, workspace, (bf16_t*)agg, ld_agg, n_rows, a.rows_per_tile,
-                       a.n_tiles, n_dst);
-  else
-    hipLaunchKernelGGL((gnn_segsum_fixup_kernel<f16_t>), dim3(a.n_tiles), dim3(64), 0, st, idx1, colptr, workspace, (f16_t*)agg, ld_agg, n_rows, a.rows_per_tile,
-                       a.n_tiles, n_dst);
-  return check_launch("gnn_segsum_fixup_kernel");
+  return check_launch("gnn_edge_chain_kernel");
 }
 
 extern "C" int anemoi_gnn_node_chain_fwd(const void* x, int64_t ld_x, const void* agg, int64_t ld_a, const void* wa, const void* ba, const void* wb,

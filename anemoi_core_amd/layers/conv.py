@@ -142,9 +142,9 @@ class GraphConv(nn.Module):
             w1 = _derived(self, "e1", [em.mlp[2].weight], lambda: P(em.mlp[2].weight))
             w2 = _derived(self, "e2", [em.mlp[4].weight], lambda: P(em.mlp[4].weight))
             ln = em.layer_norm
-            edges_new, out = ops.gnn_edge_chain(edge_attr, p_dst, csc.dst, p_src, csc.row, w0, lin0.bias, w1, em.mlp[2].bias, w2, em.mlp[4].bias,
-                                                ln.weight, ln.bias, ln.eps, colptr=csc.colptr)
-            return out, edges_new
+            edges_new = ops.gnn_edge_chain(edge_attr, p_dst, csc.dst, p_src, csc.row, w0, lin0.bias, w1, em.mlp[2].bias, w2, em.mlp[4].bias,
+                                           ln.weight, ln.bias, ln.eps)
+            return ops.segment_sum_rows(edges_new, csc.colptr), edges_new
         if gated:  # first layer = gating(gate_proj(cat)) * value_proj(cat): the same gather-add GEMM on the fused [gate; value] weight
             w, bias0 = lin0.fused_weights()
         else:

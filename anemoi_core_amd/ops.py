@@ -813,17 +813,12 @@ def gt_layer_chain(attn: Tensor, x_res: Tensor, wp: Tensor, bp: Tensor, ln1_w: T
     return x_out if q_out is None else (x_out, q_out)
 
 
-_EDGE_WS: dict = {}
-
-
 def gnn_edge_chain(e: Tensor, g1: Tensor, idx1: Tensor, g2: Tensor, idx2: Tensor, w0: Tensor, b0: Tensor, w1: Tensor, b1: Tensor, w2: Tensor,
-                   b2: Tensor, ln_w: Tensor, ln_b: Optional[Tensor], eps: float, colptr: Optional[Tensor] = None):
+                   b2: Tensor, ln_w: Tensor, ln_b: Optional[Tensor], eps: float) -> Tensor:
     """GraphConv's edge MLP (three Linears, gather-add form) + LayerNorm + residual in ONE launch (anemoi_gnn_edge_chain_fwd):
-    ``e_new = LayerNorm(W2 gelu(W1 gelu(W0e e + g1[idx1] + g2[idx2] + b0) + b1) + b2) + e``.  ``w0, w1, w2``: fragment-major images
-    (``pack_weight_frag``) of [512, 512] weights; ``idx1 / idx2`` int32.  With ``colptr`` (int32 [n_dst + 1]; ``idx1`` must then be
-    the sorted destination of every edge) it also returns the scatter-sum ``agg[d] = sum of e_new over d's in-edges``:
-    ``(e_new, agg)``.  Inference only."""
-    _dev(e, g1, idx1, g2, idx2, w0, b0, w1, b1, w2, b2, ln_w, ln_b, colptr)
+    ``LayerNorm(W2 gelu(W1 gelu(W0e e + g1[idx1] + g2[idx2] + b0) + b1) + b2) + e``.  ``w0, w1, w2``: fragment-major images
+    (``pack_weight_frag``) of [512, 512] weights; ``idx1 / idx2`` int32.  Inference only."""
+    _dev(e, g1, idx1, g2, idx2, w0, b0, w1, b1, w2, b2, ln_w, ln_b)
     M, D = e.shape
     dt = e.dtype
     if D != CHAIN_CHANNELS or dt not in (torch.bfloat16, torch.float16):
@@ -837,27 +832,11 @@ def gnn_edge_chain(e: Tensor, g1: Tensor, idx1: Tensor, g2: Tensor, idx2: Tensor
     if g1.shape[1] != D or g2.shape[1] != D:
         raise ValueError("gnn_edge_chain: the gathered tables must have 512 columns")
     out = torch.empty((M, D), dtype=dt, device=e.device)
-    agg = ws = None
-    n_dst = 0
-    if colptr is not None:
-        if colptr.dtype != torch.int32 or colptr.dim() != 1 or not colptr.is_contiguous():
-            raise ValueError("gnn_edge_chain: colptr must be a contiguous int32 vector")
-        n_dst = colptr.shape[0] - 1
-        agg = torch.empty((n_dst, D), dtype=dt, device=e.device)
-        nws = int(_lib.load().anemoi_gnn_edge_chain_workspace_floats(M))
-        key = (str(e.device), nws)
-        ws = _EDGE_WS.get(key)  # scratch for the few destinations a panel boundary cuts: written and read inside this call (stream order)
-        if ws is None:
-            if len(_EDGE_WS) > 8:
-                _EDGE_WS.clear()
-            ws = _EDGE_WS[key] = torch.empty(max(nws, 1), dtype=torch.float32, device=e.device)
     (ep, lde), (p1, ld1), (p2, ld2) = _rows(e, "e", dt), _rows(g1, "g1", dt), _rows(g2, "g2", dt)
     _lib.check(_lib.load().anemoi_gnn_edge_chain_fwd(ep, lde, p1, ld1, idx1.data_ptr(), p2, ld2, idx2.data_ptr(), w0.data_ptr(), _vec(b0, "b0", D, dt),
                                                      w1.data_ptr(), _vec(b1, "b1", D, dt), w2.data_ptr(), _vec(b2, "b2", D, dt), _vec(ln_w, "ln_w", D, dt),
-                                                     _vec(ln_b, "ln_b", D, dt), float(eps), out.data_ptr(), D, 0 if colptr is None else colptr.data_ptr(),
-                                                     0 if agg is None else agg.data_ptr(), D, n_dst, 0 if ws is None else ws.data_ptr(), M, D, _dt(e),
-                                                     _stream()), "gnn_edge_chain_fwd")
-    return out if colptr is None else (out, agg)
+                                                     _vec(ln_b, "ln_b", D, dt), float(eps), out.data_ptr(), D, M, D, _dt(e), _stream()), "gnn_edge_chain_fwd")
+    return out
 
 
 def gnn_node_chain(x: Tensor, agg: Tensor, wa: Tensor, ba: Tensor, wb: Tensor, bb: Tensor, wc: Tensor, bc: Tensor, ln_w: Tensor,

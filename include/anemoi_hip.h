@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ANEMOI_HIP_ABI_VERSION 11
+#define ANEMOI_HIP_ABI_VERSION 10
 
 typedef enum { ANEMOI_F32 = 0, ANEMOI_BF16 = 1, ANEMOI_F16 = 2 } anemoi_dtype_t;
 typedef enum { ANEMOI_ACT_NONE = 0, ANEMOI_ACT_GELU = 1 } anemoi_act_t;
@@ -381,17 +381,12 @@ int anemoi_gt_chain_rows_per_tile(int32_t n_rows);
  * where g1 = x_dst W_i^T and g2 = x_src W_j^T are node-level rows gathered by the edge's destination / source, W_e = the edge
  * columns of the first Linear's weight.  ONE launch instead of three edge-level GEMMs + the LayerNorm / residual half of
  * anemoi_edge_ln_residual_segment_sum_fwd (whose arithmetic and rounding points it keeps: the GEMM outputs rounded to the model
- * dtype, one rounding of LayerNorm(z) + e).  w0 / w1 / w2 are fragment-major images (see anemoi_gt_chain_fwd) of [512, 512] weights.
- * With colptr != NULL (idx1 = the SORTED destination of every edge row, colptr [n_dst + 1] its CSC pointer) the scatter-sum
- * agg[d] = sum of the stored e_new rows of d's in-edges (fp32, rounded once: GraphConv's scatter(sum), conv.py:79-81) is produced as
- * well - inside the panels for the destinations whose edges lie in one panel, by a small second kernel for those a panel boundary
- * cuts (and the zero rows of destinations without edges); workspace = anemoi_gnn_edge_chain_workspace_floats(n_rows) floats.
- * colptr == NULL: no sum (anemoi_segment_sum_rows over e_new gives the same). */
-int64_t anemoi_gnn_edge_chain_workspace_floats(int32_t n_rows);
+ * dtype, one rounding of LayerNorm(z) + e); the scatter-sum over e_new is anemoi_segment_sum_rows.  w0 / w1 / w2 are fragment-major
+ * images (see anemoi_gt_chain_fwd) of [512, 512] weights. */
 int anemoi_gnn_edge_chain_fwd(const void* e, int64_t ld_e, const void* g1, int64_t ld_g1, const int32_t* idx1, const void* g2, int64_t ld_g2,
                               const int32_t* idx2, const void* w0, const void* b0, const void* w1, const void* b1, const void* w2, const void* b2,
-                              const void* ln_w, const void* ln_b, float eps, void* e_new, int64_t ld_o, const int32_t* colptr, void* agg,
-                              int64_t ld_agg, int32_t n_dst, float* workspace, int32_t n_rows, int32_t channels, anemoi_dtype_t dtype, void* stream);
+                              const void* ln_w, const void* ln_b, float eps, void* e_new, int64_t ld_o, int32_t n_rows, int32_t channels,
+                              anemoi_dtype_t dtype, void* stream);
 /* The node MLP of a GraphConv block (layers/block.py:392-394; MLP of three Linears + LayerNorm, layers/mlp.py:97-179) with its skip:
  *     x_out = LayerNorm(W_c gelu(W_b gelu(W_a [x | agg] + b_a) + b_b) + b_c; ln) + x
  * and optionally t_out = x_out W_t^T [+ b_t] - the NEXT block's stacked node-level terms [x W_i^T | x W_j^T] its edge chain gathers.
