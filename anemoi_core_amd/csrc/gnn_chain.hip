@@ -27,6 +27,7 @@ struct EdgeChainArgs {
   const void* ln_g; const void* ln_b; float ln_eps;
   void* e_new;     int64_t ld_o;
   int n_rows, rows_per_tile, n_tiles;
+  int dbg;  // experiment (timing only, results are garbage): bit 0 no GELU, bit 1 no LayerNorm arithmetic, bit 2 no gathers
 };
 
 // Edge panels are 64 rows (4 MFMA row bands): the same weight stream serves a third more rows than a 48-row panel would (81 840
@@ -123,8 +124,10 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
           unpack4<T>(gb[mi][ni], t2);
 #pragma unroll
           for (int r = 0; r < 4; ++r) t[r] = (acc[mi][ni][r] + bias[r]) + (t1[r] + t2[r]);  // the association of linear.hip's gather-add epilogue
-          gelu_fast2(t[0], t[1]);
-          gelu_fast2(t[2], t[3]);
+          if (!(a.dbg & 1)) {
+            gelu_fast2(t[0], t[1]);
+            gelu_fast2(t[2], t[3]);
+          }
           *reinterpret_cast<u32x2*>(bufH + (mi * 16 + lc.x) * kRowBytes + lc.coff[ni]) = pack4<T>(t);
         }
     }
@@ -143,8 +146,10 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
         unpack4<T>(pb[ni], bias);
 #pragma unroll
         for (int r = 0; r < 4; ++r) t[r] = acc[mi][ni][r] + bias[r];
-        gelu_fast2(t[0], t[1]);
-        gelu_fast2(t[2], t[3]);
+        if (!(a.dbg & 1)) {
+          gelu_fast2(t[0], t[1]);
+          gelu_fast2(t[2], t[3]);
+        }
         hp[mi][ni] = pack4<T>(t);
       }
     lds_barrier();
@@ -432,7 +437,9 @@ extern "C" int anemoi_gnn_edge_chain_fwd(const void* e, int64_t ld_e, const void
                      ld_g1 >= kCh && ld_g2 >= kCh,
                  "gnn_edge_chain_fwd: operand alignment / leading dimensions");
   EdgeChainArgs a{e, ld_e, g1, ld_g1, idx1, g2, ld_g2, idx2, (const char*)w0, b0, (const char*)w1, b1, (const char*)w2, b2, ln_w, ln_b, eps, e_new, ld_o,
-                  n_rows, chain_rows_per_tile(n_rows, kERows), 0};
+                  n_rows, chain_rows_per_tile(n_rows, kERows), 0, 0};
+  static const int dbg = env_int(getenv("ANEMOI_EDGE_CHAIN_DBG"), 0, 0, 7);
+  a.dbg = dbg;
   a.n_tiles = (n_rows + a.rows_per_tile - 1) / a.rows_per_tile;
   const int grid = a.n_tiles < 256 ? a.n_tiles : 256;
   hipStream_t st = as_stream(stream);
