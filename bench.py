@@ -485,10 +485,20 @@ def cpu_baseline(model_fp32_params, cfg, g, x, budget_s: float = 150.0):
         left = budget_s - (time.perf_counter() - t_start)
         reps = max(3, min(10, int(left / max(first, 1e-3))))
         runs = sorted(forward() for _ in range(reps))
+        # beside the fastest thread count: ALL physical cores (BASELINE.md section 3 words the CPU line that way) - one warm-up, two timed
+        all_cores = None
+        if ncore != cores and first * 3 <= 120:
+            torch.set_num_threads(ncore)
+            forward()
+            ac = sorted(forward() for _ in range(2))
+            all_cores = {"cores": ncore, "seconds_forward": round(ac[0], 3), "timed_forwards": 2}
+            torch.set_num_threads(cores)
     t_full = statistics.median(runs)
     B, T, E, N, V = x.shape
+    if all_cores is not None:
+        all_cores["value"] = N * cfg["num_channels"] / all_cores["seconds_forward"]
     return {"value": N * cfg["num_channels"] / t_full, "unit": "nodes*channels/s", "cores": cores, "physical_cores": ncore, "logical_cpus": ncpu,
-            "kind": "port",
+            "all_physical_cores": all_cores, "kind": "port",
             "sample": f"oracle fp32, FULL forward (encoder + {L} processor layers + decoder) on {cores} threads of {ncore} physical cores / {ncpu} "
                       f"logical CPUs (fastest thread count of a sweep over one processor layer): {warm} warm-up + {reps} timed forwards, "
                       f"median {t_full:.2f} s (min {runs[0]:.2f}, max {runs[-1]:.2f})",
