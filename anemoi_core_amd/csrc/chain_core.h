@@ -57,6 +57,7 @@ __device__ __forceinline__ u32x2 pack4(const float (&v)[4]) {
 // waited for together with them (a full L2 latency exposed at every epilogue)
 template <typename T>
 __device__ __forceinline__ void load_cols(const T* __restrict__ p, int wave, int g, u32x2 (&o)[4]) {
+  asm volatile("" : "+v"(g));  // (else the per-lane address is hoisted to the kernel's entry and spilled around the GEMM segments)
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni) o[ni] = *reinterpret_cast<const u32x2*>(p + wave * 64 + ni * 16 + g * 4);
 }
@@ -85,9 +86,12 @@ typedef const __attribute__((address_space(1))) frag8* gfrag_t;
 // segment or, in its last group, of the NEXT segment (`nxt`), so the stream never drains across the epilogues.
 // sched_barrier pins the issue order: left alone the scheduler sinks all 16 loads to the end of the loop body and the
 // waitcnt pass then drains the queue at the top (measured with tools/weight_stream_probe.hip).
-template <typename T, int NB = 3>
+struct NoHook {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+template <typename T, int NB = 3, typename Hook = NoHook>
 __device__ __forceinline__ void gemm_seg(const unsigned char* abuf, int lane, frag8 (&bq)[4][4], const char* cur, const char* nxt,
-                                         uint32_t loff, f32x4 (&acc)[NB][4]) {  // cur / nxt: wave-uniform (SGPR) bases, loff = lane * 16
+                                         uint32_t loff, f32x4 (&acc)[NB][4], Hook hook = Hook()) {  // cur / nxt: wave-uniform (SGPR) bases, loff = lane * 16
   asm volatile("" : "+v"(lane));
   const int x = lane & 15, ks = lane >> 4;
   const unsigned char* arow = abuf + x * kRowBytes;
@@ -99,6 +103,7 @@ __device__ __forceinline__ void gemm_seg(const unsigned char* abuf, int lane, fr
 #pragma unroll 1
   for (int q = 0; q < 4; ++q) {
     const char* pfg = q < 3 ? cur + (q + 1) * 16384 : nxt;
+    hook(q);  // side traffic of the caller, a quarter of it per group of 4 K-steps (the edge chain's next panel)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int st = q * 4 + j;

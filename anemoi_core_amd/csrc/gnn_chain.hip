@@ -56,18 +56,42 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
 
   int tile = blockIdx.x;
   if (tile >= a.n_tiles) return;
-  u32x4 va[kLd];
-  auto request_panel = [&](int t) {
+  // The e panel is only the first GEMM's operand (the LayerNorm's residual is re-read from global, L2-hot), so the NEXT panel
+  // moves into the free e buffer under the second GEMM - the phase with registers to spare (no gathered rows) - a quarter per
+  // group of 4 K-steps: requested at the top of a group, written to LDS at the top of the next (8 registers in flight; the whole
+  // panel at once is 32 and spills).  (The same with LDS-DMA - no registers at all - was built first: with a global_load_lds in
+  // flight hipcc's waitcnt pass puts vmcnt(0) in front of every MFMA that consumes a ds_read fragment, draining the weight ring
+  // at every K-step.)
+  constexpr int kPiece = kLd / 4;
+  u32x4 va[kPiece];
+  auto request_piece = [&](int t, int pc) {
     const int r0 = t * a.rows_per_tile;
     const int nr = min(a.rows_per_tile, a.n_rows - r0);
+    int td = tid;
+    asm volatile("" : "+v"(td));
 #pragma unroll
-    for (int i = 0; i < kLd; ++i) {
-      const int idx = tid + 512 * i;
+    for (int i = 0; i < kPiece; ++i) {
+      const int idx = td + 512 * (pc * kPiece + i);
       const int rr = min(idx >> 6, nr - 1), slot = idx & 63;
       va[i] = *reinterpret_cast<const u32x4*>((const T*)a.e + (int64_t)(r0 + rr) * a.ld_e + slot * 8);
     }
   };
-  request_panel(tile);
+  auto write_piece = [&](int t, int pc) {
+    const int nr = min(a.rows_per_tile, a.n_rows - t * a.rows_per_tile);
+    int td = tid;
+    asm volatile("" : "+v"(td));
+#pragma unroll
+    for (int i = 0; i < kPiece; ++i) {
+      const int idx = td + 512 * (pc * kPiece + i);
+      const int row = idx >> 6, slot = idx & 63;
+      *reinterpret_cast<u32x4*>(bufE + row * kRowBytes + ((slot ^ (row & 15)) << 4)) = row < nr ? va[i] : zero4;
+    }
+  };
+#pragma unroll 1
+  for (int pc = 0; pc < 4; ++pc) {  // the first panel: nothing to hide behind
+    request_piece(tile, pc);
+    write_piece(tile, pc);
+  }
   __builtin_amdgcn_sched_barrier(0);
   frag8 bq[4][4];
 #pragma unroll
@@ -77,17 +101,13 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
       bq[j][ni] = *reinterpret_cast<gfrag_t>(uniform_ptr(w0 + j * 4096) + loff + ni * 1024);
       __builtin_amdgcn_sched_barrier(0);
     }
+  lds_barrier();
 
   for (;;) {
     const int r0 = tile * a.rows_per_tile;
     const int nr = min(a.rows_per_tile, a.n_rows - r0);
-#pragma unroll
-    for (int i = 0; i < kLd; ++i) {
-      const int idx = tid + 512 * i;
-      const int row = idx >> 6, slot = idx & 63;
-      *reinterpret_cast<u32x4*>(bufE + row * kRowBytes + ((slot ^ (row & 15)) << 4)) = row < nr ? va[i] : zero4;
-    }
-    lds_barrier();
+    const int next_tile = tile + (int)gridDim.x;
+    const bool more = next_tile < a.n_tiles;
     // the gathered node-level rows of this lane's panel rows (index, then 2 x 4 x 8 bytes per row) and the first bias: in flight
     // under the first GEMM
     u32x2 ga[NB][4], gb[NB][4], pb[4];
@@ -136,7 +156,16 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
     lds_barrier();
     // ---- h2 = gelu(h1 W_1^T + b1), written over h1 once every wave has read its last fragment of it
     zero_acc<T, NB>(acc);
-    gemm_seg<T, NB>(bufH, lane, bq, w1, w2, loff, acc);
+    if (more) {  // (every wave is behind its last fragment read of the e panel: the E1 barrier)
+      auto hook = [&](int q) {
+        if (q > 0) write_piece(next_tile, q - 1);
+        request_piece(next_tile, q);
+      };
+      gemm_seg<T, NB>(bufH, lane, bq, w1, w2, loff, acc, hook);
+      write_piece(next_tile, 3);  // (published by the barrier at the end of this panel)
+    } else {
+      gemm_seg<T, NB>(bufH, lane, bq, w1, w2, loff, acc);
+    }
     u32x2 hp[NB][4];
 #pragma unroll
     for (int mi = 0; mi < NB; ++mi)
@@ -174,10 +203,16 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
     // ---- z = h2 W_2^T + b2 (rounded, as the Linear's output is); e' = LayerNorm(z) + e -> global
     zero_acc<T, NB>(acc);
     gemm_seg<T, NB>(bufH, lane, bq, w2, w0, loff, acc);  // (behind it: the next panel's first segment; after the last panel a harmless re-read)
-    const int next_tile = tile + (int)gridDim.x;
-    const bool more = next_tile < a.n_tiles;
     {
       const LaneCtx lc = lane_ctx(lane, wave);
+      u32x2 er[NB][4];  // this lane's values of the e rows (the residual): in flight under the bias add and the row statistics
+#pragma unroll
+      for (int mi = 0; mi < NB; ++mi) {
+        const T* erow = (const T*)a.e + (int64_t)(r0 + min(mi * 16 + lc.x, nr - 1)) * a.ld_e + wave * 64 + lc.g * 4;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) er[mi][ni] = *reinterpret_cast<const u32x2*>(erow + ni * 16);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int mi = 0; mi < NB; ++mi)
 #pragma unroll
@@ -200,7 +235,7 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
           float gv[4], bv[4], ev[4], o[4];
           unpack4<T>(pg[ni], gv);
           unpack4<T>(pt[ni], bv);
-          unpack4<T>(*reinterpret_cast<const u32x2*>(bufE + (mi * 16 + lc.x) * kRowBytes + lc.coff[ni]), ev);
+          unpack4<T>(er[mi][ni], ev);
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[r] = fmaf((acc[mi][ni][r] - mean[mi]) * rstd[mi], gv[r], bv[r]) + ev[r];  // edge_ln_res_segsum's arithmetic
           pk[mi][ni] = pack4<T>(o);
@@ -209,9 +244,7 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
     }
     if (!more) break;
     tile = next_tile;
-    request_panel(tile);  // (requested only here: 32 more live registers across the LayerNorm epilogue spill)
-    __builtin_amdgcn_sched_barrier(0);
-    lds_barrier();  // every wave has read its residual values from bufE and emptied its strip
+    lds_barrier();  // every wave has emptied its strip (bufH is the next panel's h1) and written its part of the next e panel
   }
 }
 
