@@ -9,7 +9,7 @@ import ctypes as C
 import os
 import threading
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libanemoi_hip.so")
 
 F32, BF16, F16 = 0, 1, 2
@@ -25,6 +25,11 @@ SIGNATURES = {
     "anemoi_gt_attention_fwd": ([_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _i64, _p, _i64, _p, _i32, _i32, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_gt_attention_bwd": ([_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p,
                                  _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i32, _i32, _i32, _i32, _i32, C.c_int, _p], C.c_int),
+    "anemoi_gt_attention_dropout_fwd": ([_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _i64, _p, _i64, _p, _i32, _i32, _i32, _i32, _f, C.c_uint64,
+                                         C.c_int, _p], C.c_int),
+    "anemoi_gt_attention_dropout_bwd": ([_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p,
+                                         _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i32, _i32, _i32, _i32, _i32, _f, C.c_uint64, C.c_int, _p], C.c_int),
+    "anemoi_attention_dropout_mask": ([_p, _i32, _i32, _f, C.c_uint64, _p], C.c_int),
     "anemoi_gt_attention_fused_edge_fwd": ([_p, _i64, _p, _i64, _p, _i64, _p, _i32, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _i32, _i32, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_pack_edge_weights": ([_p, _p, _p, _i32, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_pack_edge_features": ([_p, _i64, _p, _i32, _i32, _i32, C.c_int, _p], C.c_int),
@@ -69,6 +74,7 @@ SIGNATURES = {
     "anemoi_gt_chain_fwd": ([_p, C.c_int, _p], C.c_int),
     "anemoi_gt_chain_rows_per_tile": ([_i32], C.c_int),
     "anemoi_gnn_edge_chain_fwd": ([_p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _i64, _i32, _i32, C.c_int, _p], C.c_int),
+    "anemoi_gnn_mlp_chain_fwd": ([_p, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _i64, _p, _i64, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_gnn_node_chain_fwd": ([_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _i64, _p, _p, _i32, _p, _i64, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_peer_exchange_rows": ([_p, _i64, _p, _p, _i32, _i32, _i32, _p, _p, _i64, _p], C.c_int),
 }

@@ -222,6 +222,32 @@ def attention(q: Tensor, k: Tensor, v: Tensor, e: Tensor, csc: "ops.CSC", num_he
     return out.reshape(-1, H * C)
 
 
+class AttentionConvFunction(torch.autograd.Function):
+    """``GraphTransformerConv`` as one differentiable op (reference layers/conv.py:103-147): attention with a materialised edge
+    tensor and, in training mode, dropout on the softmax weights.  The dropout mask is never stored: forward and backward derive
+    it from the same (p, seed) (csrc/common.h: attn_dropout_scale)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, e, csc, num_heads, reverse, dropout_p, dropout_seed):
+        out, lse = ops.gt_attention(q, k, v, e, csc, num_heads, return_lse=True, dropout_p=dropout_p, dropout_seed=dropout_seed)
+        ctx.csc, ctx.H, ctx.reverse, ctx.drop = csc, num_heads, reverse, (dropout_p, dropout_seed)
+        ctx.save_for_backward(q, k, v, e, out, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        q, k, v, e, out, lse = ctx.saved_tensors
+        reverse = ctx.reverse if ctx.reverse is not None else ops.build_reverse_csr(ctx.csc)
+        dq, dk, dv, de = ops.gt_attention_backward(d_out.contiguous(), q, k, v, e, out, lse, ctx.csc, reverse, ctx.H,
+                                                   dropout_p=ctx.drop[0], dropout_seed=ctx.drop[1])
+        return dq, dk, dv, de, None, None, None, None, None
+
+
+def attention_conv(q: Tensor, k: Tensor, v: Tensor, e: Tensor, csc: "ops.CSC", num_heads: int, reverse=None, dropout_p: float = 0.0,
+                   dropout_seed: int = 0) -> Tensor:
+    return AttentionConvFunction.apply(q, k, v, e, csc, num_heads, reverse, dropout_p, dropout_seed)
+
+
 class FusedAttentionFunction(torch.autograd.Function):
     """out = attention(q, k, v, e) + self_term, with q / k / v / self_term given as COLUMN SLABS of the fused projection buffers
     they were computed into (processor: one [N, 4A] buffer; mapper: [N_dst, 2A] and [N_src, 2A]).  The backward kernels write

@@ -91,7 +91,8 @@ struct NoHook {
 };
 template <typename T, int NB = 3, typename Hook = NoHook>
 __device__ __forceinline__ void gemm_seg(const unsigned char* abuf, int lane, frag8 (&bq)[4][4], const char* cur, const char* nxt,
-                                         uint32_t loff, f32x4 (&acc)[NB][4], Hook hook = Hook()) {  // cur / nxt: wave-uniform (SGPR) bases, loff = lane * 16
+                                         uint32_t loff, f32x4 (&acc)[NB][4], Hook hook = Hook(), int nq = 4) {  // cur / nxt: wave-uniform (SGPR) bases, loff = lane * 16
+  // nq: groups of 4 K-steps (K = 128 nq; 4 = the 512-wide segment every caller but the MLP chain's first GEMM uses)
   asm volatile("" : "+v"(lane));
   const int x = lane & 15, ks = lane >> 4;
   const unsigned char* arow = abuf + x * kRowBytes;
@@ -100,14 +101,15 @@ __device__ __forceinline__ void gemm_seg(const unsigned char* abuf, int lane, fr
   frag8 fa[NB];
 #pragma unroll
   for (int mi = 0; mi < NB; ++mi) fa[mi] = *reinterpret_cast<const frag8*>(arow + mi * 16 * kRowBytes + ((ks ^ x) << 4));
+  const int last = nq * 4 - 1;
 #pragma unroll 1
-  for (int q = 0; q < 4; ++q) {
-    const char* pfg = q < 3 ? cur + (q + 1) * 16384 : nxt;
+  for (int q = 0; q < nq; ++q) {
+    const char* pfg = q < nq - 1 ? cur + (q + 1) * 16384 : nxt;
     hook(q);  // side traffic of the caller, a quarter of it per group of 4 K-steps (the edge chain's next panel)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int st = q * 4 + j;
-      const int sn = st < 15 ? st + 1 : 15;  // (the last step re-reads its own fragments: no branch in the stream)
+      const int sn = st < last ? st + 1 : last;  // (the last step re-reads its own fragments: no branch in the stream)
       frag8 fn[NB];
 #pragma unroll
       for (int mi = 0; mi < NB; ++mi) fn[mi] = *reinterpret_cast<const frag8*>(arow + mi * 16 * kRowBytes + (((sn * 4 + ks) ^ x) << 4));

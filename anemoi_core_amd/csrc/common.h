@@ -98,6 +98,19 @@ __device__ __forceinline__ float group_sum(float x) {
 
 __device__ __forceinline__ float wave_sum(float x) { return group_sum<64>(x); }
 
+// Attention dropout (reference layers/conv.py:145: dropout on the softmax weights, training mode).  The keep / drop decision of
+// (CSC edge, head) is a pure function of (seed, edge, head) - a counter-based generator (splitmix64 finaliser of seed + counter,
+// top 24 bits as a uniform in [0, 1)) - so the backward pass REPLAYS the forward's mask instead of storing it.
+// Returns 1 / (1 - p) for a kept weight, 0 for a dropped one.
+__host__ __device__ __forceinline__ float attn_dropout_scale(uint64_t seed, int edge, int head, float p, float inv_keep) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * ((((uint64_t)(uint32_t)edge) << 16 | (uint64_t)(uint32_t)head) + 1ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  const float u = (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);
+  return u >= p ? inv_keep : 0.f;
+}
+
 // erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, below fp32 resolution of the surrounding arithmetic):
 // one v_rcp, one v_exp and five FMAs instead of libm's branchy erff in the GEMM epilogue.
 __device__ __forceinline__ float fast_erf(float x) {

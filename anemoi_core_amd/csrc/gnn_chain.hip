@@ -28,6 +28,9 @@ struct EdgeChainArgs {
   void* e_new;     int64_t ld_o;
   int n_rows, rows_per_tile, n_tiles;
   int dbg;  // experiment (timing only, results are garbage): bit 0 no GELU, bit 1 no LayerNorm arithmetic, bit 2 no gathers
+  // the MLP instantiation (no gathered rows): y = LayerNorm(W_2 gelu(W_1 gelu(W_0 x + b_0) + b_1) + b_2) [+ res]
+  const void* res = nullptr; int64_t ld_res = 0;  // optional residual rows (the edge chain's residual is e itself)
+  int k0_groups = 4;                              // width of x / K of the first GEMM in units of 128 columns (w0: fragment-major [512, 128 k0_groups])
 };
 
 // Edge panels are 64 rows (4 MFMA row bands): the same weight stream serves a third more rows than a 48-row panel would (81 840
@@ -38,7 +41,10 @@ constexpr int kENB = 4, kERows = 16 * kENB, kEBuf = kERows * kRowBytes;
 constexpr int kERedOff = 2 * kEBuf;
 constexpr int kEdgeSmem = kERedOff + kERows * 8 * 2 * 4;
 
-template <typename T>
+// MLP = true: the same chain without the gathered rows, the residual optional and the first GEMM's K a multiple of 128 up to 512 -
+// the embedding MLPs of the GNN mappers / processor (reference layers/mlp.py:29-100 as built at layers/mapper.py:640-700:
+// Linear -> GELU -> Linear -> GELU -> Linear -> LayerNorm over [rows, in] -> 512).
+template <typename T, bool MLP = false>
 __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const bufE = smem;          // e panel: operand of GEMM 1, residual of the LayerNorm
@@ -49,7 +55,9 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4;
   const uint32_t loff = lane * 16;
-  const char* const w0 = a.w0 + (int64_t)wave * kSlab;
+  const int nq0 = MLP ? a.k0_groups : 4;  // K of the first GEMM / 128
+  const int nslots = nq0 * 16;            // 16-byte slots per panel row
+  const char* const w0 = a.w0 + (int64_t)wave * (nq0 * 16384);
   const char* const w1 = a.w1 + (int64_t)wave * kSlab;
   const char* const w2 = a.w2 + (int64_t)wave * kSlab;
   const u32x4 zero4 = u32x4{0u, 0u, 0u, 0u};
@@ -73,7 +81,7 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
     for (int i = 0; i < kPiece; ++i) {
       const int idx = td + 512 * (pc * kPiece + i);
       const int rr = min(idx >> 6, nr - 1), slot = idx & 63;
-      va[i] = *reinterpret_cast<const u32x4*>((const T*)a.e + (int64_t)(r0 + rr) * a.ld_e + slot * 8);
+      if (!MLP || slot < nslots) va[i] = *reinterpret_cast<const u32x4*>((const T*)a.e + (int64_t)(r0 + rr) * a.ld_e + slot * 8);
     }
   };
   auto write_piece = [&](int t, int pc) {
@@ -84,7 +92,8 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
     for (int i = 0; i < kPiece; ++i) {
       const int idx = td + 512 * (pc * kPiece + i);
       const int row = idx >> 6, slot = idx & 63;
-      *reinterpret_cast<u32x4*>(bufE + row * kRowBytes + ((slot ^ (row & 15)) << 4)) = row < nr ? va[i] : zero4;
+      if (!MLP || slot < nslots)  // (the swizzle permutes the 16 slots of a 128-column group among themselves)
+        *reinterpret_cast<u32x4*>(bufE + row * kRowBytes + ((slot ^ (row & 15)) << 4)) = row < nr ? va[i] : zero4;
     }
   };
 #pragma unroll 1
@@ -110,8 +119,8 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
     const bool more = next_tile < a.n_tiles;
     // the gathered node-level rows of this lane's panel rows (index, then 2 x 4 x 8 bytes per row) and the first bias: in flight
     // under the first GEMM
-    u32x2 ga[NB][4], gb[NB][4], pb[4];
-    {
+    u32x2 ga[MLP ? 1 : NB][4], gb[MLP ? 1 : NB][4], pb[4];
+    if constexpr (!MLP) {
       const LaneCtx lc = lane_ctx(lane, wave);
 #pragma unroll
       for (int mi = 0; mi < NB; ++mi) {
@@ -131,7 +140,7 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
     f32x4 acc[NB][4];
     // ---- h1 = gelu(e W_e^T + g1[dst] + g2[src] + b0) -> bufH
     zero_acc<T, NB>(acc);
-    gemm_seg<T, NB>(bufE, lane, bq, w0, w1, loff, acc);
+    gemm_seg<T, NB>(bufE, lane, bq, w0, w1, loff, acc, NoHook(), nq0);
     {
       const LaneCtx lc = lane_ctx(lane, wave);
 #pragma unroll
@@ -140,10 +149,15 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
         for (int ni = 0; ni < 4; ++ni) {
           float bias[4], t1[4], t2[4], t[4];
           unpack4<T>(pb[ni], bias);
-          unpack4<T>(ga[mi][ni], t1);
-          unpack4<T>(gb[mi][ni], t2);
+          if constexpr (MLP) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) t[r] = (acc[mi][ni][r] + bias[r]) + (t1[r] + t2[r]);  // the association of linear.hip's gather-add epilogue
+            for (int r = 0; r < 4; ++r) t[r] = acc[mi][ni][r] + bias[r];
+          } else {
+            unpack4<T>(ga[mi][ni], t1);
+            unpack4<T>(gb[mi][ni], t2);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[r] = (acc[mi][ni][r] + bias[r]) + (t1[r] + t2[r]);  // the association of linear.hip's gather-add epilogue
+          }
           if (!(a.dbg & 1)) {
             gelu_fast2(t[0], t[1]);
             gelu_fast2(t[2], t[3]);
@@ -206,11 +220,20 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
     {
       const LaneCtx lc = lane_ctx(lane, wave);
       u32x2 er[NB][4];  // this lane's values of the e rows (the residual): in flight under the bias add and the row statistics
+      const T* const resp = MLP ? (const T*)a.res : (const T*)a.e;
+      const int64_t ld_res = MLP ? a.ld_res : a.ld_e;
+      if (!MLP || resp != nullptr) {
 #pragma unroll
-      for (int mi = 0; mi < NB; ++mi) {
-        const T* erow = (const T*)a.e + (int64_t)(r0 + min(mi * 16 + lc.x, nr - 1)) * a.ld_e + wave * 64 + lc.g * 4;
+        for (int mi = 0; mi < NB; ++mi) {
+          const T* erow = resp + (int64_t)(r0 + min(mi * 16 + lc.x, nr - 1)) * ld_res + wave * 64 + lc.g * 4;
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) er[mi][ni] = *reinterpret_cast<const u32x2*>(erow + ni * 16);
+          for (int ni = 0; ni < 4; ++ni) er[mi][ni] = *reinterpret_cast<const u32x2*>(erow + ni * 16);
+        }
+      } else {
+#pragma unroll
+        for (int mi = 0; mi < NB; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) er[mi][ni] = u32x2{0u, 0u};
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -486,6 +509,37 @@ extern "C" int anemoi_gnn_edge_chain_fwd(const void* e, int64_t ld_e, const void
     hipLaunchKernelGGL((gnn_edge_chain_kernel<f16_t>), dim3(grid), dim3(512), kEdgeSmem, st, a);
   }
   return check_launch("gnn_edge_chain_kernel");
+}
+
+extern "C" int anemoi_gnn_mlp_chain_fwd(const void* x, int64_t ld_x, int32_t in_features, const void* w0, const void* b0, const void* w1, const void* b1,
+                                        const void* w2, const void* b2, const void* ln_w, const void* ln_b, float eps, const void* res, int64_t ld_res,
+                                        void* out, int64_t ld_o, int32_t n_rows, int32_t channels, anemoi_dtype_t dtype, void* stream) {
+  ANEMOI_REQUIRE(dtype == ANEMOI_BF16 || dtype == ANEMOI_F16, "gnn_mlp_chain_fwd: 16-bit model dtypes only");
+  ANEMOI_REQUIRE(n_rows >= 0 && channels == kCh, "gnn_mlp_chain_fwd: channels=%d (this kernel is built for %d)", channels, kCh);
+  ANEMOI_REQUIRE(in_features >= 128 && in_features <= kCh && in_features % 128 == 0, "gnn_mlp_chain_fwd: in_features=%d (zero-padded width: 128, 256, 384 or 512)", in_features);
+  if (n_rows == 0) return ANEMOI_OK;
+  ANEMOI_REQUIRE(x && w0 && b0 && w1 && b1 && w2 && b2 && ln_w && out, "gnn_mlp_chain_fwd: null operand");
+  ANEMOI_REQUIRE(al(x, 16) && al(out, 16) && al(w0, 16) && al(w1, 16) && al(w2, 16) && al(res, 8) && al(b0, 8) && al(b1, 8) && al(b2, 8) && al(ln_w, 8) &&
+                     al(ln_b, 8) && ld_x % 8 == 0 && ld_o % 8 == 0 && ld_x >= in_features && ld_o >= kCh && (!res || (ld_res % 4 == 0 && ld_res >= kCh)),
+                 "gnn_mlp_chain_fwd: operand alignment / leading dimensions");
+  EdgeChainArgs a{x, ld_x, nullptr, 0, nullptr, nullptr, 0, nullptr, (const char*)w0, b0, (const char*)w1, b1, (const char*)w2, b2, ln_w, ln_b, eps, out, ld_o,
+                  n_rows, chain_rows_per_tile(n_rows, kERows), 0, 0};
+  a.res = res;
+  a.ld_res = ld_res;
+  a.k0_groups = in_features / 128;
+  a.n_tiles = (n_rows + a.rows_per_tile - 1) / a.rows_per_tile;
+  const int grid = a.n_tiles < 256 ? a.n_tiles : 256;
+  hipStream_t st = as_stream(stream);
+  if (dtype == ANEMOI_BF16) {
+    static PerDeviceOnce once;
+    once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gnn_edge_chain_kernel<bf16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kEdgeSmem); });
+    hipLaunchKernelGGL((gnn_edge_chain_kernel<bf16_t, true>), dim3(grid), dim3(512), kEdgeSmem, st, a);
+  } else {
+    static PerDeviceOnce once;
+    once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gnn_edge_chain_kernel<f16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kEdgeSmem); });
+    hipLaunchKernelGGL((gnn_edge_chain_kernel<f16_t, true>), dim3(grid), dim3(512), kEdgeSmem, st, a);
+  }
+  return check_launch("gnn_mlp_chain_kernel");
 }
 
 extern "C" int anemoi_gnn_node_chain_fwd(const void* x, int64_t ld_x, const void* agg, int64_t ld_a, const void* wa, const void* ba, const void* wb,

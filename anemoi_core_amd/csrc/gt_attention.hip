@@ -39,13 +39,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void gt_attn_fwd_kernel(
     const T* __restrict__ q, int64_t ldq, const T* __restrict__ k, int64_t ldk, const T* __restrict__ v, int64_t ldv,
     const T* __restrict__ e, int64_t lde, const int32_t* __restrict__ row, const int32_t* __restrict__ colptr,
     const T* __restrict__ addend, int64_t ldadd, T* __restrict__ out, int64_t ldo, float* __restrict__ lse, int n_dst,
-    int H, float scale) {
+    int H, float scale, float drop_p, uint64_t drop_seed) {
   const int lane = threadIdx.x & 63;
   const int d = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
   if (d >= n_dst) return;
   const int beg = __builtin_amdgcn_readfirstlane(colptr[d]);
   const int end = __builtin_amdgcn_readfirstlane(colptr[d + 1]);
   const int c0 = lane * VEC;
+  const float inv_keep = 1.0f / (1.0f - drop_p);
 
   float qv[VEC], acc[VEC];
   load_vec<T, VEC>(q + (int64_t)d * ldq + c0, qv);
@@ -81,8 +82,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void gt_attn_fwd_kernel(
     const float corr = __expf(m - m_new);  // first edge: exp(-inf) = 0
     const float p = __expf(dot - m_new);
     l = fmaf(l, corr, p);
+    // dropout acts on the NORMALISED weight: the denominator sums every edge, the numerator the kept ones (scaled by 1 / (1 - p))
+    const float pv = drop_p > 0.f ? p * attn_dropout_scale(drop_seed, ei, lane / LPH, drop_p, inv_keep) : p;
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) acc[j] = fmaf(acc[j], corr, p * cur.v[j]);
+    for (int j = 0; j < VEC; ++j) acc[j] = fmaf(acc[j], corr, pv * cur.v[j]);
     m = m_new;
   }
 
@@ -382,11 +385,13 @@ __global__ void gt_attn_fwd_generic_kernel(const T* __restrict__ q, int64_t ldq,
                                            const float* __restrict__ w_packed,
                                            const int32_t* __restrict__ row, const int32_t* __restrict__ colptr,
                                            const T* __restrict__ addend, int64_t ldadd, T* __restrict__ out,
-                                           int64_t ldo, float* __restrict__ lse, int n_dst, int H, int C, float scale) {
+                                           int64_t ldo, float* __restrict__ lse, int n_dst, int H, int C, float scale,
+                                           float drop_p, uint64_t drop_seed) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (int64_t)n_dst * H) return;
   const int d = (int)(t / H), h = (int)(t % H);
   const int beg = colptr[d], end = colptr[d + 1];
+  const float inv_keep = 1.0f / (1.0f - drop_p);
   float acc[kGenericMaxC];  // private (scratch-memory) fp32 accumulator
   for (int c = 0; c < C; ++c) acc[c] = 0.f;
   float m = -INFINITY, l = 0.f;
@@ -408,6 +413,7 @@ __global__ void gt_attn_fwd_generic_kernel(const T* __restrict__ q, int64_t ldq,
     const float m_new = fmaxf(m, dot);
     const float corr = expf(m - m_new), p = expf(dot - m_new);
     l = l * corr + p;
+    const float pv = drop_p > 0.f ? p * attn_dropout_scale(drop_seed, ei, h, drop_p, inv_keep) : p;
     for (int c = 0; c < C; ++c) {
       float ee = 0.f;
       if (e != nullptr) ee = to_float(e[(int64_t)ei * lde + h * C + c]);
@@ -415,7 +421,7 @@ __global__ void gt_attn_fwd_generic_kernel(const T* __restrict__ q, int64_t ldq,
         ee = 0.f;  // the bias rides on the constant-1 feature column fe
         for (int f = 0; f < fe_pad; ++f) ee = fmaf(feat[(int64_t)ei * fe_pad + f], w_packed[(int64_t)(h * C + c) * fe_pad + f], ee);
       }
-      acc[c] = acc[c] * corr + p * (to_float(vp[c]) + ee);
+      acc[c] = acc[c] * corr + pv * (to_float(vp[c]) + ee);
     }
     m = m_new;
   }
@@ -463,6 +469,8 @@ struct AttnArgs {
   float* lse;
   int n_dst, n_src, H, C;
   hipStream_t stream;
+  float drop_p = 0.f;      // attention dropout (materialised-E op only): probability and the seed of the replayable mask
+  uint64_t drop_seed = 0;
 };
 
 static bool pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
@@ -476,11 +484,11 @@ static int launch_fast(const AttnArgs& a) {
     if (a.e != nullptr)
       hipLaunchKernelGGL((gt_attn_fwd_kernel<T, VEC, LPH, true>), grid, block, 0, a.stream, (const T*)a.q, a.ldq,
                          (const T*)a.k, a.ldk, (const T*)a.v, a.ldv, (const T*)a.e, a.lde, a.row, a.colptr,
-                         (const T*)a.addend, a.ldadd, (T*)a.out, a.ldo, a.lse, a.n_dst, a.H, scale);
+                         (const T*)a.addend, a.ldadd, (T*)a.out, a.ldo, a.lse, a.n_dst, a.H, scale, a.drop_p, a.drop_seed);
     else
       hipLaunchKernelGGL((gt_attn_fwd_kernel<T, VEC, LPH, false>), grid, block, 0, a.stream, (const T*)a.q, a.ldq,
                          (const T*)a.k, a.ldk, (const T*)a.v, a.ldv, (const T*)nullptr, (int64_t)0, a.row, a.colptr,
-                         (const T*)a.addend, a.ldadd, (T*)a.out, a.ldo, a.lse, a.n_dst, a.H, scale);
+                         (const T*)a.addend, a.ldadd, (T*)a.out, a.ldo, a.lse, a.n_dst, a.H, scale, a.drop_p, a.drop_seed);
     return check_launch("gt_attn_fwd_kernel");
   }
   // Fused lin_edge: each wave walks `dst_per_wave` consecutive destinations so the W' staging is amortised,
@@ -567,7 +575,7 @@ static int launch(const AttnArgs& a) {
   hipLaunchKernelGGL((gt_attn_fwd_generic_kernel<T>), dim3((unsigned)((threads + 127) / 128)), dim3(128), 0, a.stream,
                      (const T*)a.q, a.ldq, (const T*)a.k, a.ldk, (const T*)a.v, a.ldv, (const T*)a.e, a.lde, a.feat, a.fe,
                      a.fe_pad, a.w_packed, a.row, a.colptr, (const T*)a.addend, a.ldadd,
-                     (T*)a.out, a.ldo, a.lse, a.n_dst, a.H, a.C, scale);
+                     (T*)a.out, a.ldo, a.lse, a.n_dst, a.H, a.C, scale, a.drop_p, a.drop_seed);
   return check_launch("gt_attn_fwd_generic_kernel");
 }
 
@@ -584,19 +592,47 @@ static int dispatch(const AttnArgs& a, anemoi_dtype_t dtype) {
 
 using namespace anemoi;
 
+extern "C" int anemoi_gt_attention_dropout_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                                       const void* e, int64_t lde, const int32_t* row, const int32_t* colptr,
+                                       const void* addend, int64_t ldadd, void* out, int64_t ldo, float* lse,
+                                       int32_t n_dst, int32_t n_src, int32_t H, int32_t C, float drop_p, uint64_t drop_seed,
+                                       anemoi_dtype_t dtype, void* stream) {
+  ANEMOI_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "gt_attention_dropout_fwd: dropout probability %g outside [0, 1)", (double)drop_p);
+  ANEMOI_REQUIRE(H < 65536, "gt_attention_dropout_fwd: the mask's counter holds 16 bits of head index, got H=%d", H);
+  ANEMOI_REQUIRE(n_dst >= 0 && n_src >= 0 && H > 0 && C > 0, "gt_attention_dropout_fwd: bad sizes n_dst=%d n_src=%d H=%d C=%d", n_dst, n_src, H, C);
+  if (n_dst == 0) return ANEMOI_OK;
+  ANEMOI_REQUIRE(q && k && v && out && colptr, "gt_attention_dropout_fwd: null q/k/v/out/colptr");
+  const int D = H * C;
+  ANEMOI_REQUIRE(ldq >= D && ldk >= D && ldv >= D && ldo >= D && (!e || lde >= D) && (!addend || ldadd >= D),
+                 "gt_attention_dropout_fwd: leading dimension smaller than H*C=%d", D);
+  AttnArgs a{q, k, v, e, ldq, ldk, ldv, lde, nullptr, 0, 0, nullptr, row, colptr, nullptr, addend, ldadd, out, ldo, lse, n_dst, n_src, H, C, as_stream(stream)};
+  a.drop_p = drop_p;
+  a.drop_seed = drop_seed;
+  return dispatch(a, dtype);
+}
+
 extern "C" int anemoi_gt_attention_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                                        const void* e, int64_t lde, const int32_t* row, const int32_t* colptr,
                                        const void* addend, int64_t ldadd, void* out, int64_t ldo, float* lse,
                                        int32_t n_dst, int32_t n_src, int32_t H, int32_t C, anemoi_dtype_t dtype,
                                        void* stream) {
-  ANEMOI_REQUIRE(n_dst >= 0 && n_src >= 0 && H > 0 && C > 0, "gt_attention_fwd: bad sizes n_dst=%d n_src=%d H=%d C=%d", n_dst, n_src, H, C);
-  if (n_dst == 0) return ANEMOI_OK;
-  ANEMOI_REQUIRE(q && k && v && out && colptr, "gt_attention_fwd: null q/k/v/out/colptr");
-  const int D = H * C;
-  ANEMOI_REQUIRE(ldq >= D && ldk >= D && ldv >= D && ldo >= D && (!e || lde >= D) && (!addend || ldadd >= D),
-                 "gt_attention_fwd: leading dimension smaller than H*C=%d", D);
-  AttnArgs a{q, k, v, e, ldq, ldk, ldv, lde, nullptr, 0, 0, nullptr, row, colptr, nullptr, addend, ldadd, out, ldo, lse, n_dst, n_src, H, C, as_stream(stream)};
-  return dispatch(a, dtype);
+  return anemoi_gt_attention_dropout_fwd(q, ldq, k, ldk, v, ldv, e, lde, row, colptr, addend, ldadd, out, ldo, lse, n_dst, n_src, H, C, 0.f, 0,
+                                         dtype, stream);
+}
+
+// keep-scale of every (edge, head) as the kernels derive it: what a caller (or a test) needs to restate the op with an explicit mask
+__global__ void attn_dropout_mask_kernel(float* __restrict__ out, int64_t n, int H, float p, uint64_t seed) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = attn_dropout_scale(seed, (int)(i / H), (int)(i % H), p, 1.0f / (1.0f - p));
+}
+
+extern "C" int anemoi_attention_dropout_mask(float* out, int32_t n_edges, int32_t H, float drop_p, uint64_t drop_seed, void* stream) {
+  ANEMOI_REQUIRE(n_edges >= 0 && H > 0 && H < 65536 && drop_p >= 0.f && drop_p < 1.f, "attention_dropout_mask: bad arguments M=%d H=%d p=%g", n_edges, H, (double)drop_p);
+  const int64_t n = (int64_t)n_edges * H;
+  if (n == 0) return ANEMOI_OK;
+  ANEMOI_REQUIRE(out, "attention_dropout_mask: null output");
+  hipLaunchKernelGGL(attn_dropout_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), out, n, H, drop_p, drop_seed);
+  return check_launch("attn_dropout_mask_kernel");
 }
 
 extern "C" int anemoi_gt_attention_fused_edge_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v,

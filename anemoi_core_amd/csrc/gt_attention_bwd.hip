@@ -34,6 +34,8 @@ struct BwdArgs {
   float *p_ws, *ds_ws;
   int n_dst, n_src, H, C;
   hipStream_t stream;
+  float drop_p = 0.f;  // attention dropout: the forward's probability and seed (the mask is re-derived, common.h)
+  uint64_t drop_seed = 0;
 };
 
 // ---------------------------------------------------------------------------------------------- fast path
@@ -43,12 +45,13 @@ __global__ __launch_bounds__(64 * kBwdWaves) void gt_attn_bwd_dst_kernel(
     const T* __restrict__ e, int64_t lde, const T* __restrict__ out, int64_t ldo, const float* __restrict__ lse,
     const T* __restrict__ d_out, int64_t lddo, const int32_t* __restrict__ row, const int32_t* __restrict__ colptr,
     T* __restrict__ dq, int64_t lddq, T* __restrict__ de, int64_t ldde, float* __restrict__ p_ws, float* __restrict__ ds_ws,
-    int n_dst, int H, float scale) {
+    int n_dst, int H, float scale, float drop_p, uint64_t drop_seed) {
   const int lane = threadIdx.x & 63;
   const int d = __builtin_amdgcn_readfirstlane(blockIdx.x * kBwdWaves + (threadIdx.x >> 6));
   if (d >= n_dst) return;
   const int c0 = lane * VEC;
   const int h = lane / LPH;
+  const float inv_keep = 1.0f / (1.0f - drop_p);
   const int beg = colptr[d], end = colptr[d + 1];
   float acc[VEC];
 #pragma unroll
@@ -77,16 +80,19 @@ __global__ __launch_bounds__(64 * kBwdWaves) void gt_attn_bwd_dst_kernel(
         da = fmaf(gv[i], vv[i] + ev[i], da);
       }
       const float p = __expf(group_sum<LPH>(dot) * scale - m);
-      const float ds = p * (group_sum<LPH>(da) - Dj) * scale;  // dS_e / sqrt(C)
+      // with dropout o_d = sum_e c_e p_e (v + E) (c_e = 0 or 1 / (1 - p)): d p_e = c_e <dO, v + E>, D_d = <dO, o_d> as before, and
+      // the value-side weight (dE's second term, dv in the source pass) is c_e p_e
+      const float pc = drop_p > 0.f ? p * attn_dropout_scale(drop_seed, ei, h, drop_p, inv_keep) : p;
+      const float ds = (pc * group_sum<LPH>(da) - p * Dj) * scale;  // dS_e / sqrt(C)
       float dev[VEC];
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         acc[i] = fmaf(ds, kv[i], acc[i]);
-        dev[i] = fmaf(ds, qv[i], p * gv[i]);
+        dev[i] = fmaf(ds, qv[i], pc * gv[i]);
       }
       store_vec<T, VEC>(de + (int64_t)ei * ldde + c0, dev);
       if ((lane % LPH) == 0) {
-        p_ws[(int64_t)ei * H + h] = p;
+        p_ws[(int64_t)ei * H + h] = pc;
         ds_ws[(int64_t)ei * H + h] = ds;
       }
     }
@@ -156,11 +162,13 @@ __global__ void gt_attn_bwd_dst_generic_kernel(const T* __restrict__ q, int64_t 
                                                const T* __restrict__ d_out, int64_t lddo, const int32_t* __restrict__ row,
                                                const int32_t* __restrict__ colptr, T* __restrict__ dq, int64_t lddq,
                                                T* __restrict__ de, int64_t ldde, float* __restrict__ p_ws,
-                                               float* __restrict__ ds_ws, int n_dst, int H, int C, float scale) {
+                                               float* __restrict__ ds_ws, int n_dst, int H, int C, float scale, float drop_p,
+                                               uint64_t drop_seed) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (int64_t)n_dst * H) return;
   const int d = (int)(t / H), h = (int)(t % H);
   const int beg = colptr[d], end = colptr[d + 1];
+  const float inv_keep = 1.0f / (1.0f - drop_p);
   const T* qp = q + (int64_t)d * ldq + h * C;
   const T* gp = d_out + (int64_t)d * lddo + h * C;
   const T* op = out + (int64_t)d * ldo + h * C;
@@ -183,11 +191,12 @@ __global__ void gt_attn_bwd_dst_generic_kernel(const T* __restrict__ q, int64_t 
       da = fmaf(to_float(gp[c]), to_float(vp[c]) + ee, da);
     }
     const float p = expf(dot * scale - m);
-    const float ds = p * (da - Dj) * scale;
-    p_ws[(int64_t)ei * H + h] = p;
+    const float pc = drop_p > 0.f ? p * attn_dropout_scale(drop_seed, ei, h, drop_p, inv_keep) : p;
+    const float ds = (pc * da - p * Dj) * scale;
+    p_ws[(int64_t)ei * H + h] = pc;
     ds_ws[(int64_t)ei * H + h] = ds;
     T* dep = de + (int64_t)ei * ldde + h * C;
-    for (int c = 0; c < C; ++c) dep[c] = from_float<T>(fmaf(ds, to_float(qp[c]), p * to_float(gp[c])));
+    for (int c = 0; c < C; ++c) dep[c] = from_float<T>(fmaf(ds, to_float(qp[c]), pc * to_float(gp[c])));
   }
   for (int c = 0; c < C; ++c) {
     float a = 0.f;
@@ -230,7 +239,7 @@ int launch_fast(const BwdArgs& a, float scale) {
     hipLaunchKernelGGL((gt_attn_bwd_dst_kernel<T, VEC, LPH>), dim3((a.n_dst + kBwdWaves - 1) / kBwdWaves), block, 0, a.stream,
                        (const T*)a.q, a.ldq, (const T*)a.k, a.ldk, (const T*)a.v, a.ldv, (const T*)a.e, a.lde, (const T*)a.out,
                        a.ldo, a.lse, (const T*)a.d_out, a.lddo, a.row, a.colptr, (T*)a.dq, a.lddq, (T*)a.de, a.ldde, a.p_ws,
-                       a.ds_ws, a.n_dst, a.H, scale);
+                       a.ds_ws, a.n_dst, a.H, scale, a.drop_p, a.drop_seed);
     const int rc = check_launch("gt_attn_bwd_dst_kernel");
     if (rc != ANEMOI_OK) return rc;
   }
@@ -282,7 +291,7 @@ int launch(const BwdArgs& a) {
     hipLaunchKernelGGL((gt_attn_bwd_dst_generic_kernel<T>), dim3((unsigned)((td + 127) / 128)), dim3(128), 0, a.stream,
                        (const T*)a.q, a.ldq, (const T*)a.k, a.ldk, (const T*)a.v, a.ldv, (const T*)a.e, a.lde, (const T*)a.out,
                        a.ldo, a.lse, (const T*)a.d_out, a.lddo, a.row, a.colptr, (T*)a.dq, a.lddq, (T*)a.de, a.ldde, a.p_ws,
-                       a.ds_ws, a.n_dst, a.H, a.C, scale);
+                       a.ds_ws, a.n_dst, a.H, a.C, scale, a.drop_p, a.drop_seed);
     rc = check_launch("gt_attn_bwd_dst_generic_kernel");
     if (rc != ANEMOI_OK) return rc;
   }
@@ -668,6 +677,36 @@ int launch_fused(const FusedBwdArgs& f) {
 
 using namespace anemoi;
 
+extern "C" int anemoi_gt_attention_dropout_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                                       const void* e, int64_t lde, const void* out, int64_t ldo, const float* lse,
+                                       const void* d_out, int64_t lddo, const int32_t* row, const int32_t* colptr,
+                                       const int32_t* rowptr, const int32_t* edge_ids, const int32_t* edge_dst, void* dq,
+                                       int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, void* de, int64_t ldde,
+                                       float* p_ws, float* ds_ws, int32_t n_dst, int32_t n_src, int32_t n_edges, int32_t H,
+                                       int32_t C, float drop_p, uint64_t drop_seed, anemoi_dtype_t dtype, void* stream) {
+  ANEMOI_REQUIRE(drop_p >= 0.f && drop_p < 1.f && H < 65536, "gt_attention_dropout_bwd: dropout probability %g outside [0, 1) or H=%d too large", (double)drop_p, H);
+  ANEMOI_REQUIRE(n_dst >= 0 && n_src >= 0 && n_edges >= 0 && H > 0 && C > 0, "gt_attention_dropout_bwd: bad sizes n_dst=%d n_src=%d M=%d H=%d C=%d",
+                 n_dst, n_src, n_edges, H, C);
+  if (n_dst == 0 && n_src == 0) return ANEMOI_OK;
+  ANEMOI_REQUIRE(colptr && rowptr && dq && dk && dv, "gt_attention_dropout_bwd: null colptr/rowptr/dq/dk/dv");
+  ANEMOI_REQUIRE(n_dst == 0 || (q && out && lse && d_out), "gt_attention_dropout_bwd: null q/out/lse/d_out");
+  ANEMOI_REQUIRE(n_edges == 0 || (k && v && e && row && edge_ids && edge_dst && de && p_ws && ds_ws),
+                 "gt_attention_dropout_bwd: null k/v/e/row/edge_ids/edge_dst/de/workspace with %d edges", n_edges);
+  const int64_t D = (int64_t)H * C;
+  ANEMOI_REQUIRE(ldq >= D && ldk >= D && ldv >= D && lde >= D && ldo >= D && lddo >= D && lddq >= D && lddk >= D && lddv >= D && ldde >= D,
+                 "gt_attention_dropout_bwd: leading dimension smaller than H*C=%lld", (long long)D);
+  BwdArgs a{q, k, v, e, out, d_out, ldq, ldk, ldv, lde, ldo, lddo, lse, row, colptr, rowptr, edge_ids, edge_dst,
+            dq, dk, dv, de, lddq, lddk, lddv, ldde, p_ws, ds_ws, n_dst, n_src, H, C, as_stream(stream)};
+  a.drop_p = drop_p;
+  a.drop_seed = drop_seed;
+  switch (dtype) {
+    case ANEMOI_F32: return launch<float>(a);
+    case ANEMOI_BF16: return launch<bf16_t>(a);
+    case ANEMOI_F16: return launch<f16_t>(a);
+    default: set_error("unknown dtype %d", (int)dtype); return ANEMOI_E_INVALID;
+  }
+}
+
 extern "C" int anemoi_gt_attention_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                                        const void* e, int64_t lde, const void* out, int64_t ldo, const float* lse,
                                        const void* d_out, int64_t lddo, const int32_t* row, const int32_t* colptr,
@@ -675,24 +714,8 @@ extern "C" int anemoi_gt_attention_bwd(const void* q, int64_t ldq, const void* k
                                        int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, void* de, int64_t ldde,
                                        float* p_ws, float* ds_ws, int32_t n_dst, int32_t n_src, int32_t n_edges, int32_t H,
                                        int32_t C, anemoi_dtype_t dtype, void* stream) {
-  ANEMOI_REQUIRE(n_dst >= 0 && n_src >= 0 && n_edges >= 0 && H > 0 && C > 0, "gt_attention_bwd: bad sizes n_dst=%d n_src=%d M=%d H=%d C=%d",
-                 n_dst, n_src, n_edges, H, C);
-  if (n_dst == 0 && n_src == 0) return ANEMOI_OK;
-  ANEMOI_REQUIRE(colptr && rowptr && dq && dk && dv, "gt_attention_bwd: null colptr/rowptr/dq/dk/dv");
-  ANEMOI_REQUIRE(n_dst == 0 || (q && out && lse && d_out), "gt_attention_bwd: null q/out/lse/d_out");
-  ANEMOI_REQUIRE(n_edges == 0 || (k && v && e && row && edge_ids && edge_dst && de && p_ws && ds_ws),
-                 "gt_attention_bwd: null k/v/e/row/edge_ids/edge_dst/de/workspace with %d edges", n_edges);
-  const int64_t D = (int64_t)H * C;
-  ANEMOI_REQUIRE(ldq >= D && ldk >= D && ldv >= D && lde >= D && ldo >= D && lddo >= D && lddq >= D && lddk >= D && lddv >= D && ldde >= D,
-                 "gt_attention_bwd: leading dimension smaller than H*C=%lld", (long long)D);
-  BwdArgs a{q, k, v, e, out, d_out, ldq, ldk, ldv, lde, ldo, lddo, lse, row, colptr, rowptr, edge_ids, edge_dst,
-            dq, dk, dv, de, lddq, lddk, lddv, ldde, p_ws, ds_ws, n_dst, n_src, H, C, as_stream(stream)};
-  switch (dtype) {
-    case ANEMOI_F32: return launch<float>(a);
-    case ANEMOI_BF16: return launch<bf16_t>(a);
-    case ANEMOI_F16: return launch<f16_t>(a);
-    default: set_error("unknown dtype %d", (int)dtype); return ANEMOI_E_INVALID;
-  }
+  return anemoi_gt_attention_dropout_bwd(q, ldq, k, ldk, v, ldv, e, lde, out, ldo, lse, d_out, lddo, row, colptr, rowptr, edge_ids, edge_dst, dq, lddq,
+                                         dk, lddk, dv, lddv, de, ldde, p_ws, ds_ws, n_dst, n_src, n_edges, H, C, 0.f, 0, dtype, stream);
 }
 
 extern "C" int64_t anemoi_gt_attention_fused_edge_bwd_partial_floats(int32_t H, int32_t C, int32_t fe_pad) {

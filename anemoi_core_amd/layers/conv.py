@@ -69,9 +69,6 @@ class GraphTransformerConv(nn.Module):
 
     def forward(self, query: Tensor, key: Tensor, value: Tensor, edge_attr: Optional[Tensor], edge_index: Tensor,
                 size=None, edges_are_dst_sorted: bool = False) -> Tensor:
-        if self.dropout > 0.0 and self.training:
-            # the reference's blocks never set it (block.py builds the conv without dropout); in eval mode it is the identity
-            raise NotImplementedError("attention dropout in training mode is not supported by the fused kernels (eval mode: no-op)")
         n_dst, H, C = query.shape
         size = (key.shape[0], n_dst) if size is None else size
         csc = get_csc(edge_index, size, edges_are_dst_sorted)
@@ -80,6 +77,15 @@ class GraphTransformerConv(nn.Module):
             e = edge_attr if csc.perm is None else edge_attr.index_select(0, csc.perm)
             e = e.reshape(e.shape[0], H * C)
         flat = lambda t: t.reshape(t.shape[0], H * C)  # noqa: E731
+        drop = self.dropout if self.training else 0.0  # conv.py:145: F.dropout(alpha, p, training)
+        if drop > 0.0 or ops._needs_grad(query, key, value, edge_attr):
+            from .. import autograd
+
+            if e is None:  # the backward kernels walk a materialised edge tensor
+                e = query.new_zeros((csc.num_edges, H * C))
+            # the seed comes from torch's (CPU) default generator: torch.manual_seed reproduces the mask, no device sync
+            seed = int(torch.empty((), dtype=torch.int64).random_().item()) if drop > 0.0 else 0
+            return autograd.attention_conv(flat(query), flat(key), flat(value), e, csc, H, get_reverse_csr(csc), drop, seed).view(n_dst, H, C)
         return ops.gt_attention(flat(query), flat(key), flat(value), e, csc, H).view(n_dst, H, C)
 
 

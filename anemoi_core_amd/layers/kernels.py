@@ -64,12 +64,20 @@ class PaddedLinear:
         kernels (an 81 840-row edge embedding with K = 3 is bound by its 84 MB of output either way; the register-staged
         kernel needs 44-90 us for it, the ring kernels ~20)."""
         K, W = lin.weight.shape[1], x.shape[-1]
+        wdt = lin.weight.dtype
         if W == K:
             to64 = (wide or x.shape[0] >= 4096) and K % 64 and (K < 64 or (-K) % 64 <= 16)
             pad = (-K) % 64 if to64 else (-K) % 8
             if pad:
-                x = torch.nn.functional.pad(x, (0, pad))
+                if (x.is_cuda and x.dim() == 2 and x.stride(1) == 1 and x.dtype in (wdt, torch.float32)
+                        and not (torch.is_grad_enabled() and x.requires_grad)):
+                    # cast (fp32 geometric attributes entering a 16-bit model) + zero columns in ONE kernel (was cast, fill, copy)
+                    x = ops.assemble_input(x.unsqueeze(0), None, K + pad, out_dtype=wdt)
+                else:
+                    x = torch.nn.functional.pad(x.to(wdt), (0, pad))
                 W = x.shape[-1]
+        if x.dtype != wdt:
+            x = x.to(wdt)
         elif W < K or W % 8:  # else: the caller already appended zero columns (one padded copy shared by several consumers,
             # possibly up to a multiple of 64 so that the GEMM takes the DMA-ring kernels)
             raise ValueError(f"input width {W} is neither in_features {K} nor a zero-padded width (multiple of 8 >= {K})")
@@ -97,8 +105,8 @@ class PaddedLinear:
         return self(x, lin), None
 
     def __call__(self, x: Tensor, lin: nn.Linear, **kw) -> Tensor:
-        if x.dtype == torch.float32:
-            return ops.linear(x, lin.weight, lin.bias, **kw)
+        if lin.weight.dtype == torch.float32:
+            return ops.linear(x.to(torch.float32), lin.weight, lin.bias, **kw)
         x, w = self._prep(x, lin)
         return ops.linear(x, w, lin.bias, **kw)
 

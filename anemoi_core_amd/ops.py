@@ -186,9 +186,12 @@ def processing_order(csc: CSC, slices: int = 8) -> Optional[Tensor]:
 
 # ------------------------------------------------------------------------------------------ kernels
 def gt_attention(q: Tensor, k: Tensor, v: Tensor, e: Optional[Tensor], csc: CSC, num_heads: int,
-                 addend: Optional[Tensor] = None, return_lse: bool = False):
-    """out[d] = softmax-attention over in-edges (+ addend).  q/out/addend [n_dst, D]; k, v [n_src, D]; e [M, D]."""
+                 addend: Optional[Tensor] = None, return_lse: bool = False, dropout_p: float = 0.0, dropout_seed: int = 0):
+    """out[d] = softmax-attention over in-edges (+ addend).  q/out/addend [n_dst, D]; k, v [n_src, D]; e [M, D].
+    ``dropout_p`` > 0: dropout on the softmax weights (conv.py:145), mask = f(dropout_seed, edge, head) (``attention_dropout_mask``)."""
     _dev(q, k, v, e, addend, csc.row)
+    if not 0.0 <= dropout_p < 1.0:
+        raise ValueError(f"dropout probability must be in [0, 1), got {dropout_p}")
     D = q.shape[1]
     if D % num_heads:
         raise ValueError(f"channels {D} not divisible by heads {num_heads}")
@@ -201,11 +204,22 @@ def gt_attention(q: Tensor, k: Tensor, v: Tensor, e: Optional[Tensor], csc: CSC,
     (qp, ldq), (kp, ldk), (vp, ldv) = _rows(q, "q"), _rows(k, "k", q.dtype), _rows(v, "v", q.dtype)
     ep, lde = _rows(e, "e", q.dtype)
     ap, lda = _rows(addend, "addend", q.dtype)
-    rc = _lib.load().anemoi_gt_attention_fwd(qp, ldq, kp, ldk, vp, ldv, ep, lde, csc.row.data_ptr(), csc.colptr.data_ptr(),
-                                             ap, lda, out.data_ptr(), D, lse.data_ptr() if return_lse else 0,
-                                             csc.n_dst, csc.n_src, num_heads, D // num_heads, _dt(q), _stream())
+    rc = _lib.load().anemoi_gt_attention_dropout_fwd(qp, ldq, kp, ldk, vp, ldv, ep, lde, csc.row.data_ptr(), csc.colptr.data_ptr(),
+                                                     ap, lda, out.data_ptr(), D, lse.data_ptr() if return_lse else 0,
+                                                     csc.n_dst, csc.n_src, num_heads, D // num_heads, float(dropout_p),
+                                                     int(dropout_seed) & (2**64 - 1), _dt(q), _stream())
     _lib.check(rc, "gt_attention_fwd")
     return (out, lse) if return_lse else out
+
+
+def attention_dropout_mask(num_edges: int, num_heads: int, dropout_p: float, dropout_seed: int, device) -> Tensor:
+    """fp32 [M, H]: 0 where ``gt_attention(dropout_p, dropout_seed)`` drops the weight of (CSC edge, head), 1 / (1 - p) where it
+    keeps it - the scale the kernels derive on the fly."""
+    out = torch.empty((num_edges, num_heads), dtype=torch.float32, device=device)
+    _dev(out)
+    _lib.check(_lib.load().anemoi_attention_dropout_mask(out.data_ptr(), num_edges, num_heads, float(dropout_p), int(dropout_seed) & (2**64 - 1),
+                                                         _stream()), "attention_dropout_mask")
+    return out
 
 
 def build_reverse_csr(csc: CSC) -> tuple[Tensor, Tensor, Tensor]:
@@ -219,7 +233,8 @@ def build_reverse_csr(csc: CSC) -> tuple[Tensor, Tensor, Tensor]:
 
 
 def gt_attention_backward(d_out: Tensor, q: Tensor, k: Tensor, v: Tensor, e: Tensor, out: Tensor, lse: Tensor, csc: CSC,
-                          reverse: tuple[Tensor, Tensor, Tensor], num_heads: int, grads_out=None):
+                          reverse: tuple[Tensor, Tensor, Tensor], num_heads: int, grads_out=None, dropout_p: float = 0.0,
+                          dropout_seed: int = 0):
     """Gradients (dq, dk, dv, de) of ``gt_attention`` with a materialised edge tensor.  All node/edge tensors [rows, D];
     ``out``/``lse`` are the forward's results; ``reverse`` = build_reverse_csr(csc).  ``grads_out`` = (dq, dk, dv): write
     the node gradients into these (row-strided) views, e.g. column slabs of one fused-projection gradient buffer."""
@@ -249,10 +264,11 @@ def gt_attention_backward(d_out: Tensor, q: Tensor, k: Tensor, v: Tensor, e: Ten
     (op, ldo), (gp, ldg) = _rows(out, "out", q.dtype), _rows(d_out, "d_out", q.dtype)
     i32 = lambda t: t if t.dtype == torch.int32 and t.is_contiguous() else t.to(torch.int32).contiguous()  # noqa: E731
     rowptr, edge_ids, edge_dst = i32(rowptr), i32(edge_ids), i32(edge_dst)
-    rc = _lib.load().anemoi_gt_attention_bwd(
+    rc = _lib.load().anemoi_gt_attention_dropout_bwd(
         qp, ldq, kp, ldk, vp, ldv, ep, lde, op, ldo, lse.contiguous().data_ptr(), gp, ldg, csc.row.data_ptr(), csc.colptr.data_ptr(),
         rowptr.data_ptr(), edge_ids.data_ptr(), edge_dst.data_ptr(), dqp, lddq, dkp, lddk, dvp, lddv,
-        de.data_ptr(), D, ws[0].data_ptr(), ws[1].data_ptr(), csc.n_dst, csc.n_src, M, num_heads, D // num_heads, _dt(q), _stream())
+        de.data_ptr(), D, ws[0].data_ptr(), ws[1].data_ptr(), csc.n_dst, csc.n_src, M, num_heads, D // num_heads, float(dropout_p),
+        int(dropout_seed) & (2**64 - 1), _dt(q), _stream())
     _lib.check(rc, "gt_attention_bwd")
     return dq, dk, dv, de
 
@@ -836,6 +852,28 @@ def gnn_edge_chain(e: Tensor, g1: Tensor, idx1: Tensor, g2: Tensor, idx2: Tensor
     _lib.check(_lib.load().anemoi_gnn_edge_chain_fwd(ep, lde, p1, ld1, idx1.data_ptr(), p2, ld2, idx2.data_ptr(), w0.data_ptr(), _vec(b0, "b0", D, dt),
                                                      w1.data_ptr(), _vec(b1, "b1", D, dt), w2.data_ptr(), _vec(b2, "b2", D, dt), _vec(ln_w, "ln_w", D, dt),
                                                      _vec(ln_b, "ln_b", D, dt), float(eps), out.data_ptr(), D, M, D, _dt(e), _stream()), "gnn_edge_chain_fwd")
+    return out
+
+
+def gnn_mlp_chain(x: Tensor, w0: Tensor, b0: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, ln_w: Tensor, ln_b: Optional[Tensor],
+                  eps: float, residual: Optional[Tensor] = None) -> Tensor:
+    """An embedding MLP in ONE launch (anemoi_gnn_mlp_chain_fwd): ``LayerNorm(W2 gelu(W1 gelu(W0 x + b0) + b1) + b2) [+ residual]``.
+    x [N, K] with K in {128, 256, 384, 512} (zero-padded by the caller), w0 = pack_weight_frag of the [512, K] weight.  Inference only."""
+    _dev(x, w0, b0, w1, b1, w2, b2, ln_w, ln_b, residual)
+    N, K = x.shape
+    D, dt = CHAIN_CHANNELS, x.dtype
+    if dt not in (torch.bfloat16, torch.float16) or K % 128 or not 128 <= K <= D:
+        raise NotImplementedError(f"gnn_mlp_chain: width {K} / {dt} (built for 16-bit rows of 128, 256, 384 or 512 columns)")
+    for name, w, numel in (("w0", w0, D * K), ("w1", w1, D * D), ("w2", w2, D * D)):
+        if w.dim() != 1 or w.numel() != numel or w.dtype != dt or not w.is_contiguous():
+            raise ValueError(f"gnn_mlp_chain: {name} must be a contiguous fragment-major image of {numel} elements (pack_weight_frag)")
+    if residual is not None and (tuple(residual.shape) != (N, D) or residual.dtype != dt):
+        raise ValueError("gnn_mlp_chain: residual must be [N, 512] of x's dtype")
+    out = torch.empty((N, D), dtype=dt, device=x.device)
+    (xp, ldx), (rp, ldr) = _rows(x, "x", dt), _rows(residual, "residual", dt)
+    _lib.check(_lib.load().anemoi_gnn_mlp_chain_fwd(xp, ldx, K, w0.data_ptr(), _vec(b0, "b0", D, dt), w1.data_ptr(), _vec(b1, "b1", D, dt), w2.data_ptr(),
+                                                    _vec(b2, "b2", D, dt), _vec(ln_w, "ln_w", D, dt), _vec(ln_b, "ln_b", D, dt), float(eps), rp, ldr,
+                                                    out.data_ptr(), D, N, D, _dt(x), _stream()), "gnn_mlp_chain_fwd")
     return out
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ANEMOI_HIP_ABI_VERSION 10
+#define ANEMOI_HIP_ABI_VERSION 11
 
 typedef enum { ANEMOI_F32 = 0, ANEMOI_BF16 = 1, ANEMOI_F16 = 2 } anemoi_dtype_t;
 typedef enum { ANEMOI_ACT_NONE = 0, ANEMOI_ACT_GELU = 1 } anemoi_act_t;
@@ -72,6 +72,27 @@ int anemoi_gt_attention_bwd(const void* q, int64_t ldq, const void* k, int64_t l
                             void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, void* de, int64_t ldde,
                             float* p_ws, float* ds_ws, int32_t n_dst, int32_t n_src, int32_t n_edges, int32_t H, int32_t C,
                             anemoi_dtype_t dtype, void* stream);
+
+/* The two ops above with DROPOUT on the softmax weights (training mode of the reference's conv: layers/conv.py:145,
+ * `alpha = dropout(alpha, p, training)` after the segment softmax): out[d] = sum_e c_e alpha_e (v_s + E_e) with c_e = 0 (dropped,
+ * probability drop_p) or 1 / (1 - drop_p); the softmax itself (and lse) sums every edge.  The keep decision of (CSC edge, head) is
+ * a pure function of (drop_seed, edge, head) - a counter-based generator, csrc/common.h: attn_dropout_scale - so the backward takes
+ * the SAME (drop_p, drop_seed) and re-derives the mask instead of reading a stored one.  drop_p = 0 is the plain op, bit for bit
+ * (anemoi_gt_attention_fwd / _bwd are these entry points with drop_p = 0).  anemoi_attention_dropout_mask writes c_e as fp32
+ * [n_edges, H]: what a caller needs to restate the op with an explicit mask (tests/test_attention_dropout_gpu.py). */
+int anemoi_gt_attention_dropout_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                                    const void* e, int64_t lde, const int32_t* row, const int32_t* colptr,
+                                    const void* addend, int64_t ldadd, void* out, int64_t ldo, float* lse,
+                                    int32_t n_dst, int32_t n_src, int32_t H, int32_t C, float drop_p, uint64_t drop_seed,
+                                    anemoi_dtype_t dtype, void* stream);
+int anemoi_gt_attention_dropout_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                                    const void* e, int64_t lde, const void* out, int64_t ldo, const float* lse,
+                                    const void* d_out, int64_t lddo, const int32_t* row, const int32_t* colptr,
+                                    const int32_t* rowptr, const int32_t* edge_ids, const int32_t* edge_dst,
+                                    void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, void* de, int64_t ldde,
+                                    float* p_ws, float* ds_ws, int32_t n_dst, int32_t n_src, int32_t n_edges, int32_t H, int32_t C,
+                                    float drop_p, uint64_t drop_seed, anemoi_dtype_t dtype, void* stream);
+int anemoi_attention_dropout_mask(float* out, int32_t n_edges, int32_t H, float drop_p, uint64_t drop_seed, void* stream);
 
 /* Same op with ``lin_edge`` fused: E[e] = edge_attr[e] @ w_edge^T + b_edge is never materialised.
  * Replaces: lin_edge(...) + the op above (layers/block.py:623-635 + triton/gt.py:81-179).
@@ -387,6 +408,17 @@ int anemoi_gnn_edge_chain_fwd(const void* e, int64_t ld_e, const void* g1, int64
                               const int32_t* idx2, const void* w0, const void* b0, const void* w1, const void* b1, const void* w2, const void* b2,
                               const void* ln_w, const void* ln_b, float eps, void* e_new, int64_t ld_o, int32_t n_rows, int32_t channels,
                               anemoi_dtype_t dtype, void* stream);
+/* An embedding MLP of the GNN mappers / processor as ONE launch (the edge chain without gathered rows):
+ *   out = LayerNorm(W_2 gelu(W_1 gelu(W_0 x + b_0) + b_1) + b_2) [+ res]
+ * Replaces: MLP.forward for `emb_edges` / `emb_nodes_src` / `emb_nodes_dst` (layers/mlp.py:29-100 as built at
+ * layers/mapper.py:640-700 and layers/processor.py GNNProcessor: Linear -> GELU -> Linear -> GELU -> Linear -> LayerNorm).
+ *   x [n_rows, in_features] with in_features in {128, 256, 384, 512} (the caller zero-pads the raw width; ld_x >= in_features);
+ *   w0: fragment-major image of the [512, in_features] weight (zero columns for the padding), w1 / w2: of [512, 512];
+ *   res (nullable): [n_rows, 512] rows added after the LayerNorm. */
+int anemoi_gnn_mlp_chain_fwd(const void* x, int64_t ld_x, int32_t in_features, const void* w0, const void* b0, const void* w1, const void* b1,
+                             const void* w2, const void* b2, const void* ln_w, const void* ln_b, float eps, const void* res, int64_t ld_res,
+                             void* out, int64_t ld_o, int32_t n_rows, int32_t channels, anemoi_dtype_t dtype, void* stream);
+
 /* The node MLP of a GraphConv block (layers/block.py:392-394; MLP of three Linears + LayerNorm, layers/mlp.py:97-179) with its skip:
  *     x_out = LayerNorm(W_c gelu(W_b gelu(W_a [x | agg] + b_a) + b_b) + b_c; ln) + x
  * and optionally t_out = x_out W_t^T [+ b_t] - the NEXT block's stacked node-level terms [x W_i^T | x W_j^T] its edge chain gathers.

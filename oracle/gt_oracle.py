@@ -103,11 +103,14 @@ def segment_softmax(alpha: Tensor, index: Tensor, num_segments: int) -> Tensor:
     return ex / seg_sum.index_select(0, index)
 
 
-def gt_conv(query: Tensor, key: Tensor, value: Tensor, edges: Tensor, edge_index: Tensor, size: tuple) -> Tensor:
+def gt_conv(query: Tensor, key: Tensor, value: Tensor, edges: Tensor, edge_index: Tensor, size: tuple,
+            alpha_scale: Optional[Tensor] = None) -> Tensor:
     """GraphTransformerConv.forward/message + add-aggregate (layers/conv.py:103-147).
 
     query [N_dst,H,C]; key,value [N_src,H,C]; edges [M,H,C]; edge_index [2,M] (src,dst), any order.
-    Zero-in-degree destinations come out as 0 (index_add into zeros)."""
+    Zero-in-degree destinations come out as 0 (index_add into zeros).
+    ``alpha_scale`` [M,H]: the training-mode dropout of conv.py:145 with an EXPLICIT mask - F.dropout multiplies the softmax weights
+    by 0 (dropped) or 1 / (1 - p) (kept); the values of that factor per (edge, head), in the order of ``edge_index``."""
     n_dst = size[1]
     C = query.shape[-1]
     src, dst = edge_index[0].long(), edge_index[1].long()
@@ -116,6 +119,8 @@ def gt_conv(query: Tensor, key: Tensor, value: Tensor, edges: Tensor, edge_index
     v_j = value.index_select(0, src) + edges
     alpha = (q_i * k_j).sum(dim=-1) / C**0.5  # [M,H]
     alpha = segment_softmax(alpha, dst, n_dst)
+    if alpha_scale is not None:
+        alpha = alpha * alpha_scale
     msg = v_j * alpha.unsqueeze(-1)
     out = query.new_zeros((n_dst,) + tuple(query.shape[1:]))
     return out.index_add_(0, dst, msg)

@@ -285,6 +285,49 @@ def test_gnn_node_chain_vs_fp32_restatement(dtype, N, trailing):
         _close(res, want, f"node chain N={N}", tol=2.5e-2)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,K,with_res", [(1500, 11, False), (5000, 100, True), (40320, 200, False), (81840, 3, False), (2049, 512, True), (3000, 384, False)])
+def test_embedding_mlp_chain(dtype, N, K, with_res):
+    """An embedding MLP (Linear-GELU-Linear-GELU-Linear-LayerNorm into 512 channels, raw input width K) through MLP.forward: the
+    row-resident launch (csrc/gnn_chain.hip, MLP instantiation) against fp32 torch with the rounding points of the launch-per-GEMM path
+    and against that path itself (ANEMOI_GNN_CHAIN=0) on the same module."""
+    from anemoi_core_amd.layers import conv as C
+    from anemoi_core_amd.layers.mlp import MLP
+    from anemoi_core_amd.layers.utils import load_layer_kernels
+
+    torch.manual_seed(N + K)
+    m = MLP(K, D, D, layer_kernels=load_layer_kernels(None), n_extra_layers=1).to(DEV).to(dtype).eval()
+    with torch.no_grad():
+        m.layer_norm.weight.uniform_(0.5, 1.5)
+        m.layer_norm.bias.uniform_(-0.3, 0.3)
+    gen = torch.Generator().manual_seed(K)
+    x32 = torch.randn(N, K, generator=gen)  # fp32 geometric attributes entering a 16-bit model (cast while padding)
+    res = torch.randn(N, D, generator=gen).to(dtype).to(DEV) if with_res else None
+    saved = C._GNN_CHAIN
+    try:
+        with torch.no_grad():
+            C._GNN_CHAIN = True
+            assert m._embedding_chain_ok(x32.to(DEV), list(m.mlp))
+            got = m(x32.to(DEV), residual=res)
+            got16 = m(x32.to(dtype).to(DEV), residual=res)  # input already in the model dtype
+            C._GNN_CHAIN = False
+            path = m(x32.to(DEV), residual=res)
+    finally:
+        C._GNN_CHAIN = saved
+    f = lambda t: t.detach().float().cpu()  # noqa: E731
+    rnd = lambda t: t.to(dtype).float()  # noqa: E731
+    l0, l1, l2, ln = m.mlp[0], m.mlp[2], m.mlp[4], m.layer_norm
+    h1 = rnd(F.gelu(F.linear(rnd(x32), f(l0.weight), f(l0.bias))))
+    h2 = rnd(F.gelu(F.linear(h1, f(l1.weight), f(l1.bias))))
+    z = rnd(F.linear(h2, f(l2.weight), f(l2.bias)))
+    want = F.layer_norm(z, (D,), f(ln.weight), f(ln.bias), ln.eps)
+    want = rnd(want + f(res)) if with_res else rnd(want)
+    _close(got, want, f"embedding chain N={N} K={K}", tol=2.5e-2)
+    assert torch.equal(got, got16)
+    err = (got.float() - path.float()).abs()
+    assert float(err.max()) <= 4e-2 * float(want.abs().max()) and float(err.mean()) <= 3e-3 * float(want.abs().mean() + 1)
+
+
 def test_gnn_model_with_chains_equals_model_without():
     """The 512-channel GNN model: chain launches (edge chain + segment sum + node chain with the next block's stacked projection) against
     the launch-per-GEMM path and the fp32 CPU oracle."""

@@ -74,14 +74,15 @@ def test_constructor_validation_matches_reference():
         load_layer_kernels({"Linear": {"_target_": "torch.nn.Bilinear"}})
 
 
-def test_attention_dropout_is_an_eval_noop_and_refused_in_training():
-    """conv.py:94,145: dropout on the attention weights only acts in training mode; the fused kernels do not implement it."""
+def test_attention_dropout_is_a_training_mode_feature_of_the_hip_path():
+    """conv.py:94,145: dropout on the attention weights only acts in training mode; it runs in the HIP kernels
+    (tests/test_attention_dropout_gpu.py), so a CPU tensor is refused like everywhere else."""
     from anemoi_core_amd.layers.conv import GraphTransformerConv
 
     conv = GraphTransformerConv(out_channels=8, dropout=0.1)
     assert conv.dropout == 0.1
     q = torch.zeros(3, 2, 8)
-    with pytest.raises(NotImplementedError, match="training mode"):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
         conv.train()(q, q, q, None, torch.zeros(2, 0, dtype=torch.long))
     with pytest.raises(ValueError):
         GraphTransformerConv(out_channels=8, dropout=1.5)
