@@ -254,6 +254,14 @@ def profile_forward(step, dtype, host_ms: float = 12.0):
         M, D = e.shape
         return "gnn_edge_chain_kernel", 2.0 * M * 3 * D * D, es * (4 * M * D + 3 * D * D) + 8 * M
 
+    def mlp_chain_work(res_, a_, kw):
+        # an embedding MLP (csrc/gnn_chain.hip, MLP instantiation of the edge chain kernel: counted in ITS family, as the traces name it)
+        x = a_[0]
+        N, K = x.shape
+        D = res_.shape[1]
+        has_res = len(a_) > 10 and a_[10] is not None or kw.get("residual") is not None
+        return "gnn_edge_chain_kernel", 2.0 * N * (K * D + 2 * D * D), es * (N * K + N * D * (2 if has_res else 1) + K * D + 2 * D * D)
+
     def node_chain_work(res_, a_, kw):
         x = a_[0]
         N, D = x.shape
@@ -278,7 +286,7 @@ def profile_forward(step, dtype, host_ms: float = 12.0):
     table = {"linear": ("linear", lin_work), "gt_attention_fused_edge": ("attn", attn_work), "layer_norm": ("ln", ln_work),
              "linear_with_row_stats": ("linear_stats", gemm_work), "linear_ln_folded": ("linear_lnfold", gemm_work),
              "gt_layer_chain": ("chain", chain_work), "gnn_edge_chain": ("edge_chain", edge_chain_work),
-             "gnn_node_chain": ("node_chain", node_chain_work), "segment_sum_rows": ("segrows", segrows_work),
+             "gnn_node_chain": ("node_chain", node_chain_work), "gnn_mlp_chain": ("mlp_chain", mlp_chain_work), "segment_sum_rows": ("segrows", segrows_work),
              "edge_ln_residual_segment_sum": ("segsum", segsum_work), "gather_rows": ("gather", rows_work("gather_rows_kernel")),
              "gather_add_rows": ("gather_add", rows_work("gather_add_rows_kernel"))}
     saved = {n: getattr(ops, n) for n in table}
