@@ -282,6 +282,9 @@ struct NodeChainArgs {
   const char* wt;   const void* bt; int tc;  // optional trailing projection [512 tc, 512] of x_out (bt may be null: no bias); tc = 0: none
   void* t_out;      int64_t ld_t;
   int n_rows, rows_per_tile, n_tiles;
+  // seg_ptr != null: `agg` holds the EDGE rows [M, 512] (sorted by destination) and the panel's agg rows are their segmented sums,
+  // agg[n] = sum_{i in [seg_ptr[n], seg_ptr[n+1])} edge_rows[i] - fp32, in edge order, rounded once: anemoi_segment_sum_rows' arithmetic
+  const int32_t* seg_ptr = nullptr;
 };
 
 template <typename T>
@@ -312,7 +315,46 @@ __global__ __launch_bounds__(512, 1) void gnn_node_chain_kernel(NodeChainArgs a)
       const int idx = tid + 512 * i;
       const int rr = min(idx >> 6, nr - 1), slot = idx & 63;
       va[i] = *reinterpret_cast<const u32x4*>((const T*)a.x + (int64_t)(r0 + rr) * a.ld_x + slot * 8);
-      vb[i] = *reinterpret_cast<const u32x4*>((const T*)a.agg + (int64_t)(r0 + rr) * a.ld_a + slot * 8);
+      if (a.seg_ptr == nullptr) vb[i] = *reinterpret_cast<const u32x4*>((const T*)a.agg + (int64_t)(r0 + rr) * a.ld_a + slot * 8);
+    }
+  };
+  // The aggregation inside the launch (GraphConv's scatter-sum, layers/conv.py:81): a wave sums the in-edge rows of panel rows wave,
+  // wave + 8, ... (1 KiB per edge row, one 16-byte slot per lane, 4 rows in flight) - the panel's ~8 x 48 edge rows come through this
+  // CU's L1 once, instead of a launch that reads every edge row and writes an [N, 512] table this kernel then reads back.
+  auto aggregate_panel = [&](int t) {
+    const int r0 = t * a.rows_per_tile;
+    const int nr = min(a.rows_per_tile, a.n_rows - r0);
+    const T* const base = (const T*)a.agg + lane * 8;
+#pragma unroll 1
+    for (int i = 0; i < 6; ++i) {
+      const int row = wave + 8 * i;
+      float s8[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) s8[c] = 0.f;
+      if (row < nr) {
+        const int beg = __builtin_amdgcn_readfirstlane(a.seg_ptr[r0 + row]), end = __builtin_amdgcn_readfirstlane(a.seg_ptr[r0 + row + 1]);
+#pragma unroll 1
+        for (int e = beg; e < end; e += 4) {
+          u32x4 r[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) r[u] = *reinterpret_cast<const u32x4*>(base + (int64_t)min(e + u, end - 1) * a.ld_a);
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (e + u < end) {
+              float lo[4], hi[4];
+              unpack4<T>(u32x2{r[u][0], r[u][1]}, lo);
+              unpack4<T>(u32x2{r[u][2], r[u][3]}, hi);
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                s8[c] += lo[c];
+                s8[4 + c] += hi[c];
+              }
+            }
+        }
+      }
+      float lo[4] = {s8[0], s8[1], s8[2], s8[3]}, hi[4] = {s8[4], s8[5], s8[6], s8[7]};
+      const u32x2 pl = pack4<T>(lo), ph = pack4<T>(hi);
+      *reinterpret_cast<u32x4*>(bufC + row * kRowBytes + ((lane ^ (row & 15)) << 4)) = u32x4{pl[0], pl[1], ph[0], ph[1]};
     }
   };
   request_panel(tile);
@@ -335,8 +377,9 @@ __global__ __launch_bounds__(512, 1) void gnn_node_chain_kernel(NodeChainArgs a)
       const int row = idx >> 6, slot = idx & 63;
       const int off = row * kRowBytes + ((slot ^ (row & 15)) << 4);
       *reinterpret_cast<u32x4*>(bufA + off) = row < nr ? va[i] : zero4;
-      *reinterpret_cast<u32x4*>(bufC + off) = row < nr ? vb[i] : zero4;
+      if (a.seg_ptr == nullptr) *reinterpret_cast<u32x4*>(bufC + off) = row < nr ? vb[i] : zero4;
     }
+    if (a.seg_ptr != nullptr) aggregate_panel(tile);
     u32x2 pb[4];
     load_cols<T>((const T*)a.ba, wave, g, pb);
     __builtin_amdgcn_sched_barrier(0);
@@ -542,10 +585,10 @@ extern "C" int anemoi_gnn_mlp_chain_fwd(const void* x, int64_t ld_x, int32_t in_
   return check_launch("gnn_mlp_chain_kernel");
 }
 
-extern "C" int anemoi_gnn_node_chain_fwd(const void* x, int64_t ld_x, const void* agg, int64_t ld_a, const void* wa, const void* ba, const void* wb,
-                                         const void* bb, const void* wc, const void* bc, const void* ln_w, const void* ln_b, float eps, void* x_out,
-                                         int64_t ld_o, const void* wt, const void* bt, int32_t t_out_features, void* t_out, int64_t ld_t,
-                                         int32_t n_rows, int32_t channels, anemoi_dtype_t dtype, void* stream) {
+static int node_chain_launch(const void* x, int64_t ld_x, const void* agg, int64_t ld_a, const int32_t* seg_ptr, const void* wa, const void* ba, const void* wb,
+                             const void* bb, const void* wc, const void* bc, const void* ln_w, const void* ln_b, float eps, void* x_out,
+                             int64_t ld_o, const void* wt, const void* bt, int32_t t_out_features, void* t_out, int64_t ld_t,
+                             int32_t n_rows, int32_t channels, anemoi_dtype_t dtype, void* stream) {
   ANEMOI_REQUIRE(dtype == ANEMOI_BF16 || dtype == ANEMOI_F16, "gnn_node_chain_fwd: 16-bit model dtypes only");
   ANEMOI_REQUIRE(n_rows >= 0 && channels == kCh, "gnn_node_chain_fwd: channels=%d (this kernel is built for %d)", channels, kCh);
   if (n_rows == 0) return ANEMOI_OK;
@@ -557,6 +600,7 @@ extern "C" int anemoi_gnn_node_chain_fwd(const void* x, int64_t ld_x, const void
                  "gnn_node_chain_fwd: operand alignment / leading dimensions");
   NodeChainArgs a{x, ld_x, agg, ld_a, (const char*)wa, ba, (const char*)wb, bb, (const char*)wc, bc, ln_w, ln_b, eps, x_out, ld_o,
                   (const char*)wt, bt, t_out_features / kCh, t_out, ld_t, n_rows, chain_rows_per_tile(n_rows), 0};
+  a.seg_ptr = seg_ptr;
   a.n_tiles = (n_rows + a.rows_per_tile - 1) / a.rows_per_tile;
   const int grid = a.n_tiles < 256 ? a.n_tiles : 256;
   hipStream_t st = as_stream(stream);
@@ -570,4 +614,22 @@ extern "C" int anemoi_gnn_node_chain_fwd(const void* x, int64_t ld_x, const void
     hipLaunchKernelGGL((gnn_node_chain_kernel<f16_t>), dim3(grid), dim3(512), kChainSmem, st, a);
   }
   return check_launch("gnn_node_chain_kernel");
+}
+
+extern "C" int anemoi_gnn_node_chain_fwd(const void* x, int64_t ld_x, const void* agg, int64_t ld_a, const void* wa, const void* ba, const void* wb,
+                                         const void* bb, const void* wc, const void* bc, const void* ln_w, const void* ln_b, float eps, void* x_out,
+                                         int64_t ld_o, const void* wt, const void* bt, int32_t t_out_features, void* t_out, int64_t ld_t,
+                                         int32_t n_rows, int32_t channels, anemoi_dtype_t dtype, void* stream) {
+  return node_chain_launch(x, ld_x, agg, ld_a, nullptr, wa, ba, wb, bb, wc, bc, ln_w, ln_b, eps, x_out, ld_o, wt, bt, t_out_features, t_out, ld_t, n_rows,
+                           channels, dtype, stream);
+}
+
+extern "C" int anemoi_gnn_node_chain_segsum_fwd(const void* x, int64_t ld_x, const void* edge_rows, int64_t ld_e, const int32_t* seg_ptr, const void* wa,
+                                                const void* ba, const void* wb, const void* bb, const void* wc, const void* bc, const void* ln_w,
+                                                const void* ln_b, float eps, void* x_out, int64_t ld_o, const void* wt, const void* bt,
+                                                int32_t t_out_features, void* t_out, int64_t ld_t, int32_t n_rows, int32_t channels,
+                                                anemoi_dtype_t dtype, void* stream) {
+  ANEMOI_REQUIRE(seg_ptr != nullptr || n_rows == 0, "gnn_node_chain_segsum_fwd: null segment pointer");
+  return node_chain_launch(x, ld_x, edge_rows, ld_e, seg_ptr, wa, ba, wb, bb, wc, bc, ln_w, ln_b, eps, x_out, ld_o, wt, bt, t_out_features, t_out, ld_t,
+                           n_rows, channels, dtype, stream);
 }

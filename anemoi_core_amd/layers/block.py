@@ -20,7 +20,7 @@ from ..distributed import primitives as comm
 from ..distributed.halo import HaloInfo, build_halo_info
 from ..distributed.partition import build_graph_partition_from_shard_info
 from ..distributed.shapes import BipartiteGraphShardInfo, GraphShardInfo, comm_rank, comm_size, model_is_distributed
-from .conv import GraphConv, mlp_chain_ok, node_mlp_chain
+from .conv import DeferredAggregate, GraphConv, mlp_chain_ok, node_mlp_chain
 from . import conv as _conv
 from .graphcache import get_csc, get_edge_features, get_reverse_csr
 from .kernels import PaddedLinear
@@ -657,7 +657,7 @@ class GraphConvProcessorBlock(GraphConvBaseBlock):
             p = chain["p"] if (chain is not None and chain.get("p_x") is x and self.conv.chain_ok(x, edge_attr)) else None
             if chain is not None:
                 chain.clear()
-            out, edges_new = self.conv(x, edge_attr, edge_index, size=size, p=p)
+            out, edges_new = self.conv(x, edge_attr, edge_index, size=size, p=p, defer_sum=mlp_chain_ok(self.node_mlp, 2 * ops.CHAIN_CHANNELS, x))
         if mlp_chain_ok(self.node_mlp, 2 * ops.CHAIN_CHANNELS, x) and out.dtype == x.dtype:
             kw = {}
             if (chain is not None and not model_is_distributed(model_comm_group) and isinstance(nxt, GraphConvProcessorBlock)
@@ -668,6 +668,8 @@ class GraphConvProcessorBlock(GraphConvBaseBlock):
                 chain["p_x"], chain["p"] = res
                 return res[0], edges_new
             return res, edges_new
+        if isinstance(out, DeferredAggregate):
+            out = out.materialize()
         nodes_new = self.node_mlp(x, x2=out, residual=x)
         return nodes_new, edges_new
 
@@ -698,11 +700,14 @@ class GraphConvMapperBlock(GraphConvBaseBlock):
         """``x_src_conv``: the source rows ``edge_index[0]`` refers to; ``x_src_update``: the source rows this rank owns
         (the same tensor when nothing is sharded)."""
         size = (x_src_conv.shape[0], x_dst.shape[0]) if size is None else size
-        out, edges_new = self.conv((x_src_conv, x_dst), edge_attr, edge_index, size=size)
+        out, edges_new = self.conv((x_src_conv, x_dst), edge_attr, edge_index, size=size,
+                                   defer_sum=x_dst.dim() == 2 and mlp_chain_ok(self.node_mlp, 2 * ops.CHAIN_CHANNELS, x_dst))
 
         def node(xr, x2):  # LayerNorm(node_mlp([x | x2])) + x: one row-resident launch where the chain kernel takes the shapes
             if mlp_chain_ok(self.node_mlp, 2 * ops.CHAIN_CHANNELS, xr) and x2.dtype == xr.dtype and xr.dim() == 2:
                 return node_mlp_chain(self.node_mlp, xr, x2)
+            if isinstance(x2, DeferredAggregate):
+                x2 = x2.materialize()
             return self.node_mlp(xr, x2=x2, residual=xr)
 
         nodes_new_dst = node(x_dst, out)

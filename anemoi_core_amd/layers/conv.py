@@ -32,6 +32,26 @@ def _derived(owner, tag: str, params: list, builder):
     return val
 
 
+# GraphConv's scatter-sum inside the node chain launch that consumes it (ops.gnn_node_chain(seg_ptr=...)); 0: its own launch
+_NODE_SEGSUM = os.environ.get("ANEMOI_GNN_NODE_SEGSUM", "1") == "1"
+
+
+class DeferredAggregate:
+    """``scatter(edges_new, dst, "sum")`` not yet taken: the dst-sorted edge rows and the CSC column pointer, handed to the node chain
+    kernel, which sums a panel's in-edge rows while it loads the panel (same arithmetic as ops.segment_sum_rows)."""
+    __slots__ = ("rows", "ptr")
+
+    def __init__(self, rows: Tensor, ptr: Tensor):
+        self.rows, self.ptr = rows, ptr
+
+    @property
+    def dtype(self):
+        return self.rows.dtype
+
+    def materialize(self) -> Tensor:
+        return ops.segment_sum_rows(self.rows, self.ptr)
+
+
 def mlp_chain_ok(m: MLP, k_in: int, x: Tensor) -> bool:
     """A GraphConv-style MLP the row-resident chain kernels take: inference, 16-bit, 512 channels, Linear-GELU-Linear-GELU-Linear with
     a plain affine LayerNorm (mlp_extra_layers = 0, mlp_implementation = "mlp")."""
@@ -53,6 +73,8 @@ def node_mlp_chain(m: MLP, x: Tensor, agg: Tensor, *, wt: Optional[Tensor] = Non
     wc = _derived(m, "nc", [m.mlp[4].weight], lambda: P(m.mlp[4].weight))
     ln = m.layer_norm
     kw = dict(wt=wt, t_out_features=t_out_features) if wt is not None else {}
+    if isinstance(agg, DeferredAggregate):
+        agg, kw["seg_ptr"] = agg.rows, agg.ptr
     return ops.gnn_node_chain(x, agg, wa, m.mlp[0].bias, wb, m.mlp[2].bias, wc, m.mlp[4].bias, ln.weight, ln.bias, ln.eps, **kw)
 
 
@@ -123,7 +145,8 @@ class GraphConv(nn.Module):
         return (edge_attr.dim() == 2 and edge_attr.dtype == x_dst.dtype and edge_attr.shape[1] == ops.CHAIN_CHANNELS
                 and mlp_chain_ok(self.edge_mlp, 3 * ops.CHAIN_CHANNELS, x_dst) and not (torch.is_grad_enabled() and edge_attr.requires_grad))
 
-    def forward(self, x, edge_attr: Tensor, edge_index: Tensor, size=None, edges_are_dst_sorted: bool = True, p: Optional[Tensor] = None):
+    def forward(self, x, edge_attr: Tensor, edge_index: Tensor, size=None, edges_are_dst_sorted: bool = True, p: Optional[Tensor] = None,
+                defer_sum: bool = False):
         x_src, x_dst = (x, x) if isinstance(x, Tensor) else x
         size = (x_src.shape[0], x_dst.shape[0]) if size is None else size
         csc = get_csc(edge_index, size, edges_are_dst_sorted)
@@ -150,6 +173,8 @@ class GraphConv(nn.Module):
             ln = em.layer_norm
             edges_new = ops.gnn_edge_chain(edge_attr, p_dst, csc.dst, p_src, csc.row, w0, lin0.bias, w1, em.mlp[2].bias, w2, em.mlp[4].bias,
                                            ln.weight, ln.bias, ln.eps)
+            if defer_sum and _NODE_SEGSUM and csc.colptr.dtype == torch.int32:  # the caller's node chain takes the scatter-sum with it
+                return DeferredAggregate(edges_new, csc.colptr), edges_new
             return ops.segment_sum_rows(edges_new, csc.colptr), edges_new
         if gated:  # first layer = gating(gate_proj(cat)) * value_proj(cat): the same gather-add GEMM on the fused [gate; value] weight
             w, bias0 = lin0.fused_weights()

@@ -878,7 +878,8 @@ def gnn_mlp_chain(x: Tensor, w0: Tensor, b0: Tensor, w1: Tensor, b1: Tensor, w2:
 
 
 def gnn_node_chain(x: Tensor, agg: Tensor, wa: Tensor, ba: Tensor, wb: Tensor, bb: Tensor, wc: Tensor, bc: Tensor, ln_w: Tensor,
-                   ln_b: Optional[Tensor], eps: float, wt: Optional[Tensor] = None, bt: Optional[Tensor] = None, t_out_features: int = 0):
+                   ln_b: Optional[Tensor], eps: float, wt: Optional[Tensor] = None, bt: Optional[Tensor] = None, t_out_features: int = 0,
+                   seg_ptr: Optional[Tensor] = None):
     """A GraphConv block's node MLP + LayerNorm + skip in ONE launch (anemoi_gnn_node_chain_fwd):
     ``x_out = LayerNorm(Wc gelu(Wb gelu(Wa [x | agg] + ba) + bb) + bc) + x`` and optionally ``t_out = x_out Wt^T [+ bt]``.
     Weights are fragment-major images (``pack_weight_frag``).  Returns ``x_out`` or ``(x_out, t_out)``.  Inference only."""
@@ -887,7 +888,11 @@ def gnn_node_chain(x: Tensor, agg: Tensor, wa: Tensor, ba: Tensor, wb: Tensor, b
     dt = x.dtype
     if D != CHAIN_CHANNELS or dt not in (torch.bfloat16, torch.float16):
         raise NotImplementedError(f"gnn_node_chain: {D} channels / {dt} (built for {CHAIN_CHANNELS} channels, 16-bit dtypes)")
-    if tuple(agg.shape) != (N, D):
+    if seg_ptr is not None:  # ``agg`` = the dst-sorted EDGE rows [M, 512]; the kernel forms their segmented sums (segment_sum_rows' arithmetic)
+        _dev(seg_ptr)
+        if agg.dim() != 2 or agg.shape[1] != D or seg_ptr.dtype != torch.int32 or tuple(seg_ptr.shape) != (N + 1,) or not seg_ptr.is_contiguous():
+            raise ValueError("gnn_node_chain: with seg_ptr, agg must be the [M, 512] edge rows and seg_ptr contiguous int32 [N + 1]")
+    elif tuple(agg.shape) != (N, D):
         raise ValueError("gnn_node_chain: x and agg must have the same [N, 512] shape")
     for name, w, numel in (("wa", wa, 2 * D * D), ("wb", wb, D * D), ("wc", wc, D * D)):
         if w.dim() != 1 or w.numel() != numel or w.dtype != dt or not w.is_contiguous():
@@ -898,10 +903,14 @@ def gnn_node_chain(x: Tensor, agg: Tensor, wa: Tensor, ba: Tensor, wb: Tensor, b
     tf = t_out_features if wt is not None else 0
     t_out = torch.empty((N, tf), dtype=dt, device=x.device) if tf else None
     (xp, ldx), (ap, lda) = _rows(x, "x", dt), _rows(agg, "agg", dt)
-    _lib.check(_lib.load().anemoi_gnn_node_chain_fwd(xp, ldx, ap, lda, wa.data_ptr(), _vec(ba, "ba", D, dt), wb.data_ptr(), _vec(bb, "bb", D, dt), wc.data_ptr(),
-                                                     _vec(bc, "bc", D, dt), _vec(ln_w, "ln_w", D, dt), _vec(ln_b, "ln_b", D, dt), float(eps), x_out.data_ptr(), D,
-                                                     0 if wt is None else wt.data_ptr(), _vec(bt, "bt", tf, dt) if (bt is not None and tf) else 0, tf,
-                                                     0 if t_out is None else t_out.data_ptr(), tf, N, D, _dt(x), _stream()), "gnn_node_chain_fwd")
+    tail = (wa.data_ptr(), _vec(ba, "ba", D, dt), wb.data_ptr(), _vec(bb, "bb", D, dt), wc.data_ptr(),
+            _vec(bc, "bc", D, dt), _vec(ln_w, "ln_w", D, dt), _vec(ln_b, "ln_b", D, dt), float(eps), x_out.data_ptr(), D,
+            0 if wt is None else wt.data_ptr(), _vec(bt, "bt", tf, dt) if (bt is not None and tf) else 0, tf,
+            0 if t_out is None else t_out.data_ptr(), tf, N, D, _dt(x), _stream())
+    if seg_ptr is not None:
+        _lib.check(_lib.load().anemoi_gnn_node_chain_segsum_fwd(xp, ldx, ap, lda, seg_ptr.data_ptr(), *tail), "gnn_node_chain_segsum_fwd")
+    else:
+        _lib.check(_lib.load().anemoi_gnn_node_chain_fwd(xp, ldx, ap, lda, *tail), "gnn_node_chain_fwd")
     return x_out if t_out is None else (x_out, t_out)
 
 

@@ -266,7 +266,8 @@ def profile_forward(step, dtype, host_ms: float = 12.0):
         x = a_[0]
         N, D = x.shape
         T = kw.get("t_out_features", 0) if kw.get("wt") is not None else 0
-        return "gnn_node_chain_kernel", 2.0 * N * (4 * D * D + D * T), es * (3 * N * D + N * T + 4 * D * D + D * T)
+        rows_in = a_[1].shape[0]  # the aggregated table [N, D] or, with the scatter-sum inside the launch (seg_ptr), the edge rows [M, D]
+        return "gnn_node_chain_kernel", 2.0 * N * (4 * D * D + D * T), es * (2 * N * D + rows_in * D + N * T + 4 * D * D + D * T)
 
     def segrows_work(res_, a_, kw):
         x, ptr = a_[0], a_[1]

@@ -427,6 +427,16 @@ int anemoi_gnn_node_chain_fwd(const void* x, int64_t ld_x, const void* agg, int6
                               const void* bb, const void* wc, const void* bc, const void* ln_w, const void* ln_b, float eps, void* x_out,
                               int64_t ld_o, const void* wt, const void* bt, int32_t t_out_features, void* t_out, int64_t ld_t, int32_t n_rows,
                               int32_t channels, anemoi_dtype_t dtype, void* stream);
+/* The same launch with GraphConv's scatter-sum inside it (layers/conv.py:81: `out = scatter(edge_attr_new, edge_index[1], reduce="sum")`):
+ * instead of an aggregated table the kernel takes the EDGE rows edge_rows [M, 512] (sorted by destination) and seg_ptr [n_rows + 1] (the CSC
+ * column pointer) and forms agg[n] = sum of the rows [seg_ptr[n], seg_ptr[n+1]) in fp32, in edge order, rounded once - the arithmetic of
+ * anemoi_segment_sum_rows - while it loads the panel.  Saves that launch, the [N, 512] table it writes and its read-back. */
+int anemoi_gnn_node_chain_segsum_fwd(const void* x, int64_t ld_x, const void* edge_rows, int64_t ld_e, const int32_t* seg_ptr, const void* wa,
+                                     const void* ba, const void* wb, const void* bb, const void* wc, const void* bc, const void* ln_w,
+                                     const void* ln_b, float eps, void* x_out, int64_t ld_o, const void* wt, const void* bt,
+                                     int32_t t_out_features, void* t_out, int64_t ld_t, int32_t n_rows, int32_t channels,
+                                     anemoi_dtype_t dtype, void* stream);
+
 
 #ifdef __cplusplus
 }

@@ -286,6 +286,38 @@ def test_gnn_node_chain_vs_fp32_restatement(dtype, N, trailing):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,deg,trailing", [(9, 3, True), (1000, 8, False), (10242, 8, True), (5000, 40, False)])
+def test_gnn_node_chain_with_the_scatter_sum_inside(dtype, N, deg, trailing):
+    """ops.gnn_node_chain(seg_ptr=...): the kernel sums a panel's in-edge rows itself (fp32, edge order, one rounding - the arithmetic of
+    ops.segment_sum_rows) - bit-equal to the launch fed with the materialised segment sums, incl. destinations without edges and degrees
+    beyond one batch of loads."""
+    from anemoi_core_amd import ops
+
+    gen = torch.Generator().manual_seed(N + deg)
+    p = _gnn_params(gen, dtype)
+    x = torch.randn(N, D, generator=gen).to(dtype)
+    degs = torch.randint(0, 2 * deg + 1, (N,), generator=gen)
+    degs[::7] = 0
+    ptr = torch.zeros(N + 1, dtype=torch.int32)
+    ptr[1:] = degs.cumsum(0).to(torch.int32)
+    M = int(ptr[-1])
+    e = torch.randn(M, D, generator=gen).to(dtype)
+    d = lambda t: t.to(DEV)  # noqa: E731
+    P = ops.pack_weight_frag
+    kw = dict(wt=P(d(p["wt"])), t_out_features=2 * D) if trailing else {}
+    w = (P(d(p["wa"])), d(p["ba"]), P(d(p["w1"])), d(p["b1"]), P(d(p["w2"])), d(p["b2"]), d(p["g"]), d(p["be"]), 1e-5)
+    agg = ops.segment_sum_rows(d(e), d(ptr))
+    want = ops.gnn_node_chain(d(x), agg, *w, **kw)
+    got = ops.gnn_node_chain(d(x), d(e), *w, seg_ptr=d(ptr), **kw)
+    if trailing:
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    else:
+        assert torch.equal(got, want)
+    ref = torch.zeros(N, D).index_add_(0, torch.repeat_interleave(torch.arange(N), degs), e.float())
+    assert float((agg.float().cpu() - ref).abs().max()) <= 2e-2 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("N,K,with_res", [(1500, 11, False), (5000, 100, True), (40320, 200, False), (81840, 3, False), (2049, 512, True), (3000, 384, False)])
 def test_embedding_mlp_chain(dtype, N, K, with_res):
     """An embedding MLP (Linear-GELU-Linear-GELU-Linear-LayerNorm into 512 channels, raw input width K) through MLP.forward: the
