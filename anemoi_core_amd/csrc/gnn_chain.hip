@@ -325,32 +325,54 @@ __global__ __launch_bounds__(512, 1) void gnn_node_chain_kernel(NodeChainArgs a)
     const int r0 = t * a.rows_per_tile;
     const int nr = min(a.rows_per_tile, a.n_rows - r0);
     const T* const base = (const T*)a.agg + lane * 8;
-#pragma unroll 1
+    // the segment bounds of this wave's six rows in ONE vector load (lane 2 i + w holds seg_ptr[row_i + w]), broadcast with v_readlane;
+    // the first 8 edge rows of row i + 1 are requested before row i is summed (the loop is a chain of memory round trips otherwise:
+    // measured 11 us per panel with one row at a time, bounds by scalar loads)
+    int pv = 0;
+    if (lane < 12) pv = a.seg_ptr[r0 + min(wave + 8 * (lane >> 1), nr - 1) + (lane & 1)];
+    u32x4 buf[2][8];
+    auto issue = [&](int beg, int end, u32x4 (&b)[8]) {
+      if (end > beg) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) b[u] = *reinterpret_cast<const u32x4*>(base + (int64_t)min(beg + u, end - 1) * a.ld_a);
+      }
+    };
+    auto add_row = [&](const u32x4& r, float (&s8)[8]) {
+      float lo[4], hi[4];
+      unpack4<T>(u32x2{r[0], r[1]}, lo);
+      unpack4<T>(u32x2{r[2], r[3]}, hi);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        s8[c] += lo[c];
+        s8[4 + c] += hi[c];
+      }
+    };
+    int beg[6], end[6];
+#pragma unroll
     for (int i = 0; i < 6; ++i) {
+      beg[i] = __builtin_amdgcn_readlane(pv, 2 * i);
+      end[i] = (wave + 8 * i < nr) ? __builtin_amdgcn_readlane(pv, 2 * i + 1) : beg[i];
+    }
+    issue(beg[0], end[0], buf[0]);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      if (i + 1 < 6) issue(beg[i + 1], end[i + 1], buf[(i + 1) & 1]);
       const int row = wave + 8 * i;
       float s8[8];
 #pragma unroll
       for (int c = 0; c < 8; ++c) s8[c] = 0.f;
-      if (row < nr) {
-        const int beg = __builtin_amdgcn_readfirstlane(a.seg_ptr[r0 + row]), end = __builtin_amdgcn_readfirstlane(a.seg_ptr[r0 + row + 1]);
+      const int n = end[i] - beg[i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (u < n) add_row(buf[i & 1][u], s8);
 #pragma unroll 1
-        for (int e = beg; e < end; e += 4) {
-          u32x4 r[4];
+      for (int e = beg[i] + 8; e < end[i]; e += 4) {  // (degrees beyond 8: the mappers' hubs)
+        u32x4 r[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) r[u] = *reinterpret_cast<const u32x4*>(base + (int64_t)min(e + u, end - 1) * a.ld_a);
+        for (int u = 0; u < 4; ++u) r[u] = *reinterpret_cast<const u32x4*>(base + (int64_t)min(e + u, end[i] - 1) * a.ld_a);
 #pragma unroll
-          for (int u = 0; u < 4; ++u)
-            if (e + u < end) {
-              float lo[4], hi[4];
-              unpack4<T>(u32x2{r[u][0], r[u][1]}, lo);
-              unpack4<T>(u32x2{r[u][2], r[u][3]}, hi);
-#pragma unroll
-              for (int c = 0; c < 4; ++c) {
-                s8[c] += lo[c];
-                s8[4 + c] += hi[c];
-              }
-            }
-        }
+        for (int u = 0; u < 4; ++u)
+          if (e + u < end[i]) add_row(r[u], s8);
       }
       float lo[4] = {s8[0], s8[1], s8[2], s8[3]}, hi[4] = {s8[4], s8[5], s8[6], s8[7]};
       const u32x2 pl = pack4<T>(lo), ph = pack4<T>(hi);
