@@ -920,10 +920,16 @@ def main():
                                       "same 48 back to back, same backed-up queue: an upper bound); `rocprof_cross_check` = the family's "
                                       "duration in the committed rocprofv3 --kernel-trace summary of the timed replays (profiles/)")
             res["roofline"]["rocprof_cross_check"] = rocprof_cross_check(args.config, dom, fam[dom], "mfma" if fam[dom]["flops"] else "hbm")
-            gs = "gt_attn_fused_edge_fwd_kernel" if args.kind == "gt" else ("segment_sum_rows_kernel" if "segment_sum_rows_kernel" in fam else "edge_ln_res_segsum_kernel")
+            # the gather / scatter side of the path: the attention (GraphTransformer); for GraphConv the scatter-sum, which since round 4
+            # runs INSIDE the node chain launch (its bytes: the edge rows in, x in / out, the projection out, the weights once)
+            gs = "gt_attn_fused_edge_fwd_kernel" if args.kind == "gt" else next(
+                (k for k in ("segment_sum_rows_kernel", "edge_ln_res_segsum_kernel", "gnn_node_chain_kernel") if k in fam), None)
             if gs in fam:
                 res["roofline"]["gather_scatter"] = roof(gs, "hbm")
                 res["roofline"]["gather_scatter"]["rocprof_cross_check"] = rocprof_cross_check(args.config, gs, fam[gs], "hbm")
+                if gs == "gnn_node_chain_kernel":
+                    res["roofline"]["gather_scatter"]["note"] = ("GraphConv's scatter-sum inside the node MLP launch: a GEMM chain whose panel load is "
+                                                                  "the segmented sum; the HBM figure prices the whole launch against its bytes")
         if world == 1 and not args.no_cpu_baseline:
             cfg = {"num_heads": args.heads, "num_layers": args.layers, "num_channels": args.channels, "kind": args.kind}
             try:
