@@ -12,22 +12,10 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-VARIANTS = {"bigtile-everywhere": {"ANEMOI_GEMM_BIG": "1"}, "ring-lockstep": {"ANEMOI_GEMM_BIG": "0", "ANEMOI_GEMM_PP": "0"},
-            "ring-pingpong": {"ANEMOI_GEMM_BIG": "0", "ANEMOI_GEMM_PP": "1"}, "small-m-two-wave-tiles": {"ANEMOI_GEMM_SPLITWAVE": "0"}}
-
-
-def test_linear_suite_with_forced_kernel_variants():
-    """The four child processes run side by side on the one GPU (each is mostly interpreter start-up and small launches)."""
-    cmd = [sys.executable, "-m", "pytest", os.path.join(REPO, "tests", "test_kernels_gpu.py"), "-x", "-q", "-k", "linear", "-p", "no:cacheprovider"]
-    procs = {name: subprocess.Popen(cmd, cwd=REPO, env={**os.environ, **env}, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-             for name, env in VARIANTS.items()}
-    failed = {}
-    for name, pr in procs.items():
-        try:
-            out, _ = pr.communicate(timeout=900)
-        except subprocess.TimeoutExpired:
-            pr.kill()
-            out = "timed out"
-        if pr.returncode != 0:
-            failed[name] = out[-3000:]
-    assert not failed, failed
+@pytest.mark.parametrize("env", [{"ANEMOI_GEMM_BIG": "1"}, {"ANEMOI_GEMM_BIG": "0", "ANEMOI_GEMM_PP": "0"}, {"ANEMOI_GEMM_BIG": "0", "ANEMOI_GEMM_PP": "1"},
+                                 {"ANEMOI_GEMM_SPLITWAVE": "0"}],
+                         ids=["bigtile-everywhere", "ring-lockstep", "ring-pingpong", "small-m-two-wave-tiles"])
+def test_linear_suite_with_forced_kernel_variant(env):
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(REPO, "tests", "test_kernels_gpu.py"), "-x", "-q", "-k", "linear",
+                        "-p", "no:cacheprovider"], cwd=REPO, env={**os.environ, **env}, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
