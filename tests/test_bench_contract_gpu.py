@@ -12,7 +12,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_default_bench_line_contract():
-    env = dict(os.environ, ANEMOI_BENCH_CPU_BUDGET_S="25")
+    env = dict(os.environ, ANEMOI_BENCH_CPU_BUDGET_S="15")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "ANEMOI_BENCH_TRANSPORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "5", "--warmup", "2"], env=env, capture_output=True, text=True,
