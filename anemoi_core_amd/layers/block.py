@@ -44,10 +44,14 @@ _LN_FOLD_MIN_ROWS = int(os.environ.get("ANEMOI_LN_FOLD_MIN_ROWS", "512"))
 # as ONE launch that keeps a 48-row panel in LDS and streams the weights (ops.gt_layer_chain, csrc/gt_chain.hip) instead of four
 # GEMM launches with the LayerNorm fold between them.  Built, parity-green and MEASURED: 105-115 us per launch against 108 us for
 # the four launches it replaces, O96 forward 3.01 against 2.955 ms (at 40 rows per CU every CU streams all
-# 6.5 MB of a layer's weights through its own L1, 106 k cycles at 64 B/clk before any epilogue) - so it is OPT-IN
-# (ANEMOI_LAYER_CHAIN=1), kept under test with its in-kernel timeline (tools/chain_timeline.py).
-_LAYER_CHAIN = os.environ.get("ANEMOI_LAYER_CHAIN", "0") == "1"
-_LAYER_CHAIN_MIN_ROWS = int(os.environ.get("ANEMOI_LAYER_CHAIN_MIN_ROWS", "0"))
+# 6.5 MB of a layer's weights through its own L1, 106 k cycles at 64 B/clk before any epilogue) - so at the hidden meshes' sizes it
+# is OPT-IN (ANEMOI_LAYER_CHAIN=1: every eligible block), kept under test with its in-kernel timeline (tools/chain_timeline.py).
+# Where it wins is a block with MANY rows - the N320 decoder's 542 080 destination rows: the [N, 2048] hidden activations (2.2 GB
+# written and read back by the two MLP launches) never exist; N320 forward 15.25 -> 14.98 ms on the same box (O96's 40 320-row
+# decoder: 3.02 -> 3.04 ms, so the gate stays well above that).  Default: blocks of >= 100 000 rows; ANEMOI_LAYER_CHAIN=0: never.
+_chain_env = os.environ.get("ANEMOI_LAYER_CHAIN", "")
+_LAYER_CHAIN = _chain_env != "0"
+_LAYER_CHAIN_MIN_ROWS = int(os.environ.get("ANEMOI_LAYER_CHAIN_MIN_ROWS", "0" if _chain_env == "1" else "100000"))
 
 
 _IDENTITY: dict = {}

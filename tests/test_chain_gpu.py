@@ -194,14 +194,14 @@ def test_model_with_chain_equals_model_without():
     m = model.to(DEV).to(torch.bfloat16)
     xb = x.to(DEV).to(torch.bfloat16)
     outs = {}
-    saved = B._LAYER_CHAIN
+    saved = (B._LAYER_CHAIN, B._LAYER_CHAIN_MIN_ROWS)
     for flag in (True, False):
-        B._LAYER_CHAIN = flag
+        B._LAYER_CHAIN, B._LAYER_CHAIN_MIN_ROWS = flag, 0  # (by default only blocks of >= 100 000 rows take the chain)
         try:
             with torch.no_grad():
                 outs[flag] = m({"data": xb})["data"].float().cpu()
         finally:
-            B._LAYER_CHAIN = saved
+            B._LAYER_CHAIN, B._LAYER_CHAIN_MIN_ROWS = saved
     a, b = outs[True], outs[False]
     scale = float(want.abs().max())
     assert float((a - b).abs().max()) <= 3e-2 * scale and float((a - b).abs().mean()) <= 4e-3 * scale, (float((a - b).abs().max()), scale)
