@@ -8,7 +8,10 @@
 //      the LayerNorm half of edge_ln_res_segsum: 251 us per processor layer at M = 81 840, of which the GEMMs' intermediates are
 //      4 x 84 MB of HBM round trips.  Here only e is read and e' written; the segment sum over e' is anemoi_segment_sum_rows.
 //  node chain   x' = LayerNorm(W_c gelu(W_b gelu(W_a [x | agg] + b_a) + b_b) + b_c) + x, and optionally the NEXT block's stacked
-//      node-level projection [x' W_i'^T | x' W_j'^T] (the gather operands of its edge chain).
+//      node-level projection [x' W_i'^T | x' W_j'^T] (the gather operands of its edge chain).  agg is either a table or - segsum entry
+//      point - formed in the launch from the dst-sorted edge rows e' (GraphConv's scatter-sum, layers/conv.py:81).
+//  MLP chain    the edge chain's MLP instantiation: an embedding MLP (Linear-GELU-Linear-GELU-Linear-LayerNorm into 512 channels) of
+//      the mappers / first processor block on a zero-padded input of 128..512 columns (layers/mlp.py:29-100).
 //
 // Why the row-resident form pays HERE when it did not for the GraphTransformer block: a panel needs 1.5 MB
 // (edge chain) / 2.5-3.5 MB (node chain) of weights through its CU's L1 instead of 6.5 MB, against launches whose K = N = 512
