@@ -584,6 +584,8 @@ def main():
                          "report a number measured on another rank count")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (ROCm) device; there is no CPU fallback for the product path")
+    if world > 1:  # the ranks of a node share its cores: the set-up's CPU-side index work (partitions, halo plans) must not run world x cores threads
+        torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))
     # Wire of the N > 1 run (ANEMOI_BENCH_TRANSPORT):
     #   unset  = the product: RCCL process group (backend "nccl") for set-up and as the fallback, the device-initiated hipIpc
     #            exchange (anemoi_core_amd/distributed/peer.py) as the data path - one hipGraph per rank; verified against

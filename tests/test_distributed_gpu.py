@@ -28,6 +28,9 @@ def _spawn(fn, world, *args):
 
 def _entry(rank, world, init_file, fn, tmp, args):
     sys.path.insert(0, REPO)
+    # the `world` processes of a case share the box's cores: without a cap every process runs its CPU-side index work (partitions, halo
+    # plans, CSCs of the full graph) on ALL cores at once
+    torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
     try:
