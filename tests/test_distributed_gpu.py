@@ -478,8 +478,8 @@ def test_peer_wire_soak_random_skew_every_replay():
     """replays at world 4 with random per-rank skew in front of every exchange and every replay, outputs
     compared after every replay; the exchange diagnostics of csrc/peer.hip count every exchange and report no time-out.  Four
     processes time-slice the ONE GPU of the test box, so a replay takes ~1.4 s there (every wait needs the peer's time slice): the
-    suite runs 30 replays; ANEMOI_SOAK_REPLAYS=500 is the full soak (run once per round: ~12 min on the one-GPU box, seconds on a node)."""
-    replays = int(os.environ.get("ANEMOI_SOAK_REPLAYS", "30"))
+    suite runs 60 replays; ANEMOI_SOAK_REPLAYS=500 is the full soak (run once per round: ~12 min on the one-GPU box, seconds on a node)."""
+    replays = int(os.environ.get("ANEMOI_SOAK_REPLAYS", "60"))
     for o in _spawn(_peer_soak_worker, 4, replays):
         assert o["bad"] == [], o["bad"][:10]
         assert o["stats"]["timeout_peer"] is None
