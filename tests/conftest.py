@@ -10,6 +10,10 @@ if REPO not in sys.path:
 
 GOLDEN = os.path.join(REPO, "tests", "golden")
 
+# The oracle's CPU forwards are fastest at a few dozen threads (bench.py's sweep picks 32-64 of the GPU box's 256 logical CPUs); torch's
+# default - every logical CPU - makes the full-size parity tests slower, not faster.  ANEMOI_TEST_THREADS overrides.
+torch.set_num_threads(max(1, min(int(os.environ.get("ANEMOI_TEST_THREADS", "48")), os.cpu_count() or 1)))
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
