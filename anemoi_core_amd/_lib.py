@@ -74,6 +74,7 @@ SIGNATURES = {
     "anemoi_gt_chain_fwd": ([_p, C.c_int, _p], C.c_int),
     "anemoi_gt_chain_rows_per_tile": ([_i32], C.c_int),
     "anemoi_gnn_edge_chain_fwd": ([_p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _i64, _i32, _i32, C.c_int, _p], C.c_int),
+    "anemoi_gnn_edge_chain_timeline": ([_p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _i64, _i32, _p, _p], C.c_int),
     "anemoi_gnn_mlp_chain_fwd": ([_p, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _i64, _p, _i64, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_gnn_node_chain_segsum_fwd": ([_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _i64, _p, _p, _i32, _p, _i64, _i32, _i32,
                                           C.c_int, _p], C.c_int),

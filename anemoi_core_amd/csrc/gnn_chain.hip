@@ -34,7 +34,9 @@ struct EdgeChainArgs {
   // the MLP instantiation (no gathered rows): y = LayerNorm(W_2 gelu(W_1 gelu(W_0 x + b_0) + b_1) + b_2) [+ res]
   const void* res = nullptr; int64_t ld_res = 0;  // optional residual rows (the edge chain's residual is e itself)
   int k0_groups = 4;                              // width of x / K of the first GEMM in units of 128 columns (w0: fragment-major [512, 128 k0_groups])
+  unsigned long long* timeline = nullptr;         // developer aid (TL instantiation): [workgroups][8 waves][kETlSlots] shader-clock stamps
 };
+constexpr int kETlSlots = 48;  // entry + 8 stamps per panel of a workgroup's first 5 panels (tools/edge_chain_timeline.py)
 
 // Edge panels are 64 rows (4 MFMA row bands): the same weight stream serves a third more rows than a 48-row panel would (81 840
 // edges = 256 CUs x 5 panels of 64: five passes over the 1.5 MB of weights per CU instead of seven), and the two hidden layers
@@ -47,7 +49,7 @@ constexpr int kEdgeSmem = kERedOff + kERows * 8 * 2 * 4;
 // MLP = true: the same chain without the gathered rows, the residual optional and the first GEMM's K a multiple of 128 up to 512 -
 // the embedding MLPs of the GNN mappers / processor (reference layers/mlp.py:29-100 as built at layers/mapper.py:640-700:
 // Linear -> GELU -> Linear -> GELU -> Linear -> LayerNorm over [rows, in] -> 512).
-template <typename T, bool MLP = false>
+template <typename T, bool MLP = false, bool TL = false>
 __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const bufE = smem;          // e panel: operand of GEMM 1, residual of the LayerNorm
@@ -64,9 +66,20 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
   const char* const w1 = a.w1 + (int64_t)wave * kSlab;
   const char* const w2 = a.w2 + (int64_t)wave * kSlab;
   const u32x4 zero4 = u32x4{0u, 0u, 0u, 0u};
+  [[maybe_unused]] int tl_n = 0;
+  auto stamp = [&]() {  // (to LDS: a global store per stamp would sit in the vmcnt queue of the weight ring)
+    if constexpr (TL) {
+      if (tl_n < kETlSlots) {  // the low 32 bits (wrap: seconds) - one register, or the instrumented build spills around the GEMM segments
+        const unsigned now = (unsigned)__builtin_readcyclecounter();
+        if (lane == 0) reinterpret_cast<unsigned*>(smem + kEdgeSmem)[wave * kETlSlots + tl_n] = now;
+      }
+      ++tl_n;
+    }
+  };
 
   int tile = blockIdx.x;
   if (tile >= a.n_tiles) return;
+  stamp();  // kernel entry
   // The e panel is only the first GEMM's operand (the LayerNorm's residual is re-read from global, L2-hot), so the NEXT panel
   // moves into the free e buffer under the second GEMM - the phase with registers to spare (no gathered rows) - a quarter per
   // group of 4 K-steps: requested at the top of a group, written to LDS at the top of the next (8 registers in flight; the whole
@@ -120,6 +133,7 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
     const int nr = min(a.rows_per_tile, a.n_rows - r0);
     const int next_tile = tile + (int)gridDim.x;
     const bool more = next_tile < a.n_tiles;
+    stamp();  // panel p + 0: the e panel is in LDS (behind the barrier)
     // the gathered node-level rows of this lane's panel rows (index, then 2 x 4 x 8 bytes per row) and the first bias: in flight
     // under the first GEMM
     u32x2 ga[MLP ? 1 : NB][4], gb[MLP ? 1 : NB][4], pb[4];
@@ -144,6 +158,7 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
     // ---- h1 = gelu(e W_e^T + g1[dst] + g2[src] + b0) -> bufH
     zero_acc<T, NB>(acc);
     gemm_seg<T, NB>(bufE, lane, bq, w0, w1, loff, acc, NoHook(), nq0);
+    stamp();  // + 1: first GEMM done
     {
       const LaneCtx lc = lane_ctx(lane, wave);
 #pragma unroll
@@ -171,6 +186,7 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
     load_cols<T>((const T*)a.b1, wave, g, pb);
     __builtin_amdgcn_sched_barrier(0);
     lds_barrier();
+    stamp();  // + 2: gather-add + GELU epilogue written, barrier passed
     // ---- h2 = gelu(h1 W_1^T + b1), written over h1 once every wave has read its last fragment of it
     zero_acc<T, NB>(acc);
     if (more) {  // (every wave is behind its last fragment read of the e panel: the E1 barrier)
@@ -183,6 +199,7 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
     } else {
       gemm_seg<T, NB>(bufH, lane, bq, w1, w2, loff, acc);
     }
+    stamp();  // + 3: second GEMM done (and the next panel moved into LDS)
     u32x2 hp[NB][4];
 #pragma unroll
     for (int mi = 0; mi < NB; ++mi)
@@ -217,9 +234,11 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
     }
     __builtin_amdgcn_sched_barrier(0);
     lds_barrier();
+    stamp();  // + 4: GELU epilogue written in place (two barriers)
     // ---- z = h2 W_2^T + b2 (rounded, as the Linear's output is); e' = LayerNorm(z) + e -> global
     zero_acc<T, NB>(acc);
     gemm_seg<T, NB>(bufH, lane, bq, w2, w0, loff, acc);  // (behind it: the next panel's first segment; after the last panel a harmless re-read)
+    stamp();  // + 5: third GEMM done
     {
       const LaneCtx lc = lane_ctx(lane, wave);
       u32x2 er[NB][4];  // this lane's values of the e rows (the residual): in flight under the bias add and the row statistics
@@ -253,6 +272,7 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
         }
       float mean[NB], rstd[NB];
       panel_row_stats<T, NB>(acc, a.ln_eps, red, wave, lc.x, lc.g, mean, rstd);  // (one barrier: behind it no wave reads bufH)
+      stamp();  // + 6: row statistics merged (barrier passed)
       u32x2 pk[NB][4];
 #pragma unroll
       for (int mi = 0; mi < NB; ++mi)
@@ -268,9 +288,16 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
         }
       store_block_via_strip<T, NB>(pk, bufH + wave * (kERows * 128), (T*)a.e_new + (int64_t)r0 * a.ld_o + wave * 64, a.ld_o, nr, lane, wave);
     }
+    stamp();  // + 7: LayerNorm + residual applied, rows stored through the strips
     if (!more) break;
     tile = next_tile;
     lds_barrier();  // every wave has emptied its strip (bufH is the next panel's h1) and written its part of the next e panel
+  }
+  if constexpr (TL) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane < kETlSlots)
+      a.timeline[((size_t)blockIdx.x * 8 + wave) * kETlSlots + lane] =
+          lane < tl_n ? (unsigned long long)reinterpret_cast<const unsigned*>(smem + kEdgeSmem)[wave * kETlSlots + lane] : 0ull;
   }
 }
 
@@ -577,6 +604,25 @@ extern "C" int anemoi_gnn_edge_chain_fwd(const void* e, int64_t ld_e, const void
     hipLaunchKernelGGL((gnn_edge_chain_kernel<f16_t>), dim3(grid), dim3(512), kEdgeSmem, st, a);
   }
   return check_launch("gnn_edge_chain_kernel");
+}
+
+// Developer aid: the same launch through the instrumented instantiation (shader-clock stamps at the phase boundaries of every panel,
+// all waves, a workgroup's first five panels) - tools/edge_chain_timeline.py.  timeline: [min(256, panels)][8][48] uint64.
+extern "C" int anemoi_gnn_edge_chain_timeline(const void* e, int64_t ld_e, const void* g1, int64_t ld_g1, const int32_t* idx1, const void* g2,
+                                              int64_t ld_g2, const int32_t* idx2, const void* w0, const void* b0, const void* w1, const void* b1,
+                                              const void* w2, const void* b2, const void* ln_w, const void* ln_b, float eps, void* e_new,
+                                              int64_t ld_o, int32_t n_rows, unsigned long long* timeline, void* stream) {
+  ANEMOI_REQUIRE(n_rows > 0 && e && g1 && idx1 && g2 && idx2 && w0 && b0 && w1 && b1 && w2 && b2 && ln_w && e_new && timeline, "gnn_edge_chain_timeline: null operand");
+  EdgeChainArgs a{e, ld_e, g1, ld_g1, idx1, g2, ld_g2, idx2, (const char*)w0, b0, (const char*)w1, b1, (const char*)w2, b2, ln_w, ln_b, eps, e_new, ld_o,
+                  n_rows, chain_rows_per_tile(n_rows, kERows), 0, 0};
+  a.timeline = timeline;
+  a.n_tiles = (n_rows + a.rows_per_tile - 1) / a.rows_per_tile;
+  const int grid = a.n_tiles < 256 ? a.n_tiles : 256;
+  constexpr int smem = kEdgeSmem + 8 * kETlSlots * 8;
+  static PerDeviceOnce once;
+  once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gnn_edge_chain_kernel<bf16_t, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem); });
+  hipLaunchKernelGGL((gnn_edge_chain_kernel<bf16_t, false, true>), dim3(grid), dim3(512), smem, as_stream(stream), a);
+  return check_launch("gnn_edge_chain_kernel<timeline>");
 }
 
 extern "C" int anemoi_gnn_mlp_chain_fwd(const void* x, int64_t ld_x, int32_t in_features, const void* w0, const void* b0, const void* w1, const void* b1,

@@ -408,6 +408,14 @@ int anemoi_gnn_edge_chain_fwd(const void* e, int64_t ld_e, const void* g1, int64
                               const int32_t* idx2, const void* w0, const void* b0, const void* w1, const void* b1, const void* w2, const void* b2,
                               const void* ln_w, const void* ln_b, float eps, void* e_new, int64_t ld_o, int32_t n_rows, int32_t channels,
                               anemoi_dtype_t dtype, void* stream);
+/* Developer aid (tools/edge_chain_timeline.py): anemoi_gnn_edge_chain_fwd (bf16) through an instrumented instantiation that stamps the
+ * shader clock at the phase boundaries of every panel - all 8 waves, a workgroup's first five panels.
+ * timeline: uint64 [min(256, ceil(n_rows / 64))][8][48], slot 0 = kernel entry, then 8 slots per panel. */
+int anemoi_gnn_edge_chain_timeline(const void* e, int64_t ld_e, const void* g1, int64_t ld_g1, const int32_t* idx1, const void* g2,
+                                   int64_t ld_g2, const int32_t* idx2, const void* w0, const void* b0, const void* w1, const void* b1,
+                                   const void* w2, const void* b2, const void* ln_w, const void* ln_b, float eps, void* e_new,
+                                   int64_t ld_o, int32_t n_rows, unsigned long long* timeline, void* stream);
+
 /* An embedding MLP of the GNN mappers / processor as ONE launch (the edge chain without gathered rows):
  *   out = LayerNorm(W_2 gelu(W_1 gelu(W_0 x + b_0) + b_1) + b_2) [+ res]
  * Replaces: MLP.forward for `emb_edges` / `emb_nodes_src` / `emb_nodes_dst` (layers/mlp.py:29-100 as built at
