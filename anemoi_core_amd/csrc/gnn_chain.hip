@@ -134,21 +134,20 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
     const int next_tile = tile + (int)gridDim.x;
     const bool more = next_tile < a.n_tiles;
     stamp();  // panel p + 0: the e panel is in LDS (behind the barrier)
-    // the gathered node-level rows of this lane's panel rows (index, then 2 x 4 x 8 bytes per row) and the first bias: in flight
-    // under the first GEMM
+    // The gathered node-level rows of this lane's panel rows (2 x 4 x 8 bytes per row).  Loads retire in order, so every weight-ring wait
+    // behind a gather waits for the gather too: with indices and rows requested in front of the GEMM, its steps 4.. stood behind two
+    // dependent round trips of scattered 8-byte loads (in-kernel timeline: the first GEMM 10.4 us, the other two 6.6).  Now: the indices
+    // at the panel's start, the rows behind the GEMM's 12th K-step - the ring loads issued after them are the NEXT segment's, first
+    // consumed behind the epilogue that consumes the rows anyway.
     u32x2 ga[MLP ? 1 : NB][4], gb[MLP ? 1 : NB][4], pb[4];
+    [[maybe_unused]] int i1[NB], i2[NB];
     if constexpr (!MLP) {
       const LaneCtx lc = lane_ctx(lane, wave);
 #pragma unroll
       for (int mi = 0; mi < NB; ++mi) {
         const int m = r0 + min(mi * 16 + lc.x, nr - 1);
-        const T* r1 = (const T*)a.g1 + (int64_t)a.idx1[m] * a.ld_g1 + wave * 64 + lc.g * 4;
-        const T* r2 = (const T*)a.g2 + (int64_t)a.idx2[m] * a.ld_g2 + wave * 64 + lc.g * 4;
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-          ga[mi][ni] = *reinterpret_cast<const u32x2*>(r1 + ni * 16);
-          gb[mi][ni] = *reinterpret_cast<const u32x2*>(r2 + ni * 16);
-        }
+        i1[mi] = a.idx1[m];
+        i2[mi] = a.idx2[m];
       }
     }
     load_cols<T>((const T*)a.b0, wave, g, pb);
@@ -157,7 +156,27 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
     f32x4 acc[NB][4];
     // ---- h1 = gelu(e W_e^T + g1[dst] + g2[src] + b0) -> bufH
     zero_acc<T, NB>(acc);
-    gemm_seg<T, NB>(bufE, lane, bq, w0, w1, loff, acc, NoHook(), nq0);
+    if constexpr (MLP) {
+      gemm_seg<T, NB>(bufE, lane, bq, w0, w1, loff, acc, NoHook(), nq0);
+    } else {
+      gemm_seg<T, NB>(bufE, lane, bq, w0, w0 + 3 * 16384, loff, acc, NoHook(), 3);  // K = 0 .. 383
+      {
+        const LaneCtx lc = lane_ctx(lane, wave);
+#pragma unroll
+        for (int mi = 0; mi < NB; ++mi) {
+          const T* r1 = (const T*)a.g1 + (int64_t)i1[mi] * a.ld_g1 + wave * 64 + lc.g * 4;
+          const T* r2 = (const T*)a.g2 + (int64_t)i2[mi] * a.ld_g2 + wave * 64 + lc.g * 4;
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) {
+            ga[mi][ni] = *reinterpret_cast<const u32x2*>(r1 + ni * 16);
+            gb[mi][ni] = *reinterpret_cast<const u32x2*>(r2 + ni * 16);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // K = 384 .. 511: slots 48 + s of a panel row; the swizzle only touches the low four bits of a slot index, so the offset is a pointer offset
+      gemm_seg<T, NB>(bufE + 48 * 16, lane, bq, w0 + 3 * 16384, w1, loff, acc, NoHook(), 1);
+    }
     stamp();  // + 1: first GEMM done
     {
       const LaneCtx lc = lane_ctx(lane, wave);
