@@ -30,7 +30,7 @@ struct EdgeChainArgs {
   const void* ln_g; const void* ln_b; float ln_eps;
   void* e_new;     int64_t ld_o;
   int n_rows, rows_per_tile, n_tiles;
-  int dbg;  // experiment (timing only, results are garbage): bit 0 no GELU, bit 1 no LayerNorm arithmetic, bit 2 no gathers
+  int dbg;  // experiment (timing only, results are garbage): bit 0 no GELU, bit 2 no gathered rows, bit 3 no global stores
   // the MLP instantiation (no gathered rows): y = LayerNorm(W_2 gelu(W_1 gelu(W_0 x + b_0) + b_1) + b_2) [+ res]
   const void* res = nullptr; int64_t ld_res = 0;  // optional residual rows (the edge chain's residual is e itself)
   int k0_groups = 4;                              // width of x / K of the first GEMM in units of 128 columns (w0: fragment-major [512, 128 k0_groups])
@@ -138,7 +138,13 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
     // behind a gather waits for the gather too: with indices and rows requested in front of the GEMM, its steps 4.. stood behind two
     // dependent round trips of scattered 8-byte loads (in-kernel timeline: the first GEMM 10.4 us, the other two 6.6).  Now: the indices
     // at the panel's start, the rows behind the GEMM's 12th K-step - the ring loads issued after them are the NEXT segment's, first
-    // consumed behind the epilogue that consumes the rows anyway.
+    // consumed behind the epilogue that consumes the rows anyway.  What is left of their cost is their share of the CU's L1 path, which the
+    // weight stream saturates: 3 us per panel (ANEMOI_EDGE_CHAIN_DBG=4 against 0, same box: 177 against 192 us per launch).  Tried on top,
+    // same-box A/Bs, no gain, not kept: the next panel's indices prefetched an epilogue ahead (two registers per lane, __shfl at the
+    // use: 176.3 against 176.2 us); sixteen 16-byte loads per lane instead of thirty-two 8-byte ones, the two lanes of a row 16 lanes
+    // apart fetching what both need and trading halves with v_permlane16_swap (176.0-177.7 against 174.0-176.6 us; the tail segment
+    // then has registers for three of the four bands only).  Neither are the e' stores in front of the next panel what delays it
+    // (DBG=8: the first GEMM stays at 10.9 us).
     u32x2 ga[MLP ? 1 : NB][4], gb[MLP ? 1 : NB][4], pb[4];
     [[maybe_unused]] int i1[NB], i2[NB];
     if constexpr (!MLP) {
@@ -168,8 +174,12 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
           const T* r2 = (const T*)a.g2 + (int64_t)i2[mi] * a.ld_g2 + wave * 64 + lc.g * 4;
 #pragma unroll
           for (int ni = 0; ni < 4; ++ni) {
-            ga[mi][ni] = *reinterpret_cast<const u32x2*>(r1 + ni * 16);
-            gb[mi][ni] = *reinterpret_cast<const u32x2*>(r2 + ni * 16);
+            if (a.dbg & 4) {  // (timing experiment: no gathered rows)
+              ga[mi][ni] = gb[mi][ni] = u32x2{0u, 0u};
+            } else {
+              ga[mi][ni] = *reinterpret_cast<const u32x2*>(r1 + ni * 16);
+              gb[mi][ni] = *reinterpret_cast<const u32x2*>(r2 + ni * 16);
+            }
           }
         }
       }
@@ -305,7 +315,7 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
           for (int r = 0; r < 4; ++r) o[r] = fmaf((acc[mi][ni][r] - mean[mi]) * rstd[mi], gv[r], bv[r]) + ev[r];  // edge_ln_res_segsum's arithmetic
           pk[mi][ni] = pack4<T>(o);
         }
-      store_block_via_strip<T, NB>(pk, bufH + wave * (kERows * 128), (T*)a.e_new + (int64_t)r0 * a.ld_o + wave * 64, a.ld_o, nr, lane, wave);
+      store_block_via_strip<T, NB>(pk, bufH + wave * (kERows * 128), (T*)a.e_new + (int64_t)r0 * a.ld_o + wave * 64, a.ld_o, (a.dbg & 8) ? 0 : nr, lane, wave);
     }
     stamp();  // + 7: LayerNorm + residual applied, rows stored through the strips
     if (!more) break;
@@ -608,7 +618,7 @@ extern "C" int anemoi_gnn_edge_chain_fwd(const void* e, int64_t ld_e, const void
                  "gnn_edge_chain_fwd: operand alignment / leading dimensions");
   EdgeChainArgs a{e, ld_e, g1, ld_g1, idx1, g2, ld_g2, idx2, (const char*)w0, b0, (const char*)w1, b1, (const char*)w2, b2, ln_w, ln_b, eps, e_new, ld_o,
                   n_rows, chain_rows_per_tile(n_rows, kERows), 0, 0};
-  static const int dbg = env_int(getenv("ANEMOI_EDGE_CHAIN_DBG"), 0, 0, 7);
+  static const int dbg = env_int(getenv("ANEMOI_EDGE_CHAIN_DBG"), 0, 0, 15);
   a.dbg = dbg;
   a.n_tiles = (n_rows + a.rows_per_tile - 1) / a.rows_per_tile;
   const int grid = a.n_tiles < 256 ? a.n_tiles : 256;
@@ -635,6 +645,8 @@ extern "C" int anemoi_gnn_edge_chain_timeline(const void* e, int64_t ld_e, const
   EdgeChainArgs a{e, ld_e, g1, ld_g1, idx1, g2, ld_g2, idx2, (const char*)w0, b0, (const char*)w1, b1, (const char*)w2, b2, ln_w, ln_b, eps, e_new, ld_o,
                   n_rows, chain_rows_per_tile(n_rows, kERows), 0, 0};
   a.timeline = timeline;
+  static const int dbg = env_int(getenv("ANEMOI_EDGE_CHAIN_DBG"), 0, 0, 15);
+  a.dbg = dbg;
   a.n_tiles = (n_rows + a.rows_per_tile - 1) / a.rows_per_tile;
   const int grid = a.n_tiles < 256 ? a.n_tiles : 256;
   constexpr int smem = kEdgeSmem + 8 * kETlSlots * 8;

@@ -60,7 +60,8 @@ print(f"plain kernel: {per_launch(plain):.1f} us per launch (back to back, {M} r
 for _ in range(50):
     timed()
 wall_us = per_launch(timed)
-assert torch.equal(out, plain()), "the instrumented instantiation must compute what the production one does"
+if os.environ.get("ANEMOI_EDGE_CHAIN_DBG", "0") == "0":
+    assert torch.equal(out, plain()), "the instrumented instantiation must compute what the production one does"
 t = tl.cpu().double()  # [wg, wave, slot]
 n = int((t[0, 0] > 0).sum())
 span = (t[:, :, :n].amax((1, 2)) - t[:, :, 0].amin(1)).median().item()
