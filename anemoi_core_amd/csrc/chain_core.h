@@ -91,7 +91,8 @@ struct NoHook {
 };
 template <typename T, int NB = 3, typename Hook = NoHook>
 __device__ __forceinline__ void gemm_seg(const unsigned char* abuf, int lane, frag8 (&bq)[4][4], const char* cur, const char* nxt,
-                                         uint32_t loff, f32x4 (&acc)[NB][4], Hook hook = Hook(), int nq = 4) {  // cur / nxt: wave-uniform (SGPR) bases, loff = lane * 16
+                                         uint32_t loff, f32x4 (&acc)[NB][4], Hook hook = Hook(), int nq = 4, int flip = -1) {  // cur / nxt: wave-uniform (SGPR) bases, loff = lane * 16
+  // flip >= 0 (experiment): the wave raises its issue priority in every other group of 4 K-steps - flip = 0 / 1 for the two waves of a SIMD
   // nq: groups of 4 K-steps (K = 128 nq; 4 = the 512-wide segment every caller but the MLP chain's first GEMM uses)
   asm volatile("" : "+v"(lane));
   const int x = lane & 15, ks = lane >> 4;
@@ -106,6 +107,10 @@ __device__ __forceinline__ void gemm_seg(const unsigned char* abuf, int lane, fr
   for (int q = 0; q < nq; ++q) {
     const char* pfg = q < nq - 1 ? cur + (q + 1) * 16384 : nxt;
     hook(q);  // side traffic of the caller, a quarter of it per group of 4 K-steps (the edge chain's next panel)
+    if (flip >= 0) {
+      if ((q + flip) & 1) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int st = q * 4 + j;
@@ -128,6 +133,7 @@ __device__ __forceinline__ void gemm_seg(const unsigned char* abuf, int lane, fr
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+  if (flip >= 0) __builtin_amdgcn_s_setprio(0);
 }
 
 __device__ __forceinline__ void lds_barrier() {  // LDS writes of all waves visible; global loads in flight (the weight ring) stay in flight

@@ -30,7 +30,7 @@ struct EdgeChainArgs {
   const void* ln_g; const void* ln_b; float ln_eps;
   void* e_new;     int64_t ld_o;
   int n_rows, rows_per_tile, n_tiles;
-  int dbg;  // experiment (timing only, results are garbage): bit 0 no GELU, bit 2 no gathered rows, bit 3 no global stores
+  int dbg;  // experiment (timing only, results are garbage): bit 0 no GELU, bit 2 no gathered rows, bit 3 no global stores; bit 4 (results valid): alternating wave priorities
   // the MLP instantiation (no gathered rows): y = LayerNorm(W_2 gelu(W_1 gelu(W_0 x + b_0) + b_1) + b_2) [+ res]
   const void* res = nullptr; int64_t ld_res = 0;  // optional residual rows (the edge chain's residual is e itself)
   int k0_groups = 4;                              // width of x / K of the first GEMM in units of 128 columns (w0: fragment-major [512, 128 k0_groups])
@@ -60,6 +60,7 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4;
   const uint32_t loff = lane * 16;
+  const int flip = (a.dbg & 16) ? (wave >> 2) : -1;  // (experiment: alternating issue priority of the two waves of a SIMD, chain_core.h)
   const int nq0 = MLP ? a.k0_groups : 4;  // K of the first GEMM / 128
   const int nslots = nq0 * 16;            // 16-byte slots per panel row
   const char* const w0 = a.w0 + (int64_t)wave * (nq0 * 16384);
@@ -163,9 +164,9 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
     // ---- h1 = gelu(e W_e^T + g1[dst] + g2[src] + b0) -> bufH
     zero_acc<T, NB>(acc);
     if constexpr (MLP) {
-      gemm_seg<T, NB>(bufE, lane, bq, w0, w1, loff, acc, NoHook(), nq0);
+      gemm_seg<T, NB>(bufE, lane, bq, w0, w1, loff, acc, NoHook(), nq0, flip);
     } else {
-      gemm_seg<T, NB>(bufE, lane, bq, w0, w0 + 3 * 16384, loff, acc, NoHook(), 3);  // K = 0 .. 383
+      gemm_seg<T, NB>(bufE, lane, bq, w0, w0 + 3 * 16384, loff, acc, NoHook(), 3, flip);  // K = 0 .. 383
       {
         const LaneCtx lc = lane_ctx(lane, wave);
 #pragma unroll
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
       }
       __builtin_amdgcn_sched_barrier(0);
       // K = 384 .. 511: slots 48 + s of a panel row; the swizzle only touches the low four bits of a slot index, so the offset is a pointer offset
-      gemm_seg<T, NB>(bufE + 48 * 16, lane, bq, w0 + 3 * 16384, w1, loff, acc, NoHook(), 1);
+      gemm_seg<T, NB>(bufE + 48 * 16, lane, bq, w0 + 3 * 16384, w1, loff, acc, NoHook(), 1, flip < 0 ? -1 : flip ^ 1);
     }
     stamp();  // + 1: first GEMM done
     {
@@ -223,10 +224,10 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
         if (q > 0) write_piece(next_tile, q - 1);
         request_piece(next_tile, q);
       };
-      gemm_seg<T, NB>(bufH, lane, bq, w1, w2, loff, acc, hook);
+      gemm_seg<T, NB>(bufH, lane, bq, w1, w2, loff, acc, hook, 4, flip);
       write_piece(next_tile, 3);  // (published by the barrier at the end of this panel)
     } else {
-      gemm_seg<T, NB>(bufH, lane, bq, w1, w2, loff, acc);
+      gemm_seg<T, NB>(bufH, lane, bq, w1, w2, loff, acc, NoHook(), 4, flip);
     }
     stamp();  // + 3: second GEMM done (and the next panel moved into LDS)
     u32x2 hp[NB][4];
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
     stamp();  // + 4: GELU epilogue written in place (two barriers)
     // ---- z = h2 W_2^T + b2 (rounded, as the Linear's output is); e' = LayerNorm(z) + e -> global
     zero_acc<T, NB>(acc);
-    gemm_seg<T, NB>(bufH, lane, bq, w2, w0, loff, acc);  // (behind it: the next panel's first segment; after the last panel a harmless re-read)
+    gemm_seg<T, NB>(bufH, lane, bq, w2, w0, loff, acc, NoHook(), 4, flip);  // (behind it: the next panel's first segment; after the last panel a harmless re-read)
     stamp();  // + 5: third GEMM done
     {
       const LaneCtx lc = lane_ctx(lane, wave);
@@ -618,7 +619,7 @@ extern "C" int anemoi_gnn_edge_chain_fwd(const void* e, int64_t ld_e, const void
                  "gnn_edge_chain_fwd: operand alignment / leading dimensions");
   EdgeChainArgs a{e, ld_e, g1, ld_g1, idx1, g2, ld_g2, idx2, (const char*)w0, b0, (const char*)w1, b1, (const char*)w2, b2, ln_w, ln_b, eps, e_new, ld_o,
                   n_rows, chain_rows_per_tile(n_rows, kERows), 0, 0};
-  static const int dbg = env_int(getenv("ANEMOI_EDGE_CHAIN_DBG"), 0, 0, 15);
+  static const int dbg = env_int(getenv("ANEMOI_EDGE_CHAIN_DBG"), 0, 0, 31);
   a.dbg = dbg;
   a.n_tiles = (n_rows + a.rows_per_tile - 1) / a.rows_per_tile;
   const int grid = a.n_tiles < 256 ? a.n_tiles : 256;
@@ -645,7 +646,7 @@ extern "C" int anemoi_gnn_edge_chain_timeline(const void* e, int64_t ld_e, const
   EdgeChainArgs a{e, ld_e, g1, ld_g1, idx1, g2, ld_g2, idx2, (const char*)w0, b0, (const char*)w1, b1, (const char*)w2, b2, ln_w, ln_b, eps, e_new, ld_o,
                   n_rows, chain_rows_per_tile(n_rows, kERows), 0, 0};
   a.timeline = timeline;
-  static const int dbg = env_int(getenv("ANEMOI_EDGE_CHAIN_DBG"), 0, 0, 15);
+  static const int dbg = env_int(getenv("ANEMOI_EDGE_CHAIN_DBG"), 0, 0, 31);
   a.dbg = dbg;
   a.n_tiles = (n_rows + a.rows_per_tile - 1) / a.rows_per_tile;
   const int grid = a.n_tiles < 256 ? a.n_tiles : 256;
