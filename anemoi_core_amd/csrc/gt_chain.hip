@@ -143,15 +143,6 @@ __global__ __launch_bounds__(512, 1) void gt_chain_kernel(ChainArgs a) {
     stamp();  // 1: panel in LDS
     u32x2 xr[3][4];  // this lane's skip values (P epilogue), later x1 (MLP-2 epilogue)
     u32x2 pb[4], pg[4], pt[4];  // packed parameter columns of the coming epilogue (see load_cols)
-    {
-      const LaneCtx lc = lane_ctx(lane, wave);
-#pragma unroll
-      for (int mi = 0; mi < 3; ++mi) {
-        const T* xrow = (const T*)a.xres + (int64_t)(r0 + min(mi * 16 + lc.x, nr - 1)) * a.ld_x + wave * 64 + lc.g * 4;
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) xr[mi][ni] = *reinterpret_cast<const u32x2*>(xrow + ni * 16);
-      }
-    }
     load_cols<T>((const T*)a.bp, wave, g, pb);
     load_cols<T>((const T*)a.ln1_g, wave, g, pg);
     if (a.ln1_b != nullptr) {
@@ -165,7 +156,21 @@ __global__ __launch_bounds__(512, 1) void gt_chain_kernel(ChainArgs a) {
     f32x4 acc[3][4], acc2[3][4];
     // ---- projection + skip -> x1 (parked in the output rows), LayerNorm_mlp(x1) -> bufB
     zero_acc<T>(acc);
-    gemm_seg<T>(bufA, lane, bq, wp0, w10, loff, acc);
+    // the skip rows are requested behind the GEMM's 12th K-step: loads retire in order, and in front of the GEMM these twelve 8-byte row
+    // loads per lane (HBM latency) stood before every weight-ring wait from its 5th step on (found in the GraphConv edge chain's timeline;
+    // the ring loads issued behind them here are the next segment's, first waited for behind the epilogue that consumes the rows anyway)
+    gemm_seg<T>(bufA, lane, bq, wp0, wp0 + 3 * 16384, loff, acc, NoHook(), 3);
+    {
+      const LaneCtx lc = lane_ctx(lane, wave);
+#pragma unroll
+      for (int mi = 0; mi < 3; ++mi) {
+        const T* xrow = (const T*)a.xres + (int64_t)(r0 + min(mi * 16 + lc.x, nr - 1)) * a.ld_x + wave * 64 + lc.g * 4;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) xr[mi][ni] = *reinterpret_cast<const u32x2*>(xrow + ni * 16);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    gemm_seg<T>(bufA + 48 * 16, lane, bq, wp0 + 3 * 16384, w10, loff, acc, NoHook(), 1);  // K = 384 .. 511 (slots 48 + s: the swizzle stays in the low 4 bits)
     stamp();  // 2: projection GEMM done
     if (!(a.dbg & 8)) {
       const LaneCtx lc = lane_ctx(lane, wave);
