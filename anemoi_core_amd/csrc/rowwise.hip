@@ -433,6 +433,18 @@ __global__ void assemble_input_norm_vec8_kernel(const TI* __restrict__ x, int64_
   if (i >= (int64_t)n_rows * per_row) return;
   const int n = (int)(i / per_row), c0 = (int)(i % per_row) << 3;
   Vec<TO, 8> o;
+  if (T_steps == 1 && A == 0) {  // a plain cast + zero-pad of [N, V] rows (the GNN embeddings' inputs): no divisions
+    const TI* xr = x + (int64_t)n * ldx;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = c0 + j;
+      float v = c < V ? to_float(xr[c]) : 0.f;
+      if (mul != nullptr && c < V) v = mul_then_add(v, mul[c], add[c]);
+      o.v[j] = from_float<TO>(v);
+    }
+    *reinterpret_cast<Vec<TO, 8>*>(out + (int64_t)n * ldo + c0) = o;
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int c = c0 + j;
