@@ -957,7 +957,8 @@ def assemble_input(x: Tensor, attrs: Optional[Tensor], width: int, col_mul: Opti
         raise ValueError("assemble_input: x must be [T, N, V] with contiguous variables, attrs [N, A] of the output dtype")
     out = torch.empty((N, width), dtype=odt, device=x.device)
     ap, lda = _rows(attrs, "attrs", odt)
-    if col_mul is None and col_add is None and odt == x.dtype:
+    plain_pad = T == 1 and A == 0 and odt != torch.float32 and width % 8 == 0  # cast + zero-pad of [N, V] rows: the division-free 16-byte path
+    if col_mul is None and col_add is None and odt == x.dtype and not plain_pad:
         _lib.check(_lib.load().anemoi_assemble_input(x.data_ptr(), x.stride(0), x.stride(1), T, V, ap, lda, A, out.data_ptr(), width, width, N,
                                                      _dt(x), _stream()), "assemble_input")
         return out
