@@ -73,6 +73,7 @@ SIGNATURES = {
     "anemoi_peer_close": ([_p], C.c_int),
     "anemoi_gt_chain_fwd": ([_p, C.c_int, _p], C.c_int),
     "anemoi_gt_chain_rows_per_tile": ([_i32], C.c_int),
+    "anemoi_gt_chain2_fwd": ([_p, C.c_int, _p], C.c_int),
     "anemoi_gnn_edge_chain_fwd": ([_p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _i64, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_gnn_edge_chain_timeline": ([_p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _i64, _i32, _p, _p], C.c_int),
     "anemoi_gnn_mlp_chain_fwd": ([_p, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _i64, _p, _i64, _i32, _i32, C.c_int, _p], C.c_int),

@@ -19,7 +19,7 @@ LIBPATH = os.path.join(LIBDIR, "libanemoi_hip.so")
 EXT_PATH = os.path.join(LIBDIR, "libanemoi_torch.so")
 INCLUDE = os.path.join(REPO, "include")
 
-SOURCES = ["lib.cpp", "gt_attention.hip", "gt_attention_bwd.hip", "rowwise.hip", "rowwise_bwd.hip", "linear.hip", "wgrad.hip", "peer.hip", "gt_chain.hip", "gnn_chain.hip"]
+SOURCES = ["lib.cpp", "gt_attention.hip", "gt_attention_bwd.hip", "rowwise.hip", "rowwise_bwd.hip", "linear.hip", "wgrad.hip", "peer.hip", "gt_chain.hip", "gt_chain2.hip", "gnn_chain.hip"]
 ARCH = "gfx950"
 
 

@@ -52,6 +52,15 @@ _LN_FOLD_MIN_ROWS = int(os.environ.get("ANEMOI_LN_FOLD_MIN_ROWS", "512"))
 _chain_env = os.environ.get("ANEMOI_LAYER_CHAIN", "")
 _LAYER_CHAIN = _chain_env != "0"
 _LAYER_CHAIN_MIN_ROWS = int(os.environ.get("ANEMOI_LAYER_CHAIN_MIN_ROWS", "0" if _chain_env == "1" else "100000"))
+# Round 5: the role-split form of that launch (ops.gt_layer_chain2, csrc/gt_chain2.hip: the workgroup's waves in two groups working
+# different GEMM segments, the LayerNorms' affine parts folded into the weights here, once per parameter version).  It replaces the
+# round-4 kernel wherever that one is eligible; ANEMOI_LAYER_CHAIN_V2=0 keeps the round-4 kernel (same-box A/B).
+_LAYER_CHAIN_V2 = os.environ.get("ANEMOI_LAYER_CHAIN_V2", "1") != "0"
+# Where the role-split launch wins as well (measured): blocks of at most ONE panel per CU (256 x 48 rows: the hidden
+# meshes up to res 5, a rank's share of bigger ones) - there the launch-per-GEMM path sits on its fixed costs.  In between (the O96
+# decoder's 40 320 rows = 4 rounds of panels, each streaming all weights again: 250 us against ~160 us for its GEMM launches) the
+# GEMM launches with their big tiles re-use the weights better.  ANEMOI_LAYER_CHAIN_MAX_SMALL_ROWS=0: only the >= MIN_ROWS blocks.
+_LAYER_CHAIN_MAX_SMALL_ROWS = int(os.environ.get("ANEMOI_LAYER_CHAIN_MAX_SMALL_ROWS", str(256 * 48) if _LAYER_CHAIN_V2 else "0"))
 
 
 _IDENTITY: dict = {}
@@ -350,13 +359,18 @@ class GraphTransformerBaseBlock(BaseBlock):
         """The row-resident chain kernel takes this block's projection / LayerNorm / MLP: inference, 16-bit, 512 channels, plain
         affine LayerNorm, Linear-GELU-Linear MLP with a hidden width that is a multiple of 512."""
         mlp = self.node_dst_mlp
-        return (_LAYER_CHAIN and x.is_cuda and x.dtype != torch.float32 and x.shape[0] >= _LAYER_CHAIN_MIN_ROWS
+        return (_LAYER_CHAIN and x.is_cuda and x.dtype != torch.float32
+                and (x.shape[0] >= _LAYER_CHAIN_MIN_ROWS or x.shape[0] <= _LAYER_CHAIN_MAX_SMALL_ROWS)
                 and type(ln).__name__ in ("LayerNorm", "AutocastLayerNorm") and ln.weight is not None
                 and mlp.mlp_implementation == "mlp" and len(mlp.mlp) == 3 and mlp.layer_norm is None
                 and self.projection.weight.shape == (ops.CHAIN_CHANNELS, ops.CHAIN_CHANNELS) and self.projection.bias is not None
                 and mlp.mlp[0].weight.shape[1] == ops.CHAIN_CHANNELS and mlp.mlp[0].weight.shape[0] % ops.CHAIN_CHANNELS == 0
                 and mlp.mlp[2].weight.shape[0] == ops.CHAIN_CHANNELS and mlp.mlp[0].bias is not None and mlp.mlp[2].bias is not None
-                and not (torch.is_grad_enabled() and (x.requires_grad or ln.weight.requires_grad or self.projection.weight.requires_grad)))
+                # (mixed layouts - an fp32-kept LayerNorm or weights next to 16-bit activations - take the GEMM launches; the chain ops raise on them)
+                and all(p is None or p.dtype == x.dtype for p in (ln.weight, ln.bias, self.projection.weight, self.projection.bias,
+                                                                   mlp.mlp[0].weight, mlp.mlp[0].bias, mlp.mlp[2].weight, mlp.mlp[2].bias))
+                # (the chain ops build no autograd graph: ANY trainable parameter of the tail keeps the differentiable path)
+                and not (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for m in (ln, self.projection, mlp) for p in m.parameters()))))
 
     def _qkvs_chain_ok(self, x: Tensor) -> bool:
         """This block's layer_norm_attention + fused [q|k|v|self] projection can ride at the end of the PREVIOUS block's chain launch."""
@@ -364,7 +378,9 @@ class GraphTransformerBaseBlock(BaseBlock):
         A = self.attn_channels
         return (type(ln).__name__ in ("LayerNorm", "AutocastLayerNorm") and ln.weight is not None and not self.qk_norm
                 and x.shape[1] == ops.CHAIN_CHANNELS and (4 * A) % ops.CHAIN_CHANNELS == 0 and self.lin_query.weight.shape[1] == ops.CHAIN_CHANNELS
-                and not (torch.is_grad_enabled() and (ln.weight.requires_grad or self.lin_query.weight.requires_grad)))
+                and all(p is None or p.dtype == x.dtype for m in (ln, self.lin_query, self.lin_key, self.lin_value, self.lin_self) for p in m.parameters())
+                and not (torch.is_grad_enabled() and any(p.requires_grad for m in (ln, self.lin_query, self.lin_key, self.lin_value, self.lin_self)
+                                                         for p in m.parameters())))
 
     def _post_attention(self, attn_plus_self: Tensor, x_skip: Tensor, cond: Optional[Tensor] = None, chain: Optional[dict] = None,
                         extra: Optional[Tensor] = None, next_block=None) -> Tensor:
@@ -377,12 +393,40 @@ class GraphTransformerBaseBlock(BaseBlock):
         ln, mlp = self.layer_norm_mlp_dst, self.node_dst_mlp
         plain_mlp = mlp.mlp_implementation == "mlp" and len(mlp.mlp) == 3 and mlp.layer_norm is None
         if cond is None and self._chain_ok(ln, attn_plus_self) and attn_plus_self.shape == x_skip.shape and (extra is None or extra.shape == x_skip.shape):
+            nb = next_block if (next_block is not None and chain is not None and extra is None and next_block._qkvs_chain_ok(x_skip)) else None
+            hidden = mlp.mlp[0].weight.shape[0]
+            if _LAYER_CHAIN_V2 and ops.gt_layer_chain2_supported(attn_plus_self, hidden, 0 if nb is None else 4 * nb.attn_channels):
+                lin1, lin2 = mlp.mlp[0], mlp.mlp[2]
+                qlins = [] if nb is None else [nb.lin_query, nb.lin_key, nb.lin_value, nb.lin_self]
+                lnq = None if nb is None else nb.layer_norm_attention
+                params = [self.projection.weight, self.projection.bias, ln.weight, ln.bias, lin1.weight, lin1.bias, lin2.weight, lin2.bias]
+                params += [q for lin in qlins for q in (lin.weight, lin.bias)] + ([] if lnq is None else [lnq.weight, lnq.bias])
+
+                def build():
+                    w1g, d1 = ops.fold_layer_norm(lin1.weight, lin1.bias, ln.weight, ln.bias)
+                    parts = [self.projection.bias.float(), d1, lin2.bias.float()]
+                    wqg = None
+                    if nb is not None:
+                        wq = torch.cat([lin.weight for lin in qlins], dim=0)
+                        bq = torch.cat([lin.bias if lin.bias is not None else lin.weight.new_zeros(lin.out_features) for lin in qlins])
+                        wq, dq = ops.fold_layer_norm(wq, bq, lnq.weight, lnq.bias)
+                        wqg = ops.pack_weight_frag(wq)
+                        parts.append(dq)
+                    return (ops.pack_weight_frag(self.projection.weight), ops.pack_weight_frag(w1g), ops.pack_weight_frag(lin2.weight),
+                            torch.cat(parts).to(lin1.weight.dtype).contiguous(), wqg)
+
+                wp, w1g, w2, vec, wqg = self._fused.derived("chain2" if nb is None else f"chain2:{id(nb)}", params, build)
+                res = ops.gt_layer_chain2(attn_plus_self, x_skip, wp, w1g, w2, vec, hidden, ln.eps, extra=extra, wqg=wqg,
+                                          q_out_features=0 if nb is None else 4 * nb.attn_channels, lnq_eps=1e-5 if lnq is None else lnq.eps)
+                if nb is not None:
+                    chain["qkvs_x"], chain["qkvs"] = res
+                    return res[0]
+                return res
             wp, bp = self._fused.frag("proj", [self.projection])
             w1, b1 = self._fused.frag("mlp1", [mlp.mlp[0]])
             w2, b2 = self._fused.frag("mlp2", [mlp.mlp[2]])
             kw = {}
-            if next_block is not None and chain is not None and extra is None and next_block._qkvs_chain_ok(x_skip):
-                nb = next_block
+            if nb is not None:
                 kw["wq"], kw["bq"] = nb._fused.frag("qkvs", [nb.lin_query, nb.lin_key, nb.lin_value, nb.lin_self])
                 lnq = nb.layer_norm_attention
                 kw["lnq_w"], kw["lnq_b"], kw["lnq_eps"] = lnq.weight, lnq.bias, lnq.eps

@@ -829,6 +829,70 @@ def gt_layer_chain(attn: Tensor, x_res: Tensor, wp: Tensor, bp: Tensor, ln1_w: T
     return x_out if q_out is None else (x_out, q_out)
 
 
+class _Chain2Args(_lib.C.Structure):
+    _p, _i64, _i32, _f = _lib.C.c_void_p, _lib.C.c_int64, _lib.C.c_int32, _lib.C.c_float
+    _fields_ = [("attn", _p), ("ld_attn", _i64), ("x_res", _p), ("ld_x", _i64), ("wp", _p), ("w1", _p), ("hidden", _i32), ("w2", _p),
+                ("wq", _p), ("q_out_features", _i32), ("vec", _p), ("ln1_eps", _f), ("lnq_eps", _f), ("extra", _p), ("ld_extra", _i64),
+                ("x_out", _p), ("ld_out", _i64), ("q_out", _p), ("ld_q", _i64), ("n_rows", _i32), ("channels", _i32),
+                ("rows_per_tile", _i32), ("timeline", _p)]
+
+
+CHAIN2_VEC_MAX = 6144  # elements of [b_p | d1 | b_2 | dq] the kernel keeps in LDS (csrc/gt_chain2.hip)
+
+
+def fold_layer_norm(weight: Tensor, bias: Optional[Tensor], gamma: Tensor, beta: Optional[Tensor]) -> tuple[Tensor, Tensor]:
+    """``LN(x) W^T + b = ((x - mean) rstd) (W diag(gamma))^T + (W beta + b)``: the affine part of a LayerNorm folded into the Linear
+    that follows it.  Returns (W diag(gamma) rounded to the weight's dtype, d = W beta + b in fp32)."""
+    w = weight.detach().float()
+    b = w.new_zeros(w.shape[0]) if bias is None else bias.detach().float()
+    wg = (w * gamma.detach().float()).to(weight.dtype)
+    d = b if beta is None else w @ beta.detach().float() + b
+    return wg, d
+
+
+def gt_layer_chain2_supported(x: Tensor, hidden: int, q_out: int = 0) -> bool:
+    return gt_layer_chain_supported(x, hidden, q_out) and 2 * CHAIN_CHANNELS + hidden + q_out <= CHAIN2_VEC_MAX
+
+
+def gt_layer_chain2(attn: Tensor, x_res: Tensor, wp: Tensor, w1g: Tensor, w2: Tensor, vec: Tensor, hidden: int, ln1_eps: float, *,
+                    extra: Optional[Tensor] = None, wqg: Optional[Tensor] = None, q_out_features: int = 0, lnq_eps: float = 1e-5,
+                    rows_per_tile: int = 0, timeline: Optional[Tensor] = None):
+    """The row-local part of a GraphTransformer block in ONE launch with role-split waves (anemoi_gt_chain2_fwd, csrc/gt_chain2.hip):
+
+        x1 = attn Wp^T + bp + x_res;  h = GELU(LN(x1; ln1) W1^T + b1);  x_out = h W2^T + b2 + x1 [+ extra]
+        q_out = LN(x_out; lnq) Wq^T + bq        (optional: the NEXT block's LayerNorm + fused q|k|v|self projection)
+
+    with the LayerNorms' affine parts folded by the caller (``fold_layer_norm``): ``w1g`` / ``wqg`` are the fragment-major images of
+    ``W diag(gamma)``, ``vec = cat[bp, d1, b2, dq]`` in the model dtype with ``d = W beta + b``.  Returns ``x_out`` or
+    ``(x_out, q_out)``.  Inference only (no autograd)."""
+    _dev(attn, x_res, wp, w1g, w2, vec, extra, wqg)
+    N, D = attn.shape
+    dt = attn.dtype
+    if D != CHAIN_CHANNELS or dt not in (torch.bfloat16, torch.float16):
+        raise NotImplementedError(f"gt_layer_chain2: {D} channels / {dt} (built for {CHAIN_CHANNELS} channels, 16-bit dtypes)")
+    if 2 * D + hidden + q_out_features > CHAIN2_VEC_MAX:
+        raise NotImplementedError(f"gt_layer_chain2: hidden={hidden} + q_out={q_out_features} exceed the kernel's LDS vector region")
+    if tuple(x_res.shape) != (N, D) or (extra is not None and tuple(extra.shape) != (N, D)):
+        raise ValueError("gt_layer_chain2: attn, x_res and extra must have the same [N, channels] shape")
+    if extra is not None and q_out_features:
+        raise ValueError("gt_layer_chain2: a trailing projection and a second residual exclude each other")
+    for name, w, numel in (("wp", wp, D * D), ("w1g", w1g, hidden * D), ("w2", w2, D * hidden), ("wqg", wqg, q_out_features * D)):
+        if w is None and numel == 0:
+            continue
+        if w is None or w.dim() != 1 or w.numel() != numel or w.dtype != dt or not w.is_contiguous():
+            raise ValueError(f"gt_layer_chain2: {name} must be the contiguous fragment-major image ({numel} x {dt}) made by pack_weight_frag")
+    if vec.dim() != 1 or vec.numel() != 2 * D + hidden + q_out_features or vec.dtype != dt or not vec.is_contiguous():
+        raise ValueError(f"gt_layer_chain2: vec must be contiguous [{2 * D + hidden + q_out_features}] {dt} = cat[bp, d1, b2, dq]")
+    x_out = torch.empty((N, D), dtype=dt, device=attn.device)
+    q_out = torch.empty((N, q_out_features), dtype=dt, device=attn.device) if q_out_features else None
+    (ap, lda), (xp, ldx), (ep, lde) = _rows(attn, "attn", dt), _rows(x_res, "x_res", dt), _rows(extra, "extra", dt)
+    a = _Chain2Args(ap, lda, xp, ldx, wp.data_ptr(), w1g.data_ptr(), hidden, w2.data_ptr(), 0 if wqg is None else wqg.data_ptr(), q_out_features,
+                    vec.data_ptr(), float(ln1_eps), float(lnq_eps), ep, lde, x_out.data_ptr(), D, 0 if q_out is None else q_out.data_ptr(),
+                    q_out_features, N, D, int(rows_per_tile), 0 if timeline is None else timeline.data_ptr())
+    _lib.check(_lib.load().anemoi_gt_chain2_fwd(_lib.C.byref(a), _dt(attn), _stream()), "gt_chain2_fwd")
+    return x_out if q_out is None else (x_out, q_out)
+
+
 def gnn_edge_chain(e: Tensor, g1: Tensor, idx1: Tensor, g2: Tensor, idx2: Tensor, w0: Tensor, b0: Tensor, w1: Tensor, b1: Tensor, w2: Tensor,
                    b2: Tensor, ln_w: Tensor, ln_b: Optional[Tensor], eps: float) -> Tensor:
     """GraphConv's edge MLP (three Linears, gather-add form) + LayerNorm + residual in ONE launch (anemoi_gnn_edge_chain_fwd):

@@ -396,6 +396,37 @@ typedef struct anemoi_gt_chain_args {
 int anemoi_gt_chain_fwd(const anemoi_gt_chain_args_t* args, anemoi_dtype_t dtype, void* stream);
 int anemoi_gt_chain_rows_per_tile(int32_t n_rows);
 
+/* ---- role-split row-resident layer chain (round 5; csrc/gt_chain2.hip) ------------------------------------------------------
+ * The same block tail as anemoi_gt_chain_fwd (projection + skip, layer_norm_mlp_dst, node_dst_mlp + skip [+ latent skip], optionally the
+ * NEXT block's layer_norm_attention + fused [q|k|v|self] projection: layers/block.py:1237-1273, encoder_processor_decoder.py:295-296),
+ * with the workgroup's eight waves split into two groups of four that work DIFFERENT GEMM segments (group A: projection, MLP first
+ * Linear + GELU, even chunks of the trailing projection; group B: MLP second Linear, odd chunks), so that one group's epilogue runs
+ * beside the other group's MFMA and weight stream.  The two LayerNorms are computed as fp32 statistics of the rounded rows and applied
+ * WITHOUT their affine part, the normalised row rounded to the model dtype; the affine part is folded by the caller into the Linear that
+ * follows (ops.gt_layer_chain2 does it once per parameter version):
+ *     w1 = fragment-major image of W_1 diag(gamma_1) (rounded to the model dtype),   d1 = W_1 beta_1 + b_1
+ *     wq = fragment-major image of W_q diag(gamma_q),                                 dq = W_q beta_q + b_q
+ * and every bias enters as the START value of its GEMM's accumulators: vec = [b_p (512) | d1 (hidden) | b_2 (512) | dq (q_out_features)]
+ * in the model dtype, kept in LDS (2*512 + hidden + q_out_features <= 6144, else ANEMOI_E_UNSUPPORTED).  extra and a trailing
+ * projection exclude each other (the reference adds the latent skip behind the LAST block).  Images as for anemoi_gt_chain_fwd; all
+ * leading dimensions multiples of 8 elements; channels must be 512. */
+typedef struct anemoi_gt_chain2_args {
+  const void* attn;   int64_t ld_attn;    /* [n_rows, channels]   attention output + self term */
+  const void* x_res;  int64_t ld_x;       /* [n_rows, channels]   the block's input */
+  const void* wp;                         /* projection, fragment-major [channels, channels] */
+  const void* w1;     int32_t hidden;     /* fragment-major [hidden, channels], layer_norm_mlp_dst's gamma folded in */
+  const void* w2;                         /* fragment-major [channels, hidden] */
+  const void* wq;     int32_t q_out_features; /* fragment-major [q_out_features, channels], the next block's gamma folded in; 0: none */
+  const void* vec;                        /* [b_p | d1 | b_2 | dq], model dtype, 16-byte aligned */
+  float ln1_eps;      float lnq_eps;
+  const void* extra;  int64_t ld_extra;   /* optional [n_rows, channels] or NULL */
+  void* x_out;        int64_t ld_out;     /* [n_rows, channels] */
+  void* q_out;        int64_t ld_q;       /* [n_rows, q_out_features] */
+  int32_t n_rows;     int32_t channels;   int32_t rows_per_tile;
+  void* timeline;     /* NULL; developer aid: uint64 [min(256, panels)][8 waves][48] (tools/chain_timeline.py --v2) */
+} anemoi_gt_chain2_args_t;
+int anemoi_gt_chain2_fwd(const anemoi_gt_chain2_args_t* args, anemoi_dtype_t dtype, void* stream);
+
 /* ---- row-resident chains of the GraphConv (GNN) processor block (round 4; csrc/gnn_chain.hip) ------------------------------------
  * GraphConv (layers/conv.py:29-81) in its gather-add form, with an edge MLP of three Linears (mlp_extra_layers = 0):
  *     e_new = LayerNorm(W_2 gelu(W_1 gelu(W_e e + g1[idx1] + g2[idx2] + b_0) + b_1) + b_2; ln) + e

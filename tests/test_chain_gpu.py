@@ -394,3 +394,85 @@ def test_gnn_model_with_chains_equals_model_without():
     for name, y in (("chain", a), ("launch-per-GEMM", b)):
         err = (y - want).abs()
         assert float(err.max()) <= 6e-2 * max(scale, 1.0) and float(err.mean()) <= 1e-2 * max(scale, 1.0), (name, float(err.max()), float(err.mean()), scale)
+
+
+# ------------------------------------------------------------------------------------------ role-split chain (round 5, csrc/gt_chain2.hip)
+def _run_chain2(ops, attn, x, p, extra=None, rows_per_tile=0):
+    """the caller's side of anemoi_gt_chain2_fwd: the LayerNorms' affine parts folded into the Linears that follow them"""
+    d = lambda t: None if t is None else t.to(DEV)  # noqa: E731
+    dt = attn.dtype
+    w1g, d1 = ops.fold_layer_norm(d(p["w1"]), d(p["b1"]), d(p["g1"]), d(p["be1"]))
+    parts = [d(p["bp"]).float(), d1, d(p["b2"]).float()]
+    wqg, qf = None, 0
+    if p["wq"] is not None:
+        wq_, dq = ops.fold_layer_norm(d(p["wq"]), d(p["bq"]), d(p["gq"]), d(p["beq"]))
+        wqg, qf = ops.pack_weight_frag(wq_), p["wq"].shape[0]
+        parts.append(dq)
+    vec = torch.cat(parts).to(dt).contiguous()
+    return ops.gt_layer_chain2(d(attn), d(x), ops.pack_weight_frag(d(p["wp"])), ops.pack_weight_frag(w1g), ops.pack_weight_frag(d(p["w2"])), vec,
+                               p["w1"].shape[0], 1e-5, extra=d(extra), wqg=wqg, q_out_features=qf, lnq_eps=1e-5, rows_per_tile=rows_per_tile)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,rows_per_tile", [(41, 0), (7, 0), (1, 0), (1000, 0), (10242, 0), (10242, 48), (12345, 17), (40962, 0)])
+def test_chain2_vs_fp32_restatement(dtype, N, rows_per_tile):
+    """the role-split kernel against the same fp32 restatement (the reference's rounding points; its LayerNorm output is rounded WITH the
+    affine part, the kernel's without - the affine part rides in the rounded weights): every row of x2 and of the trailing projection,
+    ragged last panels, several panels per workgroup, panel heights that are no multiple of the 16-row MFMA band."""
+    from anemoi_core_amd import ops
+
+    gen = torch.Generator().manual_seed(N + rows_per_tile)
+    p = _params(gen, dtype)
+    attn = torch.randn(N, D, generator=gen).to(dtype)
+    x = (2.0 * torch.randn(N, D, generator=gen) + 0.5).to(dtype)
+    x2, q = _run_chain2(ops, attn, x, p, rows_per_tile=rows_per_tile)
+    ref2, refq = _reference(attn, x, p, dtype)
+    _close(x2, ref2, f"x2 N={N}")
+    _close(q, refq, f"qkvs N={N}")
+    x2b, qb = _run_chain2(ops, attn, x, p, rows_per_tile=rows_per_tile)
+    assert torch.equal(x2, x2b) and torch.equal(q, qb)  # deterministic
+
+
+@pytest.mark.parametrize("variant", ["no_q", "extra", "no_beta", "q1024", "q512", "q1536", "hidden1024", "hidden512", "hidden1536"])
+def test_chain2_variants(variant):
+    """no trailing projection, the latent skip as a second residual, LayerNorms without bias, odd / single chunk counts of the trailing
+    projection (group B has one chunk fewer, or none) and of the hidden width (x2 lands in the other h buffer)."""
+    import tests.test_chain_gpu as me
+    from anemoi_core_amd import ops
+
+    dtype, N = torch.bfloat16, 3000
+    gen = torch.Generator().manual_seed(7)
+    hd = {"hidden1024": 1024, "hidden512": 512, "hidden1536": 1536}.get(variant, 2048)
+    old = me.HD
+    me.HD = hd
+    try:
+        p = _params(gen, dtype, q_out={"no_q": 0, "extra": 0, "q1024": 1024, "q512": 512, "q1536": 1536}.get(variant, 2048), beta=variant != "no_beta")
+    finally:
+        me.HD = old
+    attn = torch.randn(N, D, generator=gen).to(dtype)
+    x = torch.randn(N, D, generator=gen).to(dtype)
+    extra = (3.0 * torch.randn(N, D, generator=gen)).to(dtype) if variant == "extra" else None
+    res = _run_chain2(ops, attn, x, p, extra=extra)
+    ref2, refq = _reference(attn, x, p, dtype, extra=extra)
+    if p["wq"] is None:
+        assert isinstance(res, torch.Tensor)
+        _close(res, ref2, variant)
+    else:
+        _close(res[0], ref2, variant)
+        _close(res[1], refq, variant + " q")
+
+
+def test_chain2_equals_round4_chain():
+    """both chain kernels on the same block: equal to a few ulps of the output scale (different accumulation order, LayerNorm output
+    rounded before / behind the affine part)"""
+    from anemoi_core_amd import ops
+
+    dtype, N = torch.bfloat16, 10242
+    gen = torch.Generator().manual_seed(11)
+    p = _params(gen, dtype)
+    attn, x = torch.randn(N, D, generator=gen).to(dtype), torch.randn(N, D, generator=gen).to(dtype)
+    a2, aq = _run_chain(ops, attn, x, p)
+    b2, bq = _run_chain2(ops, attn, x, p)
+    e2, eq = (a2.float() - b2.float()).abs(), (aq.float() - bq.float()).abs()
+    assert float(e2.max()) <= 2e-2 * float(a2.float().abs().max()) and float(e2.mean()) <= 2e-3 * float(a2.float().abs().mean() + 1)
+    assert float(eq.max()) <= 3e-2 * float(aq.float().abs().max()) and float(eq.mean()) <= 4e-3 * float(aq.float().abs().mean() + 1)
