@@ -54,6 +54,7 @@ struct Chain2Args {
   void* qout;        int64_t ld_q;          // [n_rows, 512 qc]
   int n_rows, rows_per_tile, n_tiles;
   int prio_a;                               // experiment: s_setprio of group A (0: none)
+  int prio_q;                               // experiment: chunk-ordered priorities in the trailing projection
   int warm;                                 // the L2 warm-up of the next step's weights (ANEMOI_CHAIN2_WARM=0: off, for the A/B)
   unsigned long long* timeline;             // developer aid (TL instantiation only): [workgroups][8 waves][kTl2Slots] s_memtime stamps
 };
@@ -144,15 +145,37 @@ __device__ __forceinline__ void init_acc(f32x4 (&acc)[3][8], const unsigned char
 
 // The wave's 48 x 128 block rounded to the model dtype into the panel buffer `dst` (its own columns); acc keeps the ROUNDED values.
 // STATS: per-wave (mean, M2) of every row over the wave's 128 columns -> red[row][wq].
-template <typename T, bool STATS>
-__device__ __forceinline__ void round_rows(f32x4 (&acc)[3][8], unsigned char* dst, float* red, int lane, int wq) {
+// ADD: first + vec[col0 + column] + the values the panel buffer `dst` holds at the same positions (the projection's bias and skip rows).
+template <typename T, bool STATS, bool ADD = false>
+__device__ __forceinline__ void round_rows(f32x4 (&acc)[3][8], unsigned char* dst, float* red, int lane, int wq, const unsigned char* vec = nullptr, int col0 = 0) {
   const Lane2 lc = lane2(lane, wq);
 #pragma unroll
   for (int mi = 0; mi < 3; ++mi) {
     unsigned char* drow = dst + (mi * 16 + lc.x) * kRowBytes;
+    // (ADD: the reads of half a row band are requested together, pinned - the ring's next fragments are live here: all 48 reads at once spill,
+    // one pair at a time exposes an LDS round trip twelve times)
+    u32x2 rb[8], rr[8];
+    if (ADD) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int ni = 4 * h; ni < 4 * h + 4; ++ni) {
+          rb[ni] = *reinterpret_cast<const u32x2*>(vec + (col0 + wq * 128 + ni * 16 + lc.g * 4) * 2);
+          rr[ni] = *reinterpret_cast<const u32x2*>(drow + lc.coff[ni]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
 #pragma unroll
     for (int ni = 0; ni < 8; ++ni) {
       float o[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
+      if (ADD) {
+        float b[4], r[4];
+        unpack4<T>(rb[ni], b);
+        unpack4<T>(rr[ni], r);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] += b[k] + r[k];
+      }
       const u32x2 pk = pack4<T>(o);
       *reinterpret_cast<u32x2*>(drow + lc.coff[ni]) = pk;
       if (STATS) {
@@ -261,6 +284,21 @@ __device__ __forceinline__ void load_rows12(const T* src, int64_t ld, int r0, in
     *reinterpret_cast<u32x4*>(dst + row * kRowBytes + ((lane ^ (row & 15)) << 4)) = row < nr ? v[i] : u32x4{0u, 0u, 0u, 0u};
   }
 }
+// the per-column vectors -> LDS, once per launch, by all 512 threads (requested behind the first panel's rows; visible behind the first barrier)
+struct VecCopy {
+  u32x4 v[2];
+  __device__ __forceinline__ void request(const Chain2Args& a, int tid) {
+    const int n16 = (1024 + 512 * (a.hc + a.qc)) / 8;  // <= 768
+#pragma unroll
+    for (int k = 0; k < 2; ++k) v[k] = reinterpret_cast<const u32x4*>(a.vec)[min(tid + 512 * k, n16 - 1)];
+  }
+  __device__ __forceinline__ void store(const Chain2Args& a, int tid, unsigned char* smem) {
+    const int n16 = (1024 + 512 * (a.hc + a.qc)) / 8;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (tid + 512 * k < n16) reinterpret_cast<u32x4*>(smem + kVecOff)[tid + 512 * k] = v[k];
+  }
+};
 // the wave's first weight fragments (two K-steps of both 64-column streams)
 __device__ __forceinline__ void ring_prologue(frag8 (&ring)[2][8], const char* f0, int64_t fs, uint32_t loff) {
 #pragma unroll
@@ -301,8 +339,18 @@ __device__ __forceinline__ unsigned touch_share(const char* seg, int64_t piece, 
 // (the touched value must stay "in use" until the next touch: the compiler then keeps its register and counts the load)
 __device__ __forceinline__ void touch_done(unsigned& v) { asm volatile("" : "+v"(v)); }
 
+// The trailing projection's chunks in strict priority order (chunk 0 > 1 > 2 > 3): the groups' chunks then take the weight stream one
+// behind the other, each epilogue beside the other group's GEMM, instead of the older wave of a SIMD starving the younger one.
+__device__ __forceinline__ void set_chunk_prio(int on, int k) {
+  if (!on) return;
+  if (k == 0) __builtin_amdgcn_s_setprio(3);
+  else if (k == 1) __builtin_amdgcn_s_setprio(2);
+  else if (k == 2) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
+}
+
 // Both roles execute the SAME number of s_barrier per panel (the hardware barrier counts arrivals, not program locations):
-// S0 | S1 | S2 | hc + 1 MLP steps | S8 | one behind the trailing projection (if any).
+// S0 | P GEMM | x1 | S2 | hc + 1 MLP steps | S8 | one behind the trailing projection (if any).
 template <typename T, bool TL>
 __device__ __forceinline__ void role_a(const Chain2Args& a, Ctx2& c, unsigned char* smem) {
   const int hc = a.hc, qc = a.qc, lane = c.lane, wq = __builtin_amdgcn_readfirstlane(c.wq);
@@ -329,21 +377,36 @@ __device__ __forceinline__ void role_a(const Chain2Args& a, Ctx2& c, unsigned ch
     if (wq < 2) { if (sa != nullptr) warm = touch_share(sa, kSlab, wq & 1, lane); }
     else if (sb != nullptr) warm = touch_share(sb, pb, wq & 1, lane);
   };
-  for (int tile = blockIdx.x; tile < a.n_tiles; tile += (int)gridDim.x) {
+  // S0 of the first panel (peeled: straight-line code, so that the stores of the rows wait for the rows only): the attention rows ->
+  // bufB, requested AHEAD of the vectors, the warm-up and the weight ring's first fragments - loads return in order
+  {
+    const int r0 = (int)blockIdx.x * a.rows_per_tile;
+    load_rows12<T>((const T*)a.attn, a.ld_attn, r0, min(a.rows_per_tile, a.n_rows - r0), bufB, lane, wq, [&] {
+      stamp2<TL>(c, smem);  // rows requested
+      ring_prologue(ring, wpw, s1, c.loff);
+      // this CU's share of the projection's weights (waves 0, 1) and of M1(0)'s (waves 2, 3)
+      if (a.warm) warm = touch_share(wq < 2 ? a.wp : a.w1, kSlab, wq & 1, lane);
+      stamp2<TL>(c, smem);  // everything requested
+    });
+    stamp2<TL>(c, smem);  // rows stored
+    lds_barrier();
+  }
+  for (int tile = blockIdx.x;;) {
     const int r0 = tile * a.rows_per_tile;
     const int nr = min(a.rows_per_tile, a.n_rows - r0);
-    // S0: the attention rows -> bufB (the first panel's requested AHEAD of the weight ring's first fragments: loads return in order)
-    load_rows12<T>((const T*)a.attn, a.ld_attn, r0, nr, bufB, lane, wq, [&] {
-      if (tile == (int)blockIdx.x) ring_prologue(ring, wpw, s1, c.loff);
-    });
-    lds_barrier();
     stamp2<TL>(c, smem);
-    // S1: projection + skip; x1 (rounded) over the skip rows it was computed from (each lane rewrites the positions it read)
-    init_acc<T, true>(acc, vec, 0, bufC, lane, wq);
+    // S1: the projection on the attention rows alone - the skip rows and the per-column vectors come in through group B meanwhile (the
+    // CU's memory pipe holds ~64 wave-instructions: every load in front of the first MFMA costs its share of a 2-us round, in-kernel
+    // timeline) - then + b_p + x; x1 (rounded) over the skip rows it was computed from (each lane rewrites the positions it read)
+#pragma unroll
+    for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 8; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
     gemm128<T>(bufB, lane, ring, wpw, s1, w1c(0), s1, c.loff, acc);
     touch(seg_a(0), hc > 1 ? seg_a(1) : nullptr, kSlab);  // M1(0) (4 us away) and M1(1)
     stamp2<TL>(c, smem);
-    round_rows<T, true>(acc, bufC, red, lane, wq);
+    lds_barrier();  // group B's skip rows and vectors are in LDS
+    round_rows<T, true, true>(acc, bufC, red, lane, wq, vec, 0);
     stamp2<TL>(c, smem);
     lds_barrier();
     // S2: LayerNorm_mlp(x1) without its affine part -> bufB (every wave has read the attention rows)
@@ -355,7 +418,9 @@ __device__ __forceinline__ void role_a(const Chain2Args& a, Ctx2& c, unsigned ch
       stamp2<TL>(c, smem);
       init_acc<T, false>(acc, vec, 512 + 512 * t, nullptr, lane, wq);
       const char* nxt = t + 1 < hc ? w1c(t + 1) : (qc > 0 ? wqc(0) : wpw);
+      if (a.prio_a == 1) __builtin_amdgcn_s_setprio(2);
       gemm128<T>(bufB, lane, ring, w1c(t), s1, nxt, s1, c.loff, acc);
+      if (a.prio_a == 1) __builtin_amdgcn_s_setprio(0);
       touch(t == 0 ? nullptr : seg_a(t + 1), a.w2 + (int64_t)t * kSlab, sw2);  // the next step's M1(t + 1) (t = 0: touched behind P) and M2(t)
       stamp2<TL>(c, smem);
       gelu_rows<T>(acc, hbuf(t), lane, wq);
@@ -402,7 +467,9 @@ __device__ __forceinline__ void role_a(const Chain2Args& a, Ctx2& c, unsigned ch
     for (int k = 0; k < qc; k += 2) {
       stamp2<TL>(c, smem);
       init_acc<T, false>(acc, vec, 1024 + 512 * hc + 512 * k, nullptr, lane, wq);
+      set_chunk_prio(a.prio_q, k);
       gemm128<T>(bufB, lane, ring, wqc(k), s1, k + 2 < qc ? wqc(k + 2) : wpw, s1, c.loff, acc);
+      if (a.prio_q) __builtin_amdgcn_s_setprio(0);
       touch(k + 2 < qc ? a.wq + (int64_t)(8 * (k + 2)) * kSlab : nullptr, k + 3 < qc ? a.wq + (int64_t)(8 * (k + 3)) * kSlab : nullptr, kSlab);
       stamp2<TL>(c, smem);
       round_rows<T, false>(acc, hbuf(hc), nullptr, lane, wq);
@@ -410,6 +477,14 @@ __device__ __forceinline__ void role_a(const Chain2Args& a, Ctx2& c, unsigned ch
       stamp2<TL>(c, smem);
     }
     if (qc > 0) lds_barrier();  // (the groups' chunks are independent of each other: one barrier behind them all, for the next panel's S0)
+    tile += (int)gridDim.x;
+    if (tile >= a.n_tiles) break;
+    // S0 of the next panel
+    {
+      const int rn = tile * a.rows_per_tile;
+      load_rows12<T>((const T*)a.attn, a.ld_attn, rn, min(a.rows_per_tile, a.n_rows - rn), bufB, lane, wq, [] {});
+      lds_barrier();
+    }
   }
   touch_done(warm);
 }
@@ -429,16 +504,27 @@ __device__ __forceinline__ void role_b(const Chain2Args& a, Ctx2& c, unsigned ch
   auto wqc = [&](int k) { return a.wq + (int64_t)(8 * k + 2 * wq) * kSlab; };
   frag8 ring[2][8];
   f32x4 acc[3][8];
-  for (int tile = blockIdx.x; tile < a.n_tiles; tile += (int)gridDim.x) {
+  lds_barrier();  // S0 is group A's (the attention rows)
+  for (int tile = blockIdx.x;;) {
     const int r0 = tile * a.rows_per_tile;
     const int nr = min(a.rows_per_tile, a.n_rows - r0);
-    // S0: the skip rows -> bufC
-    load_rows12<T>((const T*)a.xres, a.ld_x, r0, nr, bufC, lane, wq, [&] {
-      if (tile == (int)blockIdx.x) ring_prologue(ring, w2c(0), s2, c.loff);
-    });
-    lds_barrier();
     stamp2<TL>(c, smem);
-    lds_barrier();  // S1 is group A's
+    // beside the projection: the skip rows -> bufC; in the first panel also the per-column vectors -> LDS and the weight ring's first fragments
+    if (tile == (int)blockIdx.x) {
+      VecCopy vc0, vc1;
+      load_rows12<T>((const T*)a.xres, a.ld_x, r0, nr, bufC, lane, wq, [&] {
+        vc0.request(a, wq * 64 + lane);
+        vc1.request(a, 256 + wq * 64 + lane);
+      });
+      vc0.store(a, wq * 64 + lane, smem);
+      vc1.store(a, 256 + wq * 64 + lane, smem);
+      ring_prologue(ring, w2c(0), s2, c.loff);
+    } else {
+      load_rows12<T>((const T*)a.xres, a.ld_x, r0, nr, bufC, lane, wq, [] {});
+    }
+    stamp2<TL>(c, smem);
+    lds_barrier();  // the skip rows are in LDS
+    lds_barrier();  // x1 is group A's
     stamp2<TL>(c, smem);
     // S2: x2's accumulators start at b_2 + x1
     init_acc<T, true>(acc, vec, 512 + 512 * hc, bufC, lane, wq);
@@ -469,13 +555,18 @@ __device__ __forceinline__ void role_b(const Chain2Args& a, Ctx2& c, unsigned ch
       stamp2<TL>(c, smem);
       init_acc<T, false>(acc, vec, 1024 + 512 * hc + 512 * k, nullptr, lane, wq);
       const bool last = k + 2 >= qc;
+      set_chunk_prio(a.prio_q, k);
       gemm128<T>(bufB, lane, ring, wqc(k), s1, last ? w2c(0) : wqc(k + 2), last ? s2 : s1, c.loff, acc);
+      if (a.prio_q) __builtin_amdgcn_s_setprio(0);
       stamp2<TL>(c, smem);
       round_rows<T, false>(acc, hbuf(hc + 1), nullptr, lane, wq);
       store_staged<T>(hbuf(hc + 1), (T*)a.qout + (int64_t)r0 * a.ld_q + k * kCh, a.ld_q, nr, lane, wq);
       stamp2<TL>(c, smem);
     }
     if (qc > 0) lds_barrier();
+    tile += (int)gridDim.x;
+    if (tile >= a.n_tiles) break;
+    lds_barrier();  // S0 of the next panel is group A's
   }
 }
 
@@ -491,24 +582,12 @@ __global__ __launch_bounds__(512, 1) void gt_chain2_kernel(Chain2Args a) {
   c.tl_n = 0;
   stamp2<TL>(c, smem);  // 0: entry
   if ((int)blockIdx.x >= a.n_tiles) return;
-  // the per-column vectors -> LDS, once per launch (visible behind the first barrier)
-  {
-    const int n16 = (1024 + 512 * (a.hc + a.qc)) / 8;
-    for (int i = tid; i < n16; i += 512) reinterpret_cast<u32x4*>(smem + kVecOff)[i] = reinterpret_cast<const u32x4*>(a.vec)[i];
-  }
-  unsigned w0 = 0;
-  if (a.warm) {  // the projection's weights: this CU's share of the first segment (waves 0, 1) and M1(0)'s (waves 2, 3); the ring's own first loads follow
-    if (c.wave < 2) w0 = touch_share(a.wp, kSlab, c.wave & 1, c.lane);
-    else if (c.wave < 4) w0 = touch_share(a.w1, kSlab, c.wave & 1, c.lane);
-  }
   if (c.wave < 4) {
-    if (a.prio_a == 1) __builtin_amdgcn_s_setprio(1);
-    else if (a.prio_a == 2) __builtin_amdgcn_s_setprio(2);
+    if (a.prio_a == 2) __builtin_amdgcn_s_setprio(2);
     role_a<T, TL>(a, c, smem);
   } else {
     role_b<T, TL>(a, c, smem);
   }
-  touch_done(w0);
   if constexpr (TL) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (c.lane < kTl2Slots)
@@ -575,6 +654,8 @@ extern "C" int anemoi_gt_chain2_fwd(const anemoi_gt_chain2_args_t* p, anemoi_dty
   a.timeline = reinterpret_cast<unsigned long long*>(p->timeline);
   static const int prio_a = env_int(getenv("ANEMOI_CHAIN2_PRIO_A"), 0, 0, 2);
   a.prio_a = prio_a;
+  static const int prio_q = env_int(getenv("ANEMOI_CHAIN2_PRIO_Q"), 0, 0, 1);
+  a.prio_q = prio_q;
   static const int warm = env_int(getenv("ANEMOI_CHAIN2_WARM"), 1, 0, 1);
   a.warm = warm;
   a.n_rows = p->n_rows;

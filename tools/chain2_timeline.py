@@ -102,13 +102,13 @@ span = (tw[:nwg].max(2).values.max(1).values - tw[:nwg, :, 0].min(1).values).med
 mhz = span / wall_us
 print(f"instrumented launch {wall_us:.1f} us, {na} / {nb} stamps (group A / B), median workgroup span {span:.0f} ticks -> {mhz:.0f} ticks/us")
 hc, qc = HD // D, qf // D
-names_a = ["entry", "S0 panel in LDS", "S1 P GEMM", "S1 x1 -> bufC + stats", "S2 LN -> bufB"]
+names_a = ["entry", "S0 rows requested", "S0 all requested", "S0 rows stored", "S0 panel in LDS", "S1 P GEMM", "S1 x1 -> bufC + stats", "S2 LN -> bufB"]
 for t in range(hc):
     names_a += [f"M{t} start", f"M{t} M1 GEMM", f"M{t} GELU -> h"]
 names_a += [f"M{hc} (idle) start", f"M{hc} passed", "S8 x2 -> global"]
 for k in range(0, qc, 2):
     names_a += [f"Q{k} start", f"Q{k} GEMM", f"Q{k} stores issued"]
-names_b = ["entry", "S0 panel in LDS", "S1 passed", "S2 acc2 = b2 + x1", "M0 (idle) start"]
+names_b = ["entry", "S0 passed", "skip rows, vectors, ring", "x1 barriers passed", "S2 acc2 = b2 + x1", "M0 (idle) start"]
 for t in range(1, hc + 1):
     names_b += [f"M{t} start", f"M{t} M2 GEMM"] + (["x2 -> buf + stats"] if t == hc else [])
 names_b += ["S8 LN' -> bufB"]
