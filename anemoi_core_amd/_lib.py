@@ -9,7 +9,7 @@ import ctypes as C
 import os
 import threading
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libanemoi_hip.so")
 
 F32, BF16, F16 = 0, 1, 2

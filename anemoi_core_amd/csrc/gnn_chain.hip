@@ -643,6 +643,11 @@ extern "C" int anemoi_gnn_edge_chain_timeline(const void* e, int64_t ld_e, const
                                               const void* w2, const void* b2, const void* ln_w, const void* ln_b, float eps, void* e_new,
                                               int64_t ld_o, int32_t n_rows, unsigned long long* timeline, void* stream) {
   ANEMOI_REQUIRE(n_rows > 0 && e && g1 && idx1 && g2 && idx2 && w0 && b0 && w1 && b1 && w2 && b2 && ln_w && e_new && timeline, "gnn_edge_chain_timeline: null operand");
+  // (the argument checks of anemoi_gnn_edge_chain_fwd; this entry point is bf16 only)
+  ANEMOI_REQUIRE(al(e, 16) && al(e_new, 16) && al(w0, 16) && al(w1, 16) && al(w2, 16) && al(g1, 8) && al(g2, 8) && al(b0, 8) && al(b1, 8) && al(b2, 8) &&
+                     al(ln_w, 8) && al(ln_b, 8) && ld_e % 8 == 0 && ld_o % 8 == 0 && ld_g1 % 4 == 0 && ld_g2 % 4 == 0 && ld_e >= kCh && ld_o >= kCh &&
+                     ld_g1 >= kCh && ld_g2 >= kCh,
+                 "gnn_edge_chain_timeline: operand alignment / leading dimensions");
   EdgeChainArgs a{e, ld_e, g1, ld_g1, idx1, g2, ld_g2, idx2, (const char*)w0, b0, (const char*)w1, b1, (const char*)w2, b2, ln_w, ln_b, eps, e_new, ld_o,
                   n_rows, chain_rows_per_tile(n_rows, kERows), 0, 0};
   a.timeline = timeline;
@@ -695,7 +700,8 @@ static int node_chain_launch(const void* x, int64_t ld_x, const void* agg, int64
   ANEMOI_REQUIRE(dtype == ANEMOI_BF16 || dtype == ANEMOI_F16, "gnn_node_chain_fwd: 16-bit model dtypes only");
   ANEMOI_REQUIRE(n_rows >= 0 && channels == kCh, "gnn_node_chain_fwd: channels=%d (this kernel is built for %d)", channels, kCh);
   if (n_rows == 0) return ANEMOI_OK;
-  ANEMOI_REQUIRE(x && agg && wa && ba && wb && bb && wc && bc && ln_w && x_out, "gnn_node_chain_fwd: null operand");
+  // (agg may be NULL when the segment pointer says every destination has no in-edge at all: an empty edge table has no rows to point at)
+  ANEMOI_REQUIRE(x && (agg || seg_ptr) && wa && ba && wb && bb && wc && bc && ln_w && x_out, "gnn_node_chain_fwd: null operand");
   ANEMOI_REQUIRE(t_out_features >= 0 && t_out_features % kCh == 0 && (t_out_features == 0 || (wt && t_out && ld_t >= t_out_features && ld_t % 8 == 0 && al(t_out, 16) && al(wt, 16))),
                  "gnn_node_chain_fwd: the trailing projection needs wt, t_out and t_out_features %% %d == 0", kCh);
   ANEMOI_REQUIRE(al(x, 16) && al(agg, 16) && al(x_out, 16) && al(wa, 16) && al(wb, 16) && al(wc, 16) && al(ba, 8) && al(bb, 8) && al(bc, 8) && al(bt, 8) &&

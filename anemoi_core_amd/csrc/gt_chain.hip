@@ -411,7 +411,7 @@ extern "C" int anemoi_gt_chain_fwd(const anemoi_gt_chain_args_t* p, anemoi_dtype
                  "gt_chain_fwd: operands must be 16-byte aligned (vectors: 8-byte)");
   ANEMOI_REQUIRE(p->ld_attn >= kCh && p->ld_x >= kCh && p->ld_out >= kCh && p->ld_attn % 8 == 0 && p->ld_x % 8 == 0 && p->ld_out % 4 == 0 &&
                      (p->extra == nullptr || (p->ld_extra >= kCh && p->ld_extra % 4 == 0)) &&
-                     (p->q_out_features == 0 || (p->ld_q >= p->q_out_features && p->ld_q % 4 == 0)),
+                     (p->q_out_features == 0 || (p->ld_q >= p->q_out_features && p->ld_q % 8 == 0)),  // (q_out leaves as 16-byte pieces; x_out / extra as 8-byte ones)
                  "gt_chain_fwd: leading dimensions too small or not vector-aligned");
   ChainArgs a{};
   a.attn = p->attn; a.ld_attn = p->ld_attn;

@@ -42,25 +42,22 @@ _LN_FOLD = os.environ.get("ANEMOI_LN_FOLD", "1") == "1"
 _LN_FOLD_MIN_ROWS = int(os.environ.get("ANEMOI_LN_FOLD_MIN_ROWS", "512"))
 # Round 4: the row-local part of a block (projection + skip, LayerNorm, MLP, the NEXT block's LayerNorm + q|k|v|self projection)
 # as ONE launch that keeps a 48-row panel in LDS and streams the weights (ops.gt_layer_chain, csrc/gt_chain.hip) instead of four
-# GEMM launches with the LayerNorm fold between them.  Built, parity-green and MEASURED: 105-115 us per launch against 108 us for
-# the four launches it replaces, O96 forward 3.01 against 2.955 ms (at 40 rows per CU every CU streams all
-# 6.5 MB of a layer's weights through its own L1, 106 k cycles at 64 B/clk before any epilogue) - so at the hidden meshes' sizes it
-# is OPT-IN (ANEMOI_LAYER_CHAIN=1: every eligible block), kept under test with its in-kernel timeline (tools/chain_timeline.py).
-# Where it wins is a block with MANY rows - the N320 decoder's 542 080 destination rows: the [N, 2048] hidden activations (2.2 GB
-# written and read back by the two MLP launches) never exist; N320 forward 15.25 -> 14.98 ms on the same box (O96's 40 320-row
-# decoder: 3.02 -> 3.04 ms, so the gate stays well above that).  Default: blocks of >= 100 000 rows; ANEMOI_LAYER_CHAIN=0: never.
+# GEMM launches with the LayerNorm fold between them: 105-115 us per launch against 108 us for the four launches at 10 242 rows (all
+# eight waves in the same phase: every epilogue with the MFMA pipe and the weight stream idle), a win only for the N320 decoder's
+# 542 080 rows, whose [N, 2048] hidden activations then never exist.
 _chain_env = os.environ.get("ANEMOI_LAYER_CHAIN", "")
 _LAYER_CHAIN = _chain_env != "0"
-_LAYER_CHAIN_MIN_ROWS = int(os.environ.get("ANEMOI_LAYER_CHAIN_MIN_ROWS", "0" if _chain_env == "1" else "100000"))
 # Round 5: the role-split form of that launch (ops.gt_layer_chain2, csrc/gt_chain2.hip: the workgroup's waves in two groups working
-# different GEMM segments, the LayerNorms' affine parts folded into the weights here, once per parameter version).  It replaces the
-# round-4 kernel wherever that one is eligible; ANEMOI_LAYER_CHAIN_V2=0 keeps the round-4 kernel (same-box A/B).
+# different GEMM segments, the LayerNorms' affine parts folded into the weights here, once per parameter version, each CU warming the L2
+# with its share of the next step's weights).  It replaces the round-4 kernel; ANEMOI_LAYER_CHAIN_V2=0 keeps that one (same-box A/B).
 _LAYER_CHAIN_V2 = os.environ.get("ANEMOI_LAYER_CHAIN_V2", "1") != "0"
-# Where the role-split launch wins as well (measured): blocks of at most ONE panel per CU (256 x 48 rows: the hidden
-# meshes up to res 5, a rank's share of bigger ones) - there the launch-per-GEMM path sits on its fixed costs.  In between (the O96
-# decoder's 40 320 rows = 4 rounds of panels, each streaming all weights again: 250 us against ~160 us for its GEMM launches) the
-# GEMM launches with their big tiles re-use the weights better.  ANEMOI_LAYER_CHAIN_MAX_SMALL_ROWS=0: only the >= MIN_ROWS blocks.
-_LAYER_CHAIN_MAX_SMALL_ROWS = int(os.environ.get("ANEMOI_LAYER_CHAIN_MAX_SMALL_ROWS", str(256 * 48) if _LAYER_CHAIN_V2 else "0"))
+# Where the role-split launch wins (measured): from ~7 000 rows on - one panel per CU (the hidden meshes of res 5:
+# O96 forward 2.98 -> 2.57 ms), four rounds of panels (res 6: 8.65 -> 8.12 ms; the O96 decoder's 40 320 rows: 2.59 -> 2.55 ms), the N320
+# decoder's 45 rounds (14.7 -> 13.9 ms).  Below, a launch costs the same ~75-90 us (every busy CU streams all of the layer's weights for
+# its 48 rows, and few CUs are busy) while the GEMM launches shrink with the rows: 2 562 hidden nodes 1.91 ms per forward on the launches
+# against 2.30 ms on the chain, 642 nodes 1.67 / 2.36 ms - and a rank's share of a sharded mesh is that small.  The round-4 kernel keeps
+# its gate (>= 100 000 rows).  ANEMOI_LAYER_CHAIN=1: every eligible block; =0: never; ANEMOI_LAYER_CHAIN_MIN_ROWS: the gate.
+_LAYER_CHAIN_MIN_ROWS = int(os.environ.get("ANEMOI_LAYER_CHAIN_MIN_ROWS", "0" if _chain_env == "1" else ("7168" if _LAYER_CHAIN_V2 else "100000")))
 
 
 _IDENTITY: dict = {}
@@ -360,7 +357,7 @@ class GraphTransformerBaseBlock(BaseBlock):
         affine LayerNorm, Linear-GELU-Linear MLP with a hidden width that is a multiple of 512."""
         mlp = self.node_dst_mlp
         return (_LAYER_CHAIN and x.is_cuda and x.dtype != torch.float32
-                and (x.shape[0] >= _LAYER_CHAIN_MIN_ROWS or x.shape[0] <= _LAYER_CHAIN_MAX_SMALL_ROWS)
+                and x.shape[0] >= _LAYER_CHAIN_MIN_ROWS
                 and type(ln).__name__ in ("LayerNorm", "AutocastLayerNorm") and ln.weight is not None
                 and mlp.mlp_implementation == "mlp" and len(mlp.mlp) == 3 and mlp.layer_norm is None
                 and self.projection.weight.shape == (ops.CHAIN_CHANNELS, ops.CHAIN_CHANNELS) and self.projection.bias is not None

@@ -61,7 +61,8 @@ def mlp_chain_ok(m: MLP, k_in: int, x: Tensor) -> bool:
             and type(m.layer_norm).__name__ in ("LayerNorm", "AutocastLayerNorm") and m.layer_norm.weight is not None
             and m.mlp[0].weight.shape == (D, k_in) and m.mlp[2].weight.shape == (D, D) and m.mlp[4].weight.shape == (D, D)
             and m.mlp[0].weight.dtype == x.dtype and all(m.mlp[i].bias is not None for i in (0, 2, 4))
-            and not (torch.is_grad_enabled() and (x.requires_grad or m.mlp[0].weight.requires_grad)))
+            # (the chain ops build no autograd graph: ANY trainable parameter of the MLP keeps the differentiable path)
+            and not (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in m.parameters()))))
 
 
 def node_mlp_chain(m: MLP, x: Tensor, agg: Tensor, *, wt: Optional[Tensor] = None, t_out_features: int = 0):

@@ -76,11 +76,11 @@ class PaddedLinear:
                 else:
                     x = torch.nn.functional.pad(x.to(wdt), (0, pad))
                 W = x.shape[-1]
-        if x.dtype != wdt:
-            x = x.to(wdt)
         elif W < K or W % 8:  # else: the caller already appended zero columns (one padded copy shared by several consumers,
             # possibly up to a multiple of 64 so that the GEMM takes the DMA-ring kernels)
             raise ValueError(f"input width {W} is neither in_features {K} nor a zero-padded width (multiple of 8 >= {K})")
+        if x.dtype != wdt:
+            x = x.to(wdt)
         if W == K:
             return x, lin.weight
         if torch.is_grad_enabled() and lin.weight.requires_grad:  # training: gradients flow through the padding

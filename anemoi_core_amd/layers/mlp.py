@@ -123,7 +123,7 @@ class MLP(nn.Module):
                 and l0.weight.shape[0] == D and l0.weight.shape[1] <= D and l1.weight.shape == (D, D) and l2.weight.shape == (D, D)
                 and all(m.bias is not None for m in (l0, l1, l2))
                 and type(ln).__name__ in ("LayerNorm", "AutocastLayerNorm") and getattr(ln, "weight", None) is not None
-                and not (torch.is_grad_enabled() and (h.requires_grad or l0.weight.requires_grad)))
+                and not (torch.is_grad_enabled() and (h.requires_grad or any(p.requires_grad for p in self.parameters()))))
 
     def _embedding_chain(self, h: Tensor, mods: list, residual: Optional[Tensor]) -> Tensor:
         from .conv import _derived

@@ -756,6 +756,8 @@ def main():
                 graph, graph_checked = None, None
                 torch.cuda.synchronize()
         run = graph.replay if graph is not None else step
+        if world > 1 and wire is not None:
+            wire.stats(reset=True)  # (the capture / check forwards above ran exchanges too: count the warm-up and timed forwards only)
         for _ in range(args.warmup):
             run()
         sync_all()

@@ -194,18 +194,21 @@ def test_model_with_chain_equals_model_without():
     m = model.to(DEV).to(torch.bfloat16)
     xb = x.to(DEV).to(torch.bfloat16)
     outs = {}
-    saved = (B._LAYER_CHAIN, B._LAYER_CHAIN_MIN_ROWS)
-    for flag in (True, False):
-        B._LAYER_CHAIN, B._LAYER_CHAIN_MIN_ROWS = flag, 0  # (by default only blocks of >= 100 000 rows take the chain)
+    saved = (B._LAYER_CHAIN, B._LAYER_CHAIN_MIN_ROWS, B._LAYER_CHAIN_V2)
+    for flag in ("role-split", "round-4", "off"):
+        # (by default only blocks of >= 7 168 rows take the chain; this mesh has 642 hidden nodes)
+        B._LAYER_CHAIN, B._LAYER_CHAIN_MIN_ROWS, B._LAYER_CHAIN_V2 = flag != "off", 0, flag == "role-split"
         try:
             with torch.no_grad():
                 outs[flag] = m({"data": xb})["data"].float().cpu()
         finally:
-            B._LAYER_CHAIN, B._LAYER_CHAIN_MIN_ROWS = saved
-    a, b = outs[True], outs[False]
+            B._LAYER_CHAIN, B._LAYER_CHAIN_MIN_ROWS, B._LAYER_CHAIN_V2 = saved
+    a, a4, b = outs["role-split"], outs["round-4"], outs["off"]
     scale = float(want.abs().max())
-    assert float((a - b).abs().max()) <= 3e-2 * scale and float((a - b).abs().mean()) <= 4e-3 * scale, (float((a - b).abs().max()), scale)
-    for name, y in (("chain", a), ("launch-per-GEMM", b)):
+    assert not torch.equal(a, b) and not torch.equal(a4, b) and not torch.equal(a, a4)  # three different paths really ran
+    for y in (a, a4):
+        assert float((y - b).abs().max()) <= 3e-2 * scale and float((y - b).abs().mean()) <= 4e-3 * scale, (float((y - b).abs().max()), scale)
+    for name, y in (("role-split chain", a), ("round-4 chain", a4), ("launch-per-GEMM", b)):
         err = (y - want).abs()
         assert float(err.max()) <= 6e-2 * max(scale, 1.0) and float(err.mean()) <= 1e-2 * max(scale, 1.0), (name, float(err.max()), float(err.mean()), scale)
 

@@ -196,8 +196,9 @@ def test_linear_operand_larger_than_2_gib():
 
 
 def test_processor_with_layernorm_fold_equals_unfused(monkeypatch):
-    """The opt-in LayerNorm fold (row statistics from the producing GEMM, mean/rstd applied in the consuming GEMM's epilogue)
-    against the default path on a 4-layer, 512-channel processor at the O96 hidden-mesh size, bf16."""
+    """The LayerNorm fold (row statistics from the producing GEMM, mean/rstd applied in the consuming GEMM's epilogue) and the role-split
+    layer chain (round 5: the default) against the plain launch-per-GEMM path with LayerNorm kernels, on a 4-layer, 512-channel
+    processor at the O96 hidden-mesh size, bf16."""
     from anemoi_core_amd.distributed.shapes import GraphShardInfo
     from anemoi_core_amd.graphs.synthetic import build_synthetic_graph
     from anemoi_core_amd.layers import block as B
@@ -211,12 +212,17 @@ def test_processor_with_layernorm_fold_equals_unfused(monkeypatch):
     proc = GraphTransformerProcessor(num_layers=4, num_channels=512, num_chunks=1, num_heads=16, mlp_hidden_ratio=4, edge_dim=ea.shape[1]).to(DEV).to(torch.bfloat16).eval()
     x = torch.randn(n, 512, device=DEV).to(torch.bfloat16)
     with torch.no_grad():
+        monkeypatch.setattr(B, "_LAYER_CHAIN", False)  # the launch-per-GEMM paths (since round 5 the layer chain takes these blocks by default)
         monkeypatch.setattr(B, "_LN_FOLD", False)
         y0 = proc(x, 1, GraphShardInfo(), ea, ei)
         monkeypatch.setattr(B, "_LN_FOLD", True)
         y1 = proc(x, 1, GraphShardInfo(), ea, ei)
         y2 = proc(x, 1, GraphShardInfo(), ea, ei)
-    assert torch.equal(y1, y2)  # deterministic
-    assert not torch.equal(y0, y1)  # the fold really ran (different rounding points)
-    err = (y1.float() - y0.float()).abs()
-    assert float(err.max()) <= 6e-2 * float(y0.float().abs().max()) and float(err.mean()) <= 5e-3 * float(y0.float().abs().mean()) + 1e-3
+        monkeypatch.setattr(B, "_LAYER_CHAIN", True)  # ... and the default: one role-split chain launch per block tail
+        y3 = proc(x, 1, GraphShardInfo(), ea, ei)
+        y4 = proc(x, 1, GraphShardInfo(), ea, ei)
+    assert torch.equal(y1, y2) and torch.equal(y3, y4)  # deterministic
+    assert not torch.equal(y0, y1) and not torch.equal(y0, y3) and not torch.equal(y1, y3)  # three different paths really ran (different rounding points)
+    for y in (y1, y3):
+        err = (y.float() - y0.float()).abs()
+        assert float(err.max()) <= 6e-2 * float(y0.float().abs().max()) and float(err.mean()) <= 5e-3 * float(y0.float().abs().mean()) + 1e-3
