@@ -52,6 +52,14 @@ __device__ __forceinline__ u32x2 pack4(const float (&v)[4]) {
   return u32x2{(unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16),
                (unsigned)__builtin_bit_cast(unsigned short, c) | ((unsigned)__builtin_bit_cast(unsigned short, d) << 16)};
 }
+// (halves: two conversions + one v_pack_b32_f16 per dword instead of a shift and an or - with 96 values per lane in an epilogue the
+// longer form made the role-split chain's f16 instantiation spill)
+template <>
+__device__ __forceinline__ u32x2 pack4<f16_t>(const float (&v)[4]) {
+  using h2 = __attribute__((ext_vector_type(2))) _Float16;
+  const h2 lo = {(_Float16)v[0], (_Float16)v[1]}, hi = {(_Float16)v[2], (_Float16)v[3]};
+  return u32x2{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+}
 // this lane's 4 values of each of the wave's 4 column blocks of a parameter vector (bias, gamma, beta), loaded EARLY - before
 // the GEMM whose epilogue uses them: vmcnt retires in order, so a load issued behind the weight ring's prefetches could only be
 // waited for together with them (a full L2 latency exposed at every epilogue)

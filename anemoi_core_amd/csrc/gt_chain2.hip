@@ -55,6 +55,7 @@ struct Chain2Args {
   int n_rows, rows_per_tile, n_tiles;
   int prio_a;                               // experiment: s_setprio of group A (0: none)
   int prio_q;                               // experiment: chunk-ordered priorities in the trailing projection
+  int dbg;                                  // experiment (timing only, results are garbage): bit 0 no GELU arithmetic, 1 no LayerNorm statistics / normalisation, 2 no stores of the trailing projection
   int warm;                                 // the L2 warm-up of the next step's weights (ANEMOI_CHAIN2_WARM=0: off, for the A/B)
   unsigned long long* timeline;             // developer aid (TL instantiation only): [workgroups][8 waves][kTl2Slots] s_memtime stamps
 };
@@ -410,7 +411,8 @@ __device__ __forceinline__ void role_a(const Chain2Args& a, Ctx2& c, unsigned ch
     stamp2<TL>(c, smem);
     lds_barrier();
     // S2: LayerNorm_mlp(x1) without its affine part -> bufB (every wave has read the attention rows)
-    normalise_rows<T>(acc, red, a.eps1, bufB, lane, wq);
+    if (a.dbg & 2) round_rows<T, false>(acc, bufB, nullptr, lane, wq);
+    else normalise_rows<T>(acc, red, a.eps1, bufB, lane, wq);
     stamp2<TL>(c, smem);
     lds_barrier();
     // the MLP's first Linear, chunk by chunk (+ GELU); step hc is group B's alone
@@ -423,12 +425,19 @@ __device__ __forceinline__ void role_a(const Chain2Args& a, Ctx2& c, unsigned ch
       if (a.prio_a == 1) __builtin_amdgcn_s_setprio(0);
       touch(t == 0 ? nullptr : seg_a(t + 1), a.w2 + (int64_t)t * kSlab, sw2);  // the next step's M1(t + 1) (t = 0: touched behind P) and M2(t)
       stamp2<TL>(c, smem);
-      gelu_rows<T>(acc, hbuf(t), lane, wq);
+      if (a.dbg & 1) round_rows<T, false>(acc, hbuf(t), nullptr, lane, wq);
+      else gelu_rows<T>(acc, hbuf(t), lane, wq);
       stamp2<TL>(c, smem);
       lds_barrier();
     }
     stamp2<TL>(c, smem);
     if (qc > 1) touch(hc == 1 ? seg_a(hc) : nullptr, a.wq + (int64_t)8 * kSlab, kSlab);  // group B's first chunk of the trailing projection (Q0: behind M1(hc - 1))
+    const int tile_next = tile + (int)gridDim.x;
+    if (qc == 0 && tile_next < a.n_tiles) {
+      // nothing to do in this step and bufB free (every wave of the group is behind its last M1 segment): the NEXT panel's attention rows
+      const int rn = tile_next * a.rows_per_tile;
+      load_rows12<T>((const T*)a.attn, a.ld_attn, rn, min(a.rows_per_tile, a.n_rows - rn), bufB, lane, wq, [] {});
+    }
     lds_barrier();  // step hc
     stamp2<TL>(c, smem);
     // S8: x2 [+ latent skip] -> global as whole rows
@@ -473,14 +482,14 @@ __device__ __forceinline__ void role_a(const Chain2Args& a, Ctx2& c, unsigned ch
       touch(k + 2 < qc ? a.wq + (int64_t)(8 * (k + 2)) * kSlab : nullptr, k + 3 < qc ? a.wq + (int64_t)(8 * (k + 3)) * kSlab : nullptr, kSlab);
       stamp2<TL>(c, smem);
       round_rows<T, false>(acc, hbuf(hc), nullptr, lane, wq);
-      store_staged<T>(hbuf(hc), (T*)a.qout + (int64_t)r0 * a.ld_q + k * kCh, a.ld_q, nr, lane, wq);
+      if (!(a.dbg & 4)) store_staged<T>(hbuf(hc), (T*)a.qout + (int64_t)r0 * a.ld_q + k * kCh, a.ld_q, nr, lane, wq);
       stamp2<TL>(c, smem);
     }
     if (qc > 0) lds_barrier();  // (the groups' chunks are independent of each other: one barrier behind them all, for the next panel's S0)
-    tile += (int)gridDim.x;
+    tile = tile_next;
     if (tile >= a.n_tiles) break;
-    // S0 of the next panel
-    {
+    // S0 of the next panel (without a trailing projection its rows came in during step hc, two barriers ago)
+    if (qc > 0) {
       const int rn = tile * a.rows_per_tile;
       load_rows12<T>((const T*)a.attn, a.ld_attn, rn, min(a.rows_per_tile, a.n_rows - rn), bufB, lane, wq, [] {});
       lds_barrier();
@@ -560,13 +569,13 @@ __device__ __forceinline__ void role_b(const Chain2Args& a, Ctx2& c, unsigned ch
       if (a.prio_q) __builtin_amdgcn_s_setprio(0);
       stamp2<TL>(c, smem);
       round_rows<T, false>(acc, hbuf(hc + 1), nullptr, lane, wq);
-      store_staged<T>(hbuf(hc + 1), (T*)a.qout + (int64_t)r0 * a.ld_q + k * kCh, a.ld_q, nr, lane, wq);
+      if (!(a.dbg & 4)) store_staged<T>(hbuf(hc + 1), (T*)a.qout + (int64_t)r0 * a.ld_q + k * kCh, a.ld_q, nr, lane, wq);
       stamp2<TL>(c, smem);
     }
     if (qc > 0) lds_barrier();
     tile += (int)gridDim.x;
     if (tile >= a.n_tiles) break;
-    lds_barrier();  // S0 of the next panel is group A's
+    if (qc > 0) lds_barrier();  // S0 of the next panel is group A's
   }
 }
 
@@ -654,6 +663,8 @@ extern "C" int anemoi_gt_chain2_fwd(const anemoi_gt_chain2_args_t* p, anemoi_dty
   a.timeline = reinterpret_cast<unsigned long long*>(p->timeline);
   static const int prio_a = env_int(getenv("ANEMOI_CHAIN2_PRIO_A"), 0, 0, 2);
   a.prio_a = prio_a;
+  static const int dbg = env_int(getenv("ANEMOI_CHAIN2_DBG"), 0, 0, 7);
+  a.dbg = dbg;
   static const int prio_q = env_int(getenv("ANEMOI_CHAIN2_PRIO_Q"), 0, 0, 1);
   a.prio_q = prio_q;
   static const int warm = env_int(getenv("ANEMOI_CHAIN2_WARM"), 1, 0, 1);

@@ -122,13 +122,13 @@ def kernel_cases(model, g, args, dtype, device):
     ln = blk.layer_norm_attention
     cases = {
         "layernorm": (lambda: ops.layer_norm(x, ln.weight, ln.bias, ln.eps), "hbm", 2 * N * D * es),
-        "linear_qkvs(512->2048)": (lambda: ops.linear(x, w4, b4), "mfma", 2.0 * N * D * 4 * D),
+        f"linear_qkvs({D}->{4 * D})": (lambda: ops.linear(x, w4, b4), "mfma", 2.0 * N * D * 4 * D),
         "gt_attention_fused_edge": (lambda: ops.gt_attention_fused_edge(qkvs[:, :D], qkvs[:, D:2 * D], qkvs[:, 2 * D:3 * D], feat,
                                                                         blk._fused.packed_edge(blk.lin_edge), csc, H, addend=qkvs[:, 3 * D:]), "hbm",
                                     es * 5 * N * D + 4 * M * feat.shape[1] + 4 * (M + N + 1)),  # q,k,v,self read + out write + feat + idx
-        "linear_proj(512->512)+res": (lambda: ops.linear(x, blk.projection.weight, blk.projection.bias, residual=x), "mfma", 2.0 * N * D * D),
-        "linear_mlp1(512->2048)+gelu": (lambda: ops.linear(x, blk.node_dst_mlp.mlp[0].weight, blk.node_dst_mlp.mlp[0].bias, act="gelu"), "mfma", 2.0 * N * D * hid),
-        "linear_mlp2(2048->512)+res": (lambda: ops.linear(h, blk.node_dst_mlp.mlp[2].weight, blk.node_dst_mlp.mlp[2].bias, residual=x), "mfma", 2.0 * N * hid * D),
+        f"linear_proj({D}->{D})+res": (lambda: ops.linear(x, blk.projection.weight, blk.projection.bias, residual=x), "mfma", 2.0 * N * D * D),
+        f"linear_mlp1({D}->{hid})+gelu": (lambda: ops.linear(x, blk.node_dst_mlp.mlp[0].weight, blk.node_dst_mlp.mlp[0].bias, act="gelu"), "mfma", 2.0 * N * D * hid),
+        f"linear_mlp2({hid}->{D})+res": (lambda: ops.linear(h, blk.node_dst_mlp.mlp[2].weight, blk.node_dst_mlp.mlp[2].bias, residual=x), "mfma", 2.0 * N * hid * D),
     }
     if D == ops.CHAIN_CHANNELS and hid % ops.CHAIN_CHANNELS == 0 and dtype != torch.float32:
         # the row-resident chain: projection + LayerNorm + MLP + the next block's LayerNorm and q|k|v|self projection in ONE launch
@@ -140,6 +140,16 @@ def kernel_cases(model, g, args, dtype, device):
         cases["gt_layer_chain(proj+mlp+next qkvs)"] = (
             lambda: ops.gt_layer_chain(x, x, wp, bp, lnm.weight, lnm.bias, lnm.eps, w1, b1, w2, b2, lnq_w=ln.weight, lnq_b=ln.bias, lnq_eps=ln.eps, wq=wq, bq=bq),
             "mfma", 2.0 * N * (D * D + 2 * D * hid + D * 4 * D))
+        if ops.gt_layer_chain2_supported(x, hid, 4 * D):
+            # the role-split form (round 5: the default for blocks of >= 7 168 rows), the LayerNorms' affine parts folded into the weights
+            w1g, d1 = ops.fold_layer_norm(mlp.mlp[0].weight, mlp.mlp[0].bias, lnm.weight, lnm.bias)
+            wq4, bq4 = blk._fused.get("qkvs", [blk.lin_query, blk.lin_key, blk.lin_value, blk.lin_self])
+            wqg, dq = ops.fold_layer_norm(wq4, bq4, ln.weight, ln.bias)
+            vec = torch.cat([blk.projection.bias.float(), d1, mlp.mlp[2].bias.float(), dq]).to(dtype).contiguous()
+            w1gf, wqgf = ops.pack_weight_frag(w1g), ops.pack_weight_frag(wqg)
+            cases["gt_layer_chain2(proj+mlp+next qkvs, role-split)"] = (
+                lambda: ops.gt_layer_chain2(x, x, wp, w1gf, w2, vec, hid, lnm.eps, wqg=wqgf, q_out_features=4 * D, lnq_eps=ln.eps),
+                "mfma", 2.0 * N * (D * D + 2 * D * hid + D * 4 * D))
     return cases
 
 
@@ -247,6 +257,14 @@ def profile_forward(step, dtype, host_ms: float = 12.0):
         extra = 1 if kw.get("extra") is not None else 0
         return "gt_chain_kernel", 2.0 * N * (D * D + 2 * D * Hd + D * Oq), es * (N * D * (3 + extra) + N * Oq + D * D + 2 * D * Hd + D * Oq)
 
+    def chain2_work(res_, a_, kw):
+        # the role-split layer chain (csrc/gt_chain2.hip): the same work and compulsory bytes as chain_work (+ the per-column vectors)
+        attn, vec, Hd = a_[0], a_[5], a_[6]
+        N, D = attn.shape
+        Oq = kw.get("q_out_features", 0)
+        extra = 1 if kw.get("extra") is not None else 0
+        return "gt_chain2_kernel", 2.0 * N * (D * D + 2 * D * Hd + D * Oq), es * (N * D * (3 + extra) + N * Oq + D * D + 2 * D * Hd + D * Oq + vec.numel())
+
     def edge_chain_work(res_, a_, kw):
         # GraphConv's edge MLP (three [M x 512] -> 512 GEMMs in gather-add form) + LayerNorm + residual in one launch: e in, e' out,
         # the two gathered node-level rows per edge, the indices, every weight once
@@ -286,7 +304,7 @@ def profile_forward(step, dtype, host_ms: float = 12.0):
 
     table = {"linear": ("linear", lin_work), "gt_attention_fused_edge": ("attn", attn_work), "layer_norm": ("ln", ln_work),
              "linear_with_row_stats": ("linear_stats", gemm_work), "linear_ln_folded": ("linear_lnfold", gemm_work),
-             "gt_layer_chain": ("chain", chain_work), "gnn_edge_chain": ("edge_chain", edge_chain_work),
+             "gt_layer_chain": ("chain", chain_work), "gt_layer_chain2": ("chain2", chain2_work), "gnn_edge_chain": ("edge_chain", edge_chain_work),
              "gnn_node_chain": ("node_chain", node_chain_work), "gnn_mlp_chain": ("mlp_chain", mlp_chain_work), "segment_sum_rows": ("segrows", segrows_work),
              "edge_ln_residual_segment_sum": ("segsum", segsum_work), "gather_rows": ("gather", rows_work("gather_rows_kernel")),
              "gather_add_rows": ("gather_add", rows_work("gather_add_rows_kernel"))}
@@ -890,7 +908,11 @@ def main():
                     res["components"] = component_times(model, step, g.num_data, g.num_hidden, args.channels, args.layers, host_ms)
                 except Exception as e:  # noqa: BLE001  (an informational leg must never take the benchmark line down)
                     res["components"] = {"error": f"{type(e).__name__}: {e}"}
-            traffic, traffic_file = latest_traffic(args.config)
+            # committed traces / counter passes are per CONFIGURATION: a run at another width / depth / mesh has none to be compared with
+            cfg0 = CONFIGS[args.config]
+            ptag = args.config if (args.channels == 512 and args.layers == 16 and args.heads == 16 and args.hidden_res == cfg0.get("hidden_res")
+                                   and args.data_grid == cfg0.get("data_grid")) else f"{args.config}-c{args.channels}-l{args.layers}"
+            traffic, traffic_file = latest_traffic(ptag)
 
             def roof(name, bound):
                 d = fam[name]
@@ -923,14 +945,14 @@ def main():
                                       "= the same minus `bracket_overhead_us` per launch (48 bracketed launches of one small kernel against the "
                                       "same 48 back to back, same backed-up queue: an upper bound); `rocprof_cross_check` = the family's "
                                       "duration in the committed rocprofv3 --kernel-trace summary of the timed replays (profiles/)")
-            res["roofline"]["rocprof_cross_check"] = rocprof_cross_check(args.config, dom, fam[dom], "mfma" if fam[dom]["flops"] else "hbm")
+            res["roofline"]["rocprof_cross_check"] = rocprof_cross_check(ptag, dom, fam[dom], "mfma" if fam[dom]["flops"] else "hbm")
             # the gather / scatter side of the path: the attention (GraphTransformer); for GraphConv the scatter-sum, which since round 4
             # runs INSIDE the node chain launch (its bytes: the edge rows in, x in / out, the projection out, the weights once)
             gs = "gt_attn_fused_edge_fwd_kernel" if args.kind == "gt" else next(
                 (k for k in ("segment_sum_rows_kernel", "edge_ln_res_segsum_kernel", "gnn_node_chain_kernel") if k in fam), None)
             if gs in fam:
                 res["roofline"]["gather_scatter"] = roof(gs, "hbm")
-                res["roofline"]["gather_scatter"]["rocprof_cross_check"] = rocprof_cross_check(args.config, gs, fam[gs], "hbm")
+                res["roofline"]["gather_scatter"]["rocprof_cross_check"] = rocprof_cross_check(ptag, gs, fam[gs], "hbm")
                 if gs == "gnn_node_chain_kernel":
                     res["roofline"]["gather_scatter"]["note"] = ("GraphConv's scatter-sum inside the node MLP launch: a GEMM chain whose panel load is "
                                                                   "the segmented sum; the HBM figure prices the whole launch against its bytes")
