@@ -19,7 +19,7 @@ LIBPATH = os.path.join(LIBDIR, "libanemoi_hip.so")
 EXT_PATH = os.path.join(LIBDIR, "libanemoi_torch.so")
 INCLUDE = os.path.join(REPO, "include")
 
-SOURCES = ["lib.cpp", "gt_attention.hip", "gt_attention_bwd.hip", "rowwise.hip", "rowwise_bwd.hip", "linear.hip", "wgrad.hip", "peer.hip", "gt_chain.hip", "gt_chain2.hip", "gnn_chain.hip"]
+SOURCES = ["lib.cpp", "gt_attention.hip", "gt_attention_bwd.hip", "rowwise.hip", "rowwise_bwd.hip", "linear.hip", "wgrad.hip", "peer.hip", "gt_chain.hip", "gt_chain2.hip", "gnn_chain.hip", "gnn_chain2.hip"]
 ARCH = "gfx950"
 
 
@@ -42,7 +42,7 @@ def build_library(force: bool = False, verbose: bool = True, extra_flags: tuple[
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "chain_core.h"), os.path.join(INCLUDE, "anemoi_hip.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "chain_core.h"), os.path.join(CSRC, "chain2_core.h"), os.path.join(CSRC, "gnn_chain_args.h"), os.path.join(INCLUDE, "anemoi_hip.h")]
     flags = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I", INCLUDE, "-I", CSRC, "-Wall", "-Wno-unused-function", *extra_flags]
 
     def compile_one(src: str) -> str:

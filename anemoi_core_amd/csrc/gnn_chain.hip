@@ -17,25 +17,10 @@
 // (edge chain) / 2.5-3.5 MB (node chain) of weights through its CU's L1 instead of 6.5 MB, against launches whose K = N = 512
 // GEMMs sit on their fixed costs and on HBM round trips of the [M, 512] intermediates.
 #include "chain_core.h"
+#include "gnn_chain_args.h"
 
 namespace anemoi {
 
-struct EdgeChainArgs {
-  const void* e;   int64_t ld_e;            // [M, 512] edge features (A operand of the first GEMM and the residual)
-  const void* g1;  int64_t ld_g1; const int32_t* idx1;  // rows added in the first epilogue: g1[idx1[m]] (x W_i^T by destination)
-  const void* g2;  int64_t ld_g2; const int32_t* idx2;  //                                  g2[idx2[m]] (x W_j^T by source)
-  const char* w0;  const void* b0;          // fragment-major [512, 512] each
-  const char* w1;  const void* b1;
-  const char* w2;  const void* b2;
-  const void* ln_g; const void* ln_b; float ln_eps;
-  void* e_new;     int64_t ld_o;
-  int n_rows, rows_per_tile, n_tiles;
-  int dbg;  // experiment (timing only, results are garbage): bit 0 no GELU, bit 2 no gathered rows, bit 3 no global stores; bit 4 (results valid): alternating wave priorities
-  // the MLP instantiation (no gathered rows): y = LayerNorm(W_2 gelu(W_1 gelu(W_0 x + b_0) + b_1) + b_2) [+ res]
-  const void* res = nullptr; int64_t ld_res = 0;  // optional residual rows (the edge chain's residual is e itself)
-  int k0_groups = 4;                              // width of x / K of the first GEMM in units of 128 columns (w0: fragment-major [512, 128 k0_groups])
-  unsigned long long* timeline = nullptr;         // developer aid (TL instantiation): [workgroups][8 waves][kETlSlots] shader-clock stamps
-};
 constexpr int kETlSlots = 48;  // entry + 8 stamps per panel of a workgroup's first 5 panels (tools/edge_chain_timeline.py)
 
 // Edge panels are 64 rows (4 MFMA row bands): the same weight stream serves a third more rows than a 48-row panel would (81 840
@@ -619,6 +604,11 @@ extern "C" int anemoi_gnn_edge_chain_fwd(const void* e, int64_t ld_e, const void
                  "gnn_edge_chain_fwd: operand alignment / leading dimensions");
   EdgeChainArgs a{e, ld_e, g1, ld_g1, idx1, g2, ld_g2, idx2, (const char*)w0, b0, (const char*)w1, b1, (const char*)w2, b2, ln_w, ln_b, eps, e_new, ld_o,
                   n_rows, chain_rows_per_tile(n_rows, kERows), 0, 0};
+  // round 5: ANEMOI_GNN_CHAIN_V2=1 selects the two-group launch (gnn_chain2.hip): built, parity-green, and slower than the symmetric
+  // kernel below (212 against 195 us at 81 840 rows: its 40 / 48-row panels need 7-8 passes over the weights instead of 5,
+  // profiles/r05_gnn_edge_chain_role_split.txt) - kept for the A/B
+  static const int v2 = env_int(getenv("ANEMOI_GNN_CHAIN_V2"), 0, 0, 1);
+  if (v2) return launch_edge_chain2(a, dtype, stream, false);
   static const int dbg = env_int(getenv("ANEMOI_EDGE_CHAIN_DBG"), 0, 0, 31);
   a.dbg = dbg;
   a.n_tiles = (n_rows + a.rows_per_tile - 1) / a.rows_per_tile;
@@ -678,6 +668,8 @@ extern "C" int anemoi_gnn_mlp_chain_fwd(const void* x, int64_t ld_x, int32_t in_
   a.res = res;
   a.ld_res = ld_res;
   a.k0_groups = in_features / 128;
+  static const int v2 = env_int(getenv("ANEMOI_GNN_CHAIN_V2"), 0, 0, 1);
+  if (v2) return launch_edge_chain2(a, dtype, stream, true);
   a.n_tiles = (n_rows + a.rows_per_tile - 1) / a.rows_per_tile;
   const int grid = a.n_tiles < 256 ? a.n_tiles : 256;
   hipStream_t st = as_stream(stream);

@@ -479,3 +479,19 @@ def test_chain2_equals_round4_chain():
     e2, eq = (a2.float() - b2.float()).abs(), (aq.float() - bq.float()).abs()
     assert float(e2.max()) <= 2e-2 * float(a2.float().abs().max()) and float(e2.mean()) <= 2e-3 * float(a2.float().abs().mean() + 1)
     assert float(eq.max()) <= 3e-2 * float(aq.float().abs().max()) and float(eq.mean()) <= 4e-3 * float(aq.float().abs().mean() + 1)
+
+
+def test_gnn_two_group_chain_kernels_pass():
+    """Round 5 built the edge / embedding-MLP chains a second time on the role-split machinery (csrc/gnn_chain2.hip: two independent
+    four-wave groups per CU, each the whole chain in place on its own panel, LDS-counter group barriers) - parity-green and slower than
+    the symmetric kernels (profiles/r05_gnn_edge_chain_role_split.txt), so it sits behind ANEMOI_GNN_CHAIN_V2=1 (read once per
+    process): the same tests, in a process of their own."""
+    import os
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(repo, "tests", "test_chain_gpu.py"), "-x", "-q", "-k",
+                        "test_gnn_edge_chain_vs_fp32_restatement or test_embedding_mlp_chain"],
+                       capture_output=True, text=True, timeout=900, cwd=repo, env={**os.environ, "ANEMOI_GNN_CHAIN_V2": "1"})
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
