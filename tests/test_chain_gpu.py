@@ -154,6 +154,11 @@ def test_layernorm_under_offset_rows(offset_over_sigma):
     # x2 carries the offset (its scale grows with it); the projections see LayerNorm'd rows: their scale does not
     e2 = _close(x2, ref2, f"x2 offset {offset_over_sigma}")
     eq = _close(q, refq, f"qkvs offset {offset_over_sigma}", tol=2.5e-2)
+    # the role-split kernel (round 5): the same statistics from registers, the row normalised WITHOUT the affine part and rounded, the
+    # affine part in the rounded weights - no term that grows with the offset either
+    y2, yq = _run_chain2(ops, attn, x, p)
+    _close(y2, ref2, f"role-split x2 offset {offset_over_sigma}")
+    _close(yq, refq, f"role-split qkvs offset {offset_over_sigma}", tol=2.5e-2)
     # the fold path on the same rows: x1 with statistics, then LN folded into the MLP-1 GEMM
     d = lambda t: t.to(DEV)  # noqa: E731
     r = ops.linear_with_row_stats(d(attn), d(p["wp"]), d(p["bp"]), d(x))
