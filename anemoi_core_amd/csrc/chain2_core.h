@@ -252,4 +252,18 @@ __device__ __forceinline__ unsigned touch_share(const char* seg, int64_t piece, 
 // (the touched value must stay "in use" until the next touch: the compiler then keeps its register and counts the load)
 __device__ __forceinline__ void touch_done(unsigned& v) { asm volatile("" : "+v"(v)); }
 
+// A barrier among the FOUR waves of one group (the hardware barrier counts all eight): a monotonic LDS counter.  LDS operations of a
+// wave complete in order, so whoever sees a wave's increment sees what it wrote before.  Bounded: a miscount must not hang the GPU.
+__device__ __forceinline__ void group4_barrier(unsigned* ctr, unsigned& epoch, int lane) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  epoch += 4;
+  if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  for (int it = 0; it < (1 << 16); ++it) {
+    const unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    if ((int)(v - epoch) >= 0) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  asm volatile("" ::: "memory");
+}
+
 }  // namespace anemoi

@@ -25,20 +25,6 @@ constexpr int kG2CtrOff = kG2VecOff + 5 * kCh * 2;           // the counters of 
 constexpr int kG2Smem = kG2CtrOff + 32;
 static_assert(kG2Smem <= 160 * 1024, "LDS budget");
 
-// A barrier among the FOUR waves of one group (the hardware barrier counts all eight): a monotonic LDS counter.  LDS operations of a
-// wave complete in order, so whoever sees a wave's increment sees what it wrote before.  Bounded: a miscount must not hang the GPU.
-__device__ __forceinline__ void group4_barrier(unsigned* ctr, unsigned& epoch, int lane) {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  epoch += 4;
-  if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  for (int it = 0; it < (1 << 16); ++it) {
-    const unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-    if ((int)(v - epoch) >= 0) break;
-    __builtin_amdgcn_s_sleep(1);
-  }
-  asm volatile("" ::: "memory");
-}
-
 // 12 rows of `nslots` 16-byte slots each (a panel of a narrow first GEMM: K = 8 nslots) - load_rows12 with a width
 template <typename T>
 __device__ __forceinline__ void load_rows12_w(const T* src, int64_t ld, int r0, int nr, unsigned char* dst, int lane, int wq, int nslots) {

@@ -470,6 +470,30 @@ def test_chain2_variants(variant):
         _close(res[1], refq, variant + " q")
 
 
+@pytest.mark.parametrize("N,hidden,with_extra", [(30000, 2048, False), (50001, 2048, True), (30000, 1024, False), (30000, 1536, False)])
+def test_chain2_without_trailing_projection_over_several_panel_rounds(N, hidden, with_extra):
+    """a mapper-style tail (no trailing projection) with several panels per workgroup: from the second panel on the attention rows come
+    in during the step in which group A idles; odd and even chunk counts (x2 lands in either h buffer), with and without the latent skip"""
+    import tests.test_chain_gpu as me
+    from anemoi_core_amd import ops
+
+    dtype = torch.bfloat16
+    gen = torch.Generator().manual_seed(N + hidden)
+    old = me.HD
+    me.HD = hidden
+    try:
+        p = _params(gen, dtype, q_out=0)
+    finally:
+        me.HD = old
+    attn = torch.randn(N, D, generator=gen).to(dtype)
+    x = torch.randn(N, D, generator=gen).to(dtype)
+    extra = (2.0 * torch.randn(N, D, generator=gen)).to(dtype) if with_extra else None
+    got = _run_chain2(ops, attn, x, p, extra=extra)
+    ref2, _ = _reference(attn, x, p, dtype, extra=extra)
+    _close(got, ref2, f"x2 N={N} hidden={hidden}")
+    assert torch.equal(got, _run_chain2(ops, attn, x, p, extra=extra))
+
+
 def test_chain2_equals_round4_chain():
     """both chain kernels on the same block: equal to a few ulps of the output scale (different accumulation order, LayerNorm output
     rounded before / behind the affine part)"""
