@@ -190,6 +190,63 @@ def time_kernels(model, g, args, dtype, device):
     return out
 
 
+def gnn_scatter_sum_figure(model, g, dtype, device):
+    """GraphConv's scatter-sum (reference layers/conv.py:81) runs INSIDE the node chain launch (csrc/gnn_chain.hip: a wave sums the in-edge
+    rows of its panel rows while the panel loads), so it has no kernel of its own to bracket.  Its cost = the launch fed with the dst-sorted
+    EDGE rows + segment pointer MINUS the same launch fed with a precomputed [N, 512] table, both as hipGraph-captured back-to-back
+    launches at the processor's size; its bytes = the M x 512 edge rows it reads (the table it saves is never written)."""
+    from anemoi_core_amd import ops
+    from anemoi_core_amd.layers.conv import node_mlp_chain, DeferredAggregate
+    from anemoi_core_amd.layers.graphcache import get_csc
+
+    blk = model.processor.proc[0]
+    N, D = g.num_hidden, 512
+    ea, ei, _ = model.processor_graph_provider.get_edges(batch_size=1)
+    csc = get_csc(ei, (N, N), True)
+    M = csc.num_edges
+    x = torch.randn(N, D, device=device).to(dtype)
+    e = torch.randn(M, D, device=device).to(dtype)
+    table = ops.segment_sum_rows(e, csc.colptr)
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+        torch.cuda.current_stream().wait_stream(side)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            for _ in range(20):
+                fn()
+        gr.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(5):
+            gr.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / 100
+
+    us_seg = timed(lambda: node_mlp_chain(blk.node_mlp, x, DeferredAggregate(e, csc.colptr)))
+    us_tab = timed(lambda: node_mlp_chain(blk.node_mlp, x, table))
+    us_own = timed(lambda: ops.segment_sum_rows(e, csc.colptr))
+    es = torch.tensor([], dtype=dtype).element_size()
+    byts = es * M * D + 4 * (N + 1)
+    diff = max(us_seg - us_tab, 1e-3)
+    return {"kernel": "segmented sum of the edge rows inside gnn_node_chain_kernel", "bound": "hbm", "us_launch_with_sum": round(us_seg, 2),
+            "us_launch_table_fed": round(us_tab, 2), "us": round(diff, 2), "algorithmic_bytes": byts, "achieved": round(byts / diff / 1e3, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(byts / diff / 1e3 / HBM_PEAK_GBS, 4),
+            "own_launch": {"kernel": "segment_sum_rows_kernel", "us": round(us_own, 2), "bytes": byts + es * N * D,
+                           "achieved": round((byts + es * N * D) / us_own / 1e3, 1), "frac": round((byts + es * N * D) / us_own / 1e3 / HBM_PEAK_GBS, 4)},
+            "how": "difference of two hipGraph-captured launch series (20 launches x 5 replays each): the node chain fed with the edge rows + segment "
+                   "pointer against the same launch fed with a precomputed table; `own_launch` = the stand-alone segment-sum kernel it replaced (reads "
+                   "the rows, writes the table)"}
+
+
 def _backed_up_queue(ms: float = 12.0):
     """Back the queue up with a SLEEP kernel (no power draw, unlike a GEMM burst, which lowers the clocks for ms afterwards -
     tools/event_probe.py) so that the host is done enqueueing before the first kernel starts: every event pair then brackets
@@ -954,6 +1011,14 @@ def main():
                 res["roofline"]["gather_scatter"] = roof(gs, "hbm")
                 res["roofline"]["gather_scatter"]["rocprof_cross_check"] = rocprof_cross_check(ptag, gs, fam[gs], "hbm")
                 if gs == "gnn_node_chain_kernel":
+                    try:  # the scatter-sum's own figure: differential timing, the whole launch's line beside it
+                        whole = res["roofline"]["gather_scatter"]
+                        with torch.inference_mode():
+                            res["roofline"]["gather_scatter"] = gnn_scatter_sum_figure(model, g, dtype, device)
+                        res["roofline"]["gather_scatter"]["whole_launch"] = whole
+                    except Exception as e:  # noqa: BLE001
+                        res["roofline"]["gather_scatter"]["scatter_sum_error"] = f"{type(e).__name__}: {e}"
+                if gs == "gnn_node_chain_kernel" and "scatter_sum_error" in res["roofline"]["gather_scatter"]:
                     res["roofline"]["gather_scatter"]["note"] = ("GraphConv's scatter-sum inside the node MLP launch: a GEMM chain whose panel load is "
                                                                   "the segmented sum; the HBM figure prices the whole launch against its bytes")
         if world == 1 and not args.no_cpu_baseline:
