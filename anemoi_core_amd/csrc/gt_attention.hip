@@ -24,6 +24,9 @@ namespace anemoi {
 #define ANEMOI_ATTN_WPB 4
 #endif
 constexpr int kWavesPerBlock = ANEMOI_ATTN_WPB;
+#ifndef ANEMOI_ATTN_MIN_WAVES
+#define ANEMOI_ATTN_MIN_WAVES (16 / ANEMOI_ATTN_WPB)
+#endif
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 
 template <int VEC>
@@ -151,7 +154,7 @@ struct WLayout {
 // current destination is worked on.  Parity-green; 96 VGPRs + 2 spilled at 5 waves per SIMD (100 without the cap = 4 waves), and
 // the O96 forward went from 2.99-3.00 to 3.02-3.03 ms on the same box in two placements of the request.  Not kept.)
 template <typename T, int VEC, int LPH, int FE_PAD, bool KVADJ>
-__global__ __launch_bounds__(64 * kWavesPerBlock, 16 / kWavesPerBlock) void gt_attn_fused_edge_fwd_kernel(
+__global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt_attn_fused_edge_fwd_kernel(
     const T* __restrict__ q, int64_t ldq, const T* __restrict__ k, int64_t ldk, const T* __restrict__ v, int64_t ldv,
     const float* __restrict__ feat, const float* __restrict__ w_packed, const int32_t* __restrict__ row,
     const int32_t* __restrict__ colptr, const int32_t* __restrict__ order, const T* __restrict__ addend, int64_t ldadd,
