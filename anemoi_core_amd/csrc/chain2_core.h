@@ -9,6 +9,20 @@
 
 namespace anemoi {
 
+// Row streams (panel rows in, output rows out) are touched once per launch: with ANEMOI_CHAIN2_NT they carry the non-temporal hint, so
+// that in the XCD's L2 they do not push out the WEIGHTS, which all 32 CUs of the XCD read - and, in multi-round launches, read again.
+#ifndef ANEMOI_CHAIN2_NT
+#define ANEMOI_CHAIN2_NT 1
+#endif
+__device__ __forceinline__ u32x4 stream_load(const u32x4* p) {
+  if constexpr ((ANEMOI_CHAIN2_NT & 1) != 0) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+__device__ __forceinline__ void stream_store(u32x4 v, u32x4* p) {
+  if constexpr ((ANEMOI_CHAIN2_NT & 2) != 0) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
 // 16 K-steps (K = 512) of this wave's 48 x 128 tile.  A fragments from the swizzled LDS panel (the next K-step's requested before this
 // one's MFMAs), B fragments from a register ring of two K-steps x 8 fragments, each slot refilled right behind its three MFMAs with
 // the fragment of two K-steps ahead - of this segment or, in its last pair, of the wave's NEXT segment (`nxt`).  The wave's 128
@@ -201,7 +215,7 @@ __device__ __forceinline__ void load_rows12(const T* src, int64_t ld, int r0, in
 #pragma unroll
   for (int i = 0; i < 12; ++i) {
     const int row = wq * 12 + i;
-    v[i] = *reinterpret_cast<const u32x4*>(src + (int64_t)(r0 + min(row, nr - 1)) * ld + lane * 8);
+    v[i] = stream_load(reinterpret_cast<const u32x4*>(src + (int64_t)(r0 + min(row, nr - 1)) * ld + lane * 8));
   }
   __builtin_amdgcn_sched_barrier(0);
   between();  // (loads the caller wants queued BEHIND the rows)
@@ -234,7 +248,7 @@ __device__ __forceinline__ void store_staged(const unsigned char* strip, T* out,
   for (int it = 0; it < 12; ++it) {
     const int row = it * 4 + rl;
     const u32x4 v = *reinterpret_cast<const u32x4*>(strip + row * kRowBytes + (((wq * 16 + sl) ^ (row & 15)) << 4));
-    if (row < nr) *reinterpret_cast<u32x4*>(out + (int64_t)row * ld + wq * 128 + sl * 8) = v;
+    if (row < nr) stream_store(v, reinterpret_cast<u32x4*>(out + (int64_t)row * ld + wq * 128 + sl * 8));
   }
 }
 

@@ -225,7 +225,7 @@ __device__ __forceinline__ void role_a(const Chain2Args& a, Ctx2& c, unsigned ch
             const u32x2 hi = pack4<T>(p);
             v = u32x4{lo[0], lo[1], hi[0], hi[1]};
           }
-          *reinterpret_cast<u32x4*>((T*)a.xout + (int64_t)(r0 + row) * a.ld_out + l0 * 8) = v;
+          stream_store(v, reinterpret_cast<u32x4*>((T*)a.xout + (int64_t)(r0 + row) * a.ld_out + l0 * 8));
         }
       }
     }
