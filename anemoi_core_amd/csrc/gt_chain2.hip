@@ -123,8 +123,9 @@ __device__ __forceinline__ void role_a(const Chain2Args& a, Ctx2& c, unsigned ch
   auto hbuf = [&](int t) { return smem + (t & 1) * (2 * kBufBytes); };
   const int64_t s1 = kSlab;
   const char* const wpw = a.wp + (int64_t)(2 * wq) * kSlab;
-  auto w1c = [&](int k) { return a.w1 + (int64_t)(8 * k + 2 * wq) * kSlab; };
-  auto wqc = [&](int k) { return a.wq + (int64_t)(8 * k + 2 * wq) * kSlab; };
+  const int one = (a.dbg & 8) ? 0 : 1;  // (dbg & 8: every chunk reads chunk 0's weights - a 2-MB weight set that stays in the L2, timing experiments only)
+  auto w1c = [&](int k) { return a.w1 + (int64_t)(8 * k * one + 2 * wq) * kSlab; };
+  auto wqc = [&](int k) { return a.wq + (int64_t)(8 * k * one + 2 * wq) * kSlab; };
   frag8 ring[2][8];
   f32x4 acc[3][8];
   // the L2 warm-up: waves 0, 1 touch the CU's share of group A's next segment, waves 2, 3 of group B's (64 lines each)
@@ -268,8 +269,9 @@ __device__ __forceinline__ void role_b(const Chain2Args& a, Ctx2& c, unsigned ch
   const unsigned char* const vec = smem + kVecOff;
   auto hbuf = [&](int t) { return smem + (t & 1) * (2 * kBufBytes); };
   const int64_t s1 = kSlab, s2 = (int64_t)hc * kSlab;
-  auto w2c = [&](int k) { return a.w2 + (int64_t)(2 * wq) * s2 + (int64_t)k * kSlab; };
-  auto wqc = [&](int k) { return a.wq + (int64_t)(8 * k + 2 * wq) * kSlab; };
+  const int one = (a.dbg & 8) ? 0 : 1;
+  auto w2c = [&](int k) { return a.w2 + (int64_t)(2 * wq) * s2 + (int64_t)(k * one) * kSlab; };
+  auto wqc = [&](int k) { return a.wq + (int64_t)(8 * k * one + 2 * wq) * kSlab; };
   frag8 ring[2][8];
   f32x4 acc[3][8];
   lds_barrier();  // S0 is group A's (the attention rows)
@@ -422,7 +424,7 @@ extern "C" int anemoi_gt_chain2_fwd(const anemoi_gt_chain2_args_t* p, anemoi_dty
   a.timeline = reinterpret_cast<unsigned long long*>(p->timeline);
   static const int prio_a = env_int(getenv("ANEMOI_CHAIN2_PRIO_A"), 0, 0, 2);
   a.prio_a = prio_a;
-  static const int dbg = env_int(getenv("ANEMOI_CHAIN2_DBG"), 0, 0, 7);
+  static const int dbg = env_int(getenv("ANEMOI_CHAIN2_DBG"), 0, 0, 15);
   a.dbg = dbg;
   static const int prio_q = env_int(getenv("ANEMOI_CHAIN2_PRIO_Q"), 0, 0, 1);
   a.prio_q = prio_q;
