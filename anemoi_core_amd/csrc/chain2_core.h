@@ -9,8 +9,11 @@
 
 namespace anemoi {
 
-// Row streams (panel rows in, output rows out) are touched once per launch: with ANEMOI_CHAIN2_NT they carry the non-temporal hint, so
-// that in the XCD's L2 they do not push out the WEIGHTS, which all 32 CUs of the XCD read - and, in multi-round launches, read again.
+// Row streams (panel rows in, output rows out) are touched once per launch.  ANEMOI_CHAIN2_NT (build-time mask): 1 = the loads carry the
+// non-temporal hint, so that in the XCD's L2 they do not push out the WEIGHTS, which all 32 CUs of the XCD read - and, in multi-round
+// launches, read again (res 6 forward -2.4 %); 2 = the stores too (O96 +1.7 %: the attention launch behind reads them - off); 4 = the
+// stores write through (sc1) instead of sitting dirty in this XCD's L2 until the end of the kernel (O96 -0.4 % on one box, 0 on the next).
+// Default 1.
 #ifndef ANEMOI_CHAIN2_NT
 #define ANEMOI_CHAIN2_NT 1
 #endif
@@ -20,6 +23,7 @@ __device__ __forceinline__ u32x4 stream_load(const u32x4* p) {
 }
 __device__ __forceinline__ void stream_store(u32x4 v, u32x4* p) {
   if constexpr ((ANEMOI_CHAIN2_NT & 2) != 0) __builtin_nontemporal_store(v, p);
+  else if constexpr ((ANEMOI_CHAIN2_NT & 4) != 0) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");  // write-through
   else *p = v;
 }
 
