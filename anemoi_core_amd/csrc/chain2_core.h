@@ -263,12 +263,54 @@ __device__ __forceinline__ void store_staged(const unsigned char* strip, T* out,
 // epilogue that follows hides the latency; by the time a ring asks for the lines they are in the L2 (observed: workgroup b runs on XCD
 // b % 8, so b / 8 numbers the CUs of an XCD - for speed only: a different placement warms less, nothing depends on it).
 // A segment = the 512 x 512 weight of one group step: eight 64-KiB slabs `piece` bytes apart; `half` selects 64 of the CU's 128 lines.
-__device__ __forceinline__ unsigned touch_share(const char* seg, int64_t piece, int half, int lane) {
-  const int line = (((int)blockIdx.x >> 3) & 31) * 128 + half * 64 + lane;  // 0 .. 4095
-  return *reinterpret_cast<const unsigned*>(seg + (int64_t)(line >> 9) * piece + (line & 511) * 128);
+struct Warm {
+  unsigned v[3];
+  int first, end;  // PART: this lane's first line of the wave's share, one past the share's last line
+  int n_it;        // PART: loads per touch (wave-uniform)
+};
+// PART = false: all 256 CUs work, workgroup b touches the fixed 1/32 share (b >> 3) & 31 (observed: b runs on XCD b % 8), its line recomputed
+// from the workgroup id at every touch (nothing kept live).  PART = true (a launch of fewer than 256 workgroups): the launch's workgroups on
+// my XCD share the segment's 4096 lines out among themselves - ALL of them (10 242 rows = 214 panels of 48: 26 or 27 CUs per XCD; with a
+// fixed 1/32 share each, 16 % of every weight stayed cold: the O96 forward 2.81 instead of 2.55 ms, profiles/r05_chain2_touch_coverage.txt).
+// Two waves per share (`half`), up to 192 lines per wave = full coverage from 11 workgroups per XCD on; the bounds are computed once per kernel.
+template <bool PART>
+__device__ __forceinline__ void warm_init(Warm& w, int half, int lane) {
+  w.v[0] = w.v[1] = w.v[2] = 0u;
+  if constexpr (PART) {
+    const int xcd = (int)blockIdx.x & 7;
+    const int n_cu = ((int)gridDim.x - xcd + 7) >> 3;
+    const int s = (int)blockIdx.x >> 3;
+    const int lo = (s * 4096) / n_cu, hi = ((s + 1) * 4096) / n_cu;
+    const int mid = lo + ((hi - lo + 1) >> 1);
+    w.first = (half ? mid : lo) + lane;
+    w.end = half ? hi : mid;
+    w.n_it = __builtin_amdgcn_readfirstlane((w.end - (half ? mid : lo) + 63) >> 6);
+  }
 }
-// (the touched value must stay "in use" until the next touch: the compiler then keeps its register and counts the load)
-__device__ __forceinline__ void touch_done(unsigned& v) { asm volatile("" : "+v"(v)); }
+template <bool PART>
+__device__ __forceinline__ void touch_share(Warm& w, const char* seg, int64_t piece, int half, int lane) {
+  if constexpr (!PART) {
+    const int line = (((int)blockIdx.x >> 3) & 31) * 128 + half * 64 + lane;  // 0 .. 4095
+    w.v[0] = *reinterpret_cast<const unsigned*>(seg + (int64_t)(line >> 9) * piece + (line & 511) * 128);
+  } else {
+    int line = w.first;
+    asm volatile("" : "+v"(line));  // (else the line addresses of every call site are computed up front and live - spilled - through the kernel)
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+      if (it < w.n_it) {  // (wave-uniform)
+        const int l = min(line, w.end - 1);  // (lanes beyond the share re-touch its last line: no divergence)
+        w.v[it] = *reinterpret_cast<const unsigned*>(seg + (int64_t)(l >> 9) * piece + (l & 511) * 128);
+        line += 64;
+      }
+    }
+  }
+}
+// (the touched values must stay "in use" until the next touch: the compiler then keeps their registers and counts the loads)
+template <bool PART>
+__device__ __forceinline__ void touch_done(Warm& w) {
+  if constexpr (PART) asm volatile("" : "+v"(w.v[0]), "+v"(w.v[1]), "+v"(w.v[2]));
+  else asm volatile("" : "+v"(w.v[0]));
+}
 
 // A barrier among the FOUR waves of one group (the hardware barrier counts all eight): a monotonic LDS counter.  LDS operations of a
 // wave complete in order, so whoever sees a wave's increment sees what it wrote before.  Bounded: a miscount must not hang the GPU.

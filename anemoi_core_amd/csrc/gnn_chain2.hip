@@ -210,16 +210,17 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain2_kernel(EdgeChainArgs a
   }
   if (tid < 8) reinterpret_cast<unsigned*>(smem + kG2CtrOff)[tid] = 0u;
   // L2 warm-up: this CU's 1/32 share of the three weights (chain2_core.h)
-  unsigned warm = 0;
+  Warm warm;
+  warm_init<false>(warm, wave & 1, lane);
   if (wave >= 2) {
     const int which = (wave - 2) >> 1;
     const char* seg = which == 0 ? a.w0 : which == 1 ? a.w1 : a.w2;
-    if (which > 0 || !MLP || a.k0_groups == 4) warm = touch_share(seg, kSlab, wave & 1, lane);
+    if (which > 0 || !MLP || a.k0_groups == 4) touch_share<false>(warm, seg, kSlab, wave & 1, lane);
   }
   lds_barrier();  // the ONE workgroup barrier: the vectors and the counters
   edge_group_chain<T, MLP>(a, smem + grp * kBufBytes, reinterpret_cast<float*>(smem + kG2RedOff) + grp * (kPanel * 8), smem + kG2VecOff,
                            reinterpret_cast<unsigned*>(smem + kG2CtrOff) + grp * 4, (int)blockIdx.x * 2 + grp, lane, wq);
-  touch_done(warm);
+  touch_done<false>(warm);
 }
 
 template <typename T, bool MLP>

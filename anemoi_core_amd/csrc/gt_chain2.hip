@@ -111,7 +111,7 @@ __device__ __forceinline__ void set_chunk_prio(int on, int k) {
 
 // Both roles execute the SAME number of s_barrier per panel (the hardware barrier counts arrivals, not program locations):
 // S0 | P GEMM | x1 | S2 | hc + 1 MLP steps | S8 | one behind the trailing projection (if any).
-template <typename T, bool TL>
+template <typename T, bool TL, bool PART>
 __device__ __forceinline__ void role_a(const Chain2Args& a, Ctx2& c, unsigned char* smem) {
   const int hc = a.hc, qc = a.qc, lane = c.lane, wq = __builtin_amdgcn_readfirstlane(c.wq);
   // bufA: the even hidden chunks (x2 / group A's staged projection outputs when hc is even); bufB: the A operand of P, M1 and the
@@ -131,12 +131,13 @@ __device__ __forceinline__ void role_a(const Chain2Args& a, Ctx2& c, unsigned ch
   // the L2 warm-up: waves 0, 1 touch the CU's share of group A's next segment, waves 2, 3 of group B's (64 lines each)
   const int64_t sw2 = (int64_t)hc * kSlab;
   auto seg_a = [&](int t) { return t < hc ? a.w1 + (int64_t)(8 * t) * kSlab : (qc > 0 ? a.wq : a.wp); };  // M1(t); behind the last chunk: Q0 / the next panel's P
-  unsigned warm = 0;
+  Warm warm;
+  warm_init<PART>(warm, wq & 1, lane);
   auto touch = [&](const char* sa, const char* sb, int64_t pb) {
-    touch_done(warm);
+    touch_done<PART>(warm);
     if (!a.warm) return;
-    if (wq < 2) { if (sa != nullptr) warm = touch_share(sa, kSlab, wq & 1, lane); }
-    else if (sb != nullptr) warm = touch_share(sb, pb, wq & 1, lane);
+    if (wq < 2) { if (sa != nullptr) touch_share<PART>(warm, sa, kSlab, wq & 1, lane); }
+    else if (sb != nullptr) touch_share<PART>(warm, sb, pb, wq & 1, lane);
   };
   // S0 of the first panel (peeled: straight-line code, so that the stores of the rows wait for the rows only): the attention rows ->
   // bufB, requested AHEAD of the vectors, the warm-up and the weight ring's first fragments - loads return in order
@@ -146,7 +147,7 @@ __device__ __forceinline__ void role_a(const Chain2Args& a, Ctx2& c, unsigned ch
       stamp2<TL>(c, smem);  // rows requested
       ring_prologue(ring, wpw, s1, c.loff);
       // this CU's share of the projection's weights (waves 0, 1) and of M1(0)'s (waves 2, 3)
-      if (a.warm) warm = touch_share(wq < 2 ? a.wp : a.w1, kSlab, wq & 1, lane);
+      if (a.warm) touch_share<PART>(warm, wq < 2 ? a.wp : a.w1, kSlab, wq & 1, lane);
       stamp2<TL>(c, smem);  // everything requested
     });
     stamp2<TL>(c, smem);  // rows stored
@@ -255,7 +256,7 @@ __device__ __forceinline__ void role_a(const Chain2Args& a, Ctx2& c, unsigned ch
       lds_barrier();
     }
   }
-  touch_done(warm);
+  touch_done<PART>(warm);
 }
 
 template <typename T, bool TL>
@@ -340,7 +341,9 @@ __device__ __forceinline__ void role_b(const Chain2Args& a, Ctx2& c, unsigned ch
   }
 }
 
-template <typename T, bool TL = false>
+// PART: the launch has fewer than 256 workgroups (one round, not every CU busy): the L2 warm-up's shares follow the workgroup count.  Its own
+// instantiation, so that full-grid (multi-round) launches run the code they were tuned with (the general form costs them 1.5 %, same box).
+template <typename T, bool TL = false, bool PART = false>
 __global__ __launch_bounds__(512, 1) void gt_chain2_kernel(Chain2Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -354,7 +357,7 @@ __global__ __launch_bounds__(512, 1) void gt_chain2_kernel(Chain2Args a) {
   if ((int)blockIdx.x >= a.n_tiles) return;
   if (c.wave < 4) {
     if (a.prio_a == 2) __builtin_amdgcn_s_setprio(2);
-    role_a<T, TL>(a, c, smem);
+    role_a<T, TL, PART>(a, c, smem);
   } else {
     role_b<T, TL>(a, c, smem);
   }
@@ -371,6 +374,7 @@ static int launch_chain2(const Chain2Args& a, hipStream_t st) {
   static PerDeviceOnce attr_once;
   attr_once.run([&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gt_chain2_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, kChain2Smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gt_chain2_kernel<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kChain2Smem);
   });
   const int grid = a.n_tiles < 256 ? a.n_tiles : 256;
   if (a.timeline != nullptr) {
@@ -381,7 +385,8 @@ static int launch_chain2(const Chain2Args& a, hipStream_t st) {
     hipLaunchKernelGGL((gt_chain2_kernel<T, true>), dim3(grid), dim3(512), kTl2Off + 8 * kTl2Slots * 8, st, a);
     return check_launch("gt_chain2_kernel<timeline>");
   }
-  hipLaunchKernelGGL((gt_chain2_kernel<T>), dim3(grid), dim3(512), kChain2Smem, st, a);
+  if (grid < 256) hipLaunchKernelGGL((gt_chain2_kernel<T, false, true>), dim3(grid), dim3(512), kChain2Smem, st, a);
+  else hipLaunchKernelGGL((gt_chain2_kernel<T>), dim3(grid), dim3(512), kChain2Smem, st, a);
   return check_launch("gt_chain2_kernel");
 }
 

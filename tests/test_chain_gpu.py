@@ -74,7 +74,7 @@ def test_pack_weight_frag_layout():
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("N,rows_per_tile", [(41, 0), (7, 0), (1000, 0), (10242, 0), (10242, 48), (12345, 17), (40962, 0)])
+@pytest.mark.parametrize("N,rows_per_tile", [(41, 0), (7, 0), (1000, 0), (10242, 0), (10242, 41), (12345, 17), (40962, 0)])
 def test_chain_vs_fp32_restatement(dtype, N, rows_per_tile):
     """every output row of x2 and of the trailing projection, ragged last panels, several panels per workgroup (40 962 rows =
     4 rounds), panel heights that are no multiple of the 16-row MFMA band."""
@@ -422,7 +422,7 @@ def _run_chain2(ops, attn, x, p, extra=None, rows_per_tile=0):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("N,rows_per_tile", [(41, 0), (7, 0), (1, 0), (1000, 0), (10242, 0), (10242, 48), (12345, 17), (40962, 0)])
+@pytest.mark.parametrize("N,rows_per_tile", [(41, 0), (7, 0), (1, 0), (1000, 0), (10242, 0), (10242, 41), (12345, 17), (40962, 0)])
 def test_chain2_vs_fp32_restatement(dtype, N, rows_per_tile):
     """the role-split kernel against the same fp32 restatement (the reference's rounding points; its LayerNorm output is rounded WITH the
     affine part, the kernel's without - the affine part rides in the rounded weights): every row of x2 and of the trailing projection,
