@@ -376,7 +376,15 @@ static int launch_chain2(const Chain2Args& a, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gt_chain2_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, kChain2Smem);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gt_chain2_kernel<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kChain2Smem);
   });
-  const int grid = a.n_tiles < 256 ? a.n_tiles : 256;
+  // Several rounds: as many workgroups as make the rounds even (854 panels: 4 rounds of 214 instead of 3 of 256 + 86) - the CUs of an XCD share
+  // that L2's bandwidth, so a round of 27 CUs per XCD is faster than one of 32 (ANEMOI_CHAIN2_EVEN_GRID=0: always 256)
+  static const int even_grid = env_int(getenv("ANEMOI_CHAIN2_EVEN_GRID"), 1, 0, 1);
+  int grid = a.n_tiles < 256 ? a.n_tiles : 256;
+  static const int max_grid = env_int(getenv("ANEMOI_CHAIN2_MAX_GRID"), 256, 8, 256);  // (experiments: fewer CUs per round)
+  if (even_grid && a.n_tiles > 256) {
+    const int rounds = (a.n_tiles + max_grid - 1) / max_grid;
+    grid = (a.n_tiles + rounds - 1) / rounds;
+  }
   if (a.timeline != nullptr) {
     static PerDeviceOnce tl_once;
     tl_once.run([&] {
