@@ -57,7 +57,10 @@ _LAYER_CHAIN_V2 = os.environ.get("ANEMOI_LAYER_CHAIN_V2", "1") != "0"
 # its 48 rows, and few CUs are busy) while the GEMM launches shrink with the rows: 2 562 hidden nodes 1.91 ms per forward on the launches
 # against 2.30 ms on the chain, 642 nodes 1.67 / 2.36 ms - and a rank's share of a sharded mesh is that small.  The round-4 kernel keeps
 # its gate (>= 100 000 rows).  ANEMOI_LAYER_CHAIN=1: every eligible block; =0: never; ANEMOI_LAYER_CHAIN_MIN_ROWS: the gate.
-_LAYER_CHAIN_MIN_ROWS = int(os.environ.get("ANEMOI_LAYER_CHAIN_MIN_ROWS", "0" if _chain_env == "1" else ("7168" if _LAYER_CHAIN_V2 else "100000")))
+# Since the L2 warm-up's shares follow the workgroup count (every weight line warm at any grid size) the break-even sits near 4 200 rows:
+# a rank's share of the res-5 mesh at 2 ranks (5 121 + 277 rows) 2.39 -> 2.16 ms per forward on the chain, at 4 ranks (2 561 + 260 rows)
+# 1.59 -> 1.84 ms (tools/rank_floor.py, profiles/r05_rank_floor_gate.txt) - the gate moved from 7 168 to 4 096 rows.
+_LAYER_CHAIN_MIN_ROWS = int(os.environ.get("ANEMOI_LAYER_CHAIN_MIN_ROWS", "0" if _chain_env == "1" else ("4096" if _LAYER_CHAIN_V2 else "100000")))
 
 
 _IDENTITY: dict = {}

@@ -141,7 +141,7 @@ def kernel_cases(model, g, args, dtype, device):
             lambda: ops.gt_layer_chain(x, x, wp, bp, lnm.weight, lnm.bias, lnm.eps, w1, b1, w2, b2, lnq_w=ln.weight, lnq_b=ln.bias, lnq_eps=ln.eps, wq=wq, bq=bq),
             "mfma", 2.0 * N * (D * D + 2 * D * hid + D * 4 * D))
         if ops.gt_layer_chain2_supported(x, hid, 4 * D):
-            # the role-split form (round 5: the default for blocks of >= 7 168 rows), the LayerNorms' affine parts folded into the weights
+            # the role-split form (round 5: the default for blocks of >= 4 096 rows), the LayerNorms' affine parts folded into the weights
             w1g, d1 = ops.fold_layer_norm(mlp.mlp[0].weight, mlp.mlp[0].bias, lnm.weight, lnm.bias)
             wq4, bq4 = blk._fused.get("qkvs", [blk.lin_query, blk.lin_key, blk.lin_value, blk.lin_self])
             wqg, dq = ops.fold_layer_norm(wq4, bq4, ln.weight, ln.bias)

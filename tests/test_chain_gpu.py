@@ -201,7 +201,7 @@ def test_model_with_chain_equals_model_without():
     outs = {}
     saved = (B._LAYER_CHAIN, B._LAYER_CHAIN_MIN_ROWS, B._LAYER_CHAIN_V2)
     for flag in ("role-split", "round-4", "off"):
-        # (by default only blocks of >= 7 168 rows take the chain; this mesh has 642 hidden nodes)
+        # (by default only blocks of >= 4 096 rows take the chain; this mesh has 642 hidden nodes)
         B._LAYER_CHAIN, B._LAYER_CHAIN_MIN_ROWS, B._LAYER_CHAIN_V2 = flag != "off", 0, flag == "role-split"
         try:
             with torch.no_grad():
