@@ -389,8 +389,10 @@ static int launch_chain2(const Chain2Args& a, hipStream_t st) {
     static PerDeviceOnce tl_once;
     tl_once.run([&] {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gt_chain2_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kTl2Off + 8 * kTl2Slots * 8);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gt_chain2_kernel<T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kTl2Off + 8 * kTl2Slots * 8);
     });
-    hipLaunchKernelGGL((gt_chain2_kernel<T, true>), dim3(grid), dim3(512), kTl2Off + 8 * kTl2Slots * 8, st, a);
+    if (grid < 256) hipLaunchKernelGGL((gt_chain2_kernel<T, true, true>), dim3(grid), dim3(512), kTl2Off + 8 * kTl2Slots * 8, st, a);
+    else hipLaunchKernelGGL((gt_chain2_kernel<T, true>), dim3(grid), dim3(512), kTl2Off + 8 * kTl2Slots * 8, st, a);
     return check_launch("gt_chain2_kernel<timeline>");
   }
   if (grid < 256) hipLaunchKernelGGL((gt_chain2_kernel<T, false, true>), dim3(grid), dim3(512), kChain2Smem, st, a);
