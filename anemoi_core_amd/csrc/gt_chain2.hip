@@ -57,6 +57,7 @@ struct Chain2Args {
   int prio_q;                               // experiment: chunk-ordered priorities in the trailing projection
   int dbg;                                  // experiment (timing only, results are garbage): bit 0 no GELU arithmetic, 1 no LayerNorm statistics / normalisation, 2 no stores of the trailing projection
   int warm;                                 // the L2 warm-up of the next step's weights (ANEMOI_CHAIN2_WARM=0: off, for the A/B)
+  int b_delay;                              // group B's head start handicap in the dual MLP steps, units of ~0.5 us (ANEMOI_CHAIN2_B_DELAY)
   unsigned long long* timeline;             // developer aid (TL instantiation only): [workgroups][8 waves][kTl2Slots] s_memtime stamps
 };
 constexpr int kTl2Slots = 48;
@@ -308,6 +309,10 @@ __device__ __forceinline__ void role_b(const Chain2Args& a, Ctx2& c, unsigned ch
       stamp2<TL>(c, smem);
       const char* nxt = t < hc ? w2c(t) : (qc > 1 ? wqc(1) : w2c(0));
       const int64_t ns = (t < hc || qc <= 1) ? s2 : s1;
+      // In the dual steps group A is the critical path (its GEMM, then its GELU) while both groups pull weights through the same memory pipe:
+      // this group starts its stream a little later, so that A's GEMM gets the pipe first and A's GELU runs beside the bulk of THIS GEMM
+      if (t < hc)
+        for (int i = 0; i < a.b_delay; ++i) __builtin_amdgcn_s_sleep(16);  // ~0.5 us each
       gemm128<T>(hbuf(t - 1), lane, ring, w2c(t - 1), s2, nxt, ns, c.loff, acc);
       stamp2<TL>(c, smem);
       if (t == hc) {  // x2 (rounded) -> the h buffer nobody reads any more, for group A to store
@@ -445,6 +450,8 @@ extern "C" int anemoi_gt_chain2_fwd(const anemoi_gt_chain2_args_t* p, anemoi_dty
   a.prio_q = prio_q;
   static const int warm = env_int(getenv("ANEMOI_CHAIN2_WARM"), 1, 0, 1);
   a.warm = warm;
+  static const int b_delay = env_int(getenv("ANEMOI_CHAIN2_B_DELAY"), 0, 0, 40);
+  a.b_delay = b_delay;
   a.n_rows = p->n_rows;
   a.rows_per_tile = p->rows_per_tile > 0 ? p->rows_per_tile : anemoi_gt_chain_rows_per_tile(p->n_rows);
   ANEMOI_REQUIRE(a.rows_per_tile <= kPanel, "gt_chain2_fwd: rows_per_tile=%d exceeds the %d-row panel", a.rows_per_tile, kPanel);
