@@ -28,6 +28,13 @@ constexpr int kWavesPerBlock = ANEMOI_ATTN_WPB;
 #define ANEMOI_ATTN_MIN_WAVES (16 / ANEMOI_ATTN_WPB)
 #endif
 using f32x2 = __attribute__((ext_vector_type(2))) float;
+// Timing-only ablations of the fused-edge kernel (tools/ab_attn_ablate.sh; results are WRONG with any bit set, default 0):
+// 1 = no qw set-up per destination, 2 = no W' * sum(p a) at the end, 4 = no per-edge feature terms (score, sums, scalar loads),
+// 16 = no W' staging, 32 = every edge gathers source row 0 (no cache misses in the gather).
+#ifndef ANEMOI_ATTN_DBG
+#define ANEMOI_ATTN_DBG 0
+#endif
+constexpr int kAttnDbg = ANEMOI_ATTN_DBG;
 
 template <int VEC>
 struct EdgeRow {
@@ -166,7 +173,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt
 
   // Stage W' = [W_e | b_e | 0] (fp32 [D][FE_PAD], packed once on the host side of the ABI) into LDS: all 16-byte
   // loads are issued before the first write (one memory round trip per workgroup).
-  {
+  if constexpr (!(kAttnDbg & 16)) {
     constexpr int kQ = FE_PAD / 4;                 // float4 per channel row
     constexpr int kTotal = 64 * VEC * kQ;          // float4 in the image
     constexpr int kIter = (kTotal + 64 * kWavesPerBlock - 1) / (64 * kWavesPerBlock);
@@ -237,6 +244,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt
       // W' is stored [feature][channel] per lane: the VEC channels of a feature are contiguous (16-byte LDS reads) and
       // the channel pairs map onto packed FMAs without shuffles, here and in the final W' * sum(p a)
       float t = 0.f;
+      if constexpr (kAttnDbg & 1) {
+        qw[f] = qv[f % VEC];
+        sf[f] = 0.f;
+        continue;
+      }
       if constexpr (VEC % 2 == 0) {
         f32x2 t2 = {0.f, 0.f};
 #pragma unroll
@@ -262,7 +274,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt
       auto fetch = [&](int j, Raw& kr, Raw& vr, float (&fr)[FE_PAD]) {
         j = min(j, n - 1);  // refills past the end re-read the last edge: an UNCONDITIONAL load keeps the ring registers
                             // free of select/copy code (a conditional one made the compiler wait for the load at once)
-        const int s = __builtin_amdgcn_readlane(my_src, j);
+        const int s = (kAttnDbg & 32) ? (__builtin_amdgcn_readlane(my_src, j) & 1) : __builtin_amdgcn_readlane(my_src, j);
         const float* a;  // wave-uniform address -> scalar loads
         if constexpr (KVADJ) {
           // v = the D columns after k in the same buffer (the fused projection's layout): ONE address and an immediate
@@ -277,8 +289,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt
           vr = *reinterpret_cast<const Raw*>(v + (int64_t)s * ldv + c0);
           a = feat + (int64_t)(chunk + j) * FE_PAD;
         }
+        if constexpr (!(kAttnDbg & 4)) {
 #pragma unroll
-        for (int f = 0; f < FE_PAD; ++f) fr[f] = a[f];
+          for (int f = 0; f < FE_PAD; ++f) fr[f] = a[f];
+        }
       };
 #pragma unroll
       for (int st = 0; st < PF; ++st) fetch(st, kb[st], vb[st], fb[st]);
@@ -288,7 +302,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt
           const int j = j0 + st;
           if (j < n) {
             float dot = dot_rows<T, VEC>(q_raw, kb[st]);
-            if constexpr (FE_PAD % 2 == 0) {  // feature pairs on packed FMAs (scalar-register pairs as loaded)
+            if constexpr (kAttnDbg & 4) {
+            } else if constexpr (FE_PAD % 2 == 0) {  // feature pairs on packed FMAs (scalar-register pairs as loaded)
               f32x2 d2[2] = {{dot, 0.f}, {0.f, 0.f}};  // two chains: dependent packed FMAs back to back cost a wait state each
 #pragma unroll
               for (int f = 0; f < FE_PAD; f += 2)
@@ -314,8 +329,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt
             l += p;
 #pragma unroll
             for (int jj = 0; jj < VEC; ++jj) acc[jj] = fmaf(p, to_float(vb[st].v[jj]), acc[jj]);
+            if constexpr (!(kAttnDbg & 4)) {
 #pragma unroll
-            for (int f = 0; f < FE_PAD; ++f) sf[f] = fmaf(p, fb[st][f], sf[f]);
+              for (int f = 0; f < FE_PAD; ++f) sf[f] = fmaf(p, fb[st][f], sf[f]);
+            }
             fetch(j + PF, kb[st], vb[st], fb[st]);
           }
         }
@@ -330,7 +347,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt
 #pragma unroll
       for (int j = 0; j < VEC; j += 2) o2[j / 2] = f32x2{acc[j], acc[j + 1]};
 #pragma unroll
-      for (int f = 0; f < FE_PAD; ++f) {
+      for (int f = 0; f < ((kAttnDbg & 2) ? 0 : FE_PAD); ++f) {
         const f32x2 s2 = {sf[f], sf[f]};
 #pragma unroll
         for (int j = 0; j < VEC; j += 2) o2[j / 2] = __builtin_elementwise_fma(s2, *reinterpret_cast<const f32x2*>(wl + f * VEC + j), o2[j / 2]);
