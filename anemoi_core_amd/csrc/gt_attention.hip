@@ -28,6 +28,10 @@ constexpr int kWavesPerBlock = ANEMOI_ATTN_WPB;
 #define ANEMOI_ATTN_MIN_WAVES (16 / ANEMOI_ATTN_WPB)
 #endif
 using f32x2 = __attribute__((ext_vector_type(2))) float;
+// Where a destination's loads are requested (profiles/r05_attention_header_ab.txt, same-box A/Bs): the source ids travel WITH the q slice,
+// ahead of the qw set-up (-6 % of the launch), and the scalar part of the next header one destination ahead (ANEMOI_ATTN_SCALAR_PF).
+// ANEMOI_ATTN_EARLY_HDR (first header beside the W' staging) and ANEMOI_ATTN_EARLY_RING (1: first K|V ring fill, 2: its K slices only,
+// ahead of the qw set-up) were built and measured slower - they cost the fifth resident wave or spill - and default to 0.
 // Timing-only ablations of the fused-edge kernel (tools/ab_attn_ablate.sh; results are WRONG with any bit set, default 0):
 // 1 = no qw set-up per destination, 2 = no W' * sum(p a) at the end, 4 = no per-edge feature terms (score, sums, scalar loads),
 // 16 = no W' staging, 32 = every edge gathers source row 0 (no cache misses in the gather).
@@ -35,6 +39,25 @@ using f32x2 = __attribute__((ext_vector_type(2))) float;
 #define ANEMOI_ATTN_DBG 0
 #endif
 constexpr int kAttnDbg = ANEMOI_ATTN_DBG;
+#ifndef ANEMOI_ATTN_EARLY_HDR
+#define ANEMOI_ATTN_EARLY_HDR 0
+#endif
+constexpr bool kEarlyHdr = ANEMOI_ATTN_EARLY_HDR != 0;
+#ifndef ANEMOI_ATTN_EARLY_RING
+#define ANEMOI_ATTN_EARLY_RING 0
+#endif
+constexpr int kEarlyRing = ANEMOI_ATTN_EARLY_RING;
+#ifndef ANEMOI_ATTN_QW_GROUP
+#define ANEMOI_ATTN_QW_GROUP 4
+#endif
+constexpr int kQwGroup = ANEMOI_ATTN_QW_GROUP;
+#ifndef ANEMOI_ATTN_SCALAR_PF
+#define ANEMOI_ATTN_SCALAR_PF 1
+#endif
+constexpr bool kScalarPf = ANEMOI_ATTN_SCALAR_PF != 0;
+#ifndef ANEMOI_ATTN_PF
+#define ANEMOI_ATTN_PF 3
+#endif
 
 template <int VEC>
 struct EdgeRow {
@@ -171,6 +194,41 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt
   const int lane = threadIdx.x & 63;
   const int c0 = lane * VEC;
 
+  // XCD-aware persistent schedule.  Workgroup b runs on XCD b % 8 (observed dispatch order; only speed depends on
+  // it).  Each XCD gets one CONTIGUOUS slice of the destination range, so the K/V rows its waves gather (the mesh
+  // neighbourhood of that slice: nodes are latitude/longitude sorted) stay resident in that XCD's 4 MiB L2 instead of
+  // every L2 pulling every row from the fabric (8x the traffic).  Inside a slice, waves take destinations round-robin.
+  const int xcd = blockIdx.x & 7;
+  const int blocks_in_xcd = (gridDim.x - xcd + 7) >> 3;
+  const int waves_in_xcd = blocks_in_xcd * kWavesPerBlock;
+  const int wave_in_xcd = __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * kWavesPerBlock + (threadIdx.x >> 6));
+  const int per_xcd = (n_dst + 7) >> 3;
+  const int d_lo = xcd * per_xcd;
+  const int d_hi = min(n_dst, d_lo + per_xcd);
+
+  using Raw = Vec<T, VEC>;  // a row slice as loaded (converted to fp32 only when consumed)
+  // The header of a destination: its id, its edge range, its q row slice and the source ids of its first 64 in-edges.  The FIRST
+  // destination's header is requested beside the W' staging loads (ANEMOI_ATTN_EARLY_HDR, default on): its two dependent trips
+  // (colptr -> source ids) overlap the staging round trip instead of following the workgroup barrier.
+  const int i0 = d_lo + wave_in_xcd;
+  int h_d = 0, h_beg = 0, h_end = 0, h_src = 0;
+  Raw h_q;
+  auto load_scalars = [&](int i, int& d, int& beg, int& end) {
+    d = order ? __builtin_amdgcn_readfirstlane(order[i]) : i;
+    beg = __builtin_amdgcn_readfirstlane(colptr[d]);
+    end = __builtin_amdgcn_readfirstlane(colptr[d + 1]);
+  };
+  auto load_header = [&](int i, int& d, int& beg, int& end, Raw& qr, int& src) {
+    if constexpr (!kScalarPf) load_scalars(i, d, beg, end);
+    qr = *reinterpret_cast<const Raw*>(q + (int64_t)d * ldq + c0);
+    src = (lane < end - beg) ? row[beg + lane] : 0;
+  };
+  // ANEMOI_ATTN_SCALAR_PF: the scalar part of a header (id, edge range: scalar registers only) is requested one destination ahead -
+  // the first one's in front of the W' staging - so that a destination starts with its q slice and source ids, not with colptr.
+  int n_d = 0, n_beg = 0, n_end = 0;
+  if constexpr (kScalarPf) {
+    if (i0 < d_hi) load_scalars(i0, n_d, n_beg, n_end);
+  }
   // Stage W' = [W_e | b_e | 0] (fp32 [D][FE_PAD], packed once on the host side of the ABI) into LDS: all 16-byte
   // loads are issued before the first write (one memory round trip per workgroup).
   if constexpr (!(kAttnDbg & 16)) {
@@ -182,6 +240,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt
     for (int it = 0; it < kIter; ++it) {
       const int idx = threadIdx.x + it * 64 * kWavesPerBlock;
       tmp[it] = idx < kTotal ? reinterpret_cast<const float4*>(w_packed)[idx] : float4{0.f, 0.f, 0.f, 0.f};
+    }
+    if constexpr (kEarlyHdr) {
+      if (i0 < d_hi) { if constexpr (kScalarPf) { h_d = n_d, h_beg = n_beg, h_end = n_end; } load_header(i0, h_d, h_beg, h_end, h_q, h_src); }
     }
 #pragma unroll
     for (int it = 0; it < kIter; ++it) {
@@ -196,38 +257,32 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt
       }
     }
   }
+  if constexpr (kEarlyHdr && (kAttnDbg & 16) != 0) {
+    if (i0 < d_hi) { if constexpr (kScalarPf) { h_d = n_d, h_beg = n_beg, h_end = n_end; } load_header(i0, h_d, h_beg, h_end, h_q, h_src); }
+  }
   __syncthreads();
   const float* wl = w_lds + lane * L::kChunk;
 
-  // XCD-aware persistent schedule.  Workgroup b runs on XCD b % 8 (observed dispatch order; only speed depends on
-  // it).  Each XCD gets one CONTIGUOUS slice of the destination range, so the K/V rows its waves gather (the mesh
-  // neighbourhood of that slice: nodes are latitude/longitude sorted) stay resident in that XCD's 4 MiB L2 instead of
-  // every L2 pulling every row from the fabric (8x the traffic).  Inside a slice, waves take destinations round-robin.
-  const int xcd = blockIdx.x & 7;
-  const int blocks_in_xcd = (gridDim.x - xcd + 7) >> 3;
-  const int waves_in_xcd = blocks_in_xcd * kWavesPerBlock;
-  const int wave_in_xcd = __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * kWavesPerBlock + (threadIdx.x >> 6));
-  const int per_xcd = (n_dst + 7) >> 3;
-  const int d_lo = xcd * per_xcd;
-  const int d_hi = min(n_dst, d_lo + per_xcd);
-
-  using Raw = Vec<T, VEC>;  // a row slice as loaded (converted to fp32 only when consumed)
   const float sl2e = scale * 1.4426950408889634f;  // p = 2^((s' - m') * scale * log2 e)
   const float thr = kDeferThr / scale;
-  constexpr int PF = 3;     // edges in flight per wave (modulo-unrolled: no register rotation, counted waits)
+  constexpr int PF = ANEMOI_ATTN_PF;     // edges in flight per wave (modulo-unrolled: no register rotation, counted waits)
 
   // `order` (optional): the destination processed at position i.  The ~768 destinations an XCD works on at one moment are
   // then a compact patch of the mesh instead of a whole latitude ring, so the K|V rows they gather fit that XCD's L2
   // (layers/graphcache.py builds it from the graph; outputs are written at their own rows, the result does not depend on it).
-  for (int i = d_lo + wave_in_xcd; i < d_hi; i += waves_in_xcd) {
-    const int d = order ? __builtin_amdgcn_readfirstlane(order[i]) : i;
+  for (int i = i0; i < d_hi; i += waves_in_xcd) {
     // W' lives in LDS and is re-read per destination: without this barrier the compiler hoists all VEC*FE_PAD values
     // into registers across the loop (256 VGPRs, 1 wave/SIMD) and the kernel becomes latency-bound.
     asm volatile("" ::: "memory");
-    const int beg = __builtin_amdgcn_readfirstlane(colptr[d]);
-    const int end = __builtin_amdgcn_readfirstlane(colptr[d + 1]);
-
-    const Raw q_raw = *reinterpret_cast<const Raw*>(q + (int64_t)d * ldq + c0);
+    if constexpr (kScalarPf) {
+      h_d = n_d, h_beg = n_beg, h_end = n_end;
+    }
+    if (!kEarlyHdr || i != i0) load_header(i, h_d, h_beg, h_end, h_q, h_src);
+    if constexpr (kScalarPf) {
+      if (i + waves_in_xcd < d_hi) load_scalars(i + waves_in_xcd, n_d, n_beg, n_end);
+    }
+    const int d = h_d, beg = h_beg, end = h_end;
+    const Raw q_raw = h_q;
     float qv[VEC], acc[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
@@ -236,6 +291,43 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt
     }
     // Scores are kept in units of 1/scale (s' = <q, k + e>, the softmax argument is scale * s'): the scale rides in the
     // exponent's multiplier (one multiply per edge less).
+    // Edge loop in chunks of 64: the source ids of a chunk are fetched with ONE coalesced load (lane j holds
+    // row[chunk + j]) and broadcast with v_readlane, so row loads never wait on a dependent scalar load.  The ring of the FIRST
+    // chunk is filled here, ahead of the qw set-up (ANEMOI_ATTN_EARLY_RING): the K|V round trip runs beside that arithmetic.
+    int chunk = beg, n = min(64, end - beg), my_src = h_src;  // the first chunk's ids came with the header
+    Raw kb[PF], vb[PF];
+    float fb[PF][FE_PAD];
+    auto fetch = [&](int j, Raw& kr, Raw& vr, float (&fr)[FE_PAD], int what = 3) {  // what: 1 = the K slice, 2 = V + features
+      j = min(j, n - 1);  // refills past the end re-read the last edge: an UNCONDITIONAL load keeps the ring registers
+                          // free of select/copy code (a conditional one made the compiler wait for the load at once)
+      const int s = (kAttnDbg & 32) ? (__builtin_amdgcn_readlane(my_src, j) & 1) : __builtin_amdgcn_readlane(my_src, j);
+      const float* a;  // wave-uniform address -> scalar loads
+      if constexpr (KVADJ) {
+        // v = the D columns after k in the same buffer (the fused projection's layout): ONE address and an immediate
+        // offset; the row offset in 32 bits (checked at launch) - 13 scalar instructions fewer per edge, and this
+        // kernel is bound by instruction issue
+        const T* kp = k + (uint32_t)((uint32_t)s * (uint32_t)ldk) + c0;
+        if (what & 1) kr = *reinterpret_cast<const Raw*>(kp);
+        if (what & 2) vr = *reinterpret_cast<const Raw*>(kp + 64 * VEC);
+        a = feat + (int64_t)(chunk + j) * FE_PAD;
+      } else {
+        if (what & 1) kr = *reinterpret_cast<const Raw*>(k + (int64_t)s * ldk + c0);
+        if (what & 2) vr = *reinterpret_cast<const Raw*>(v + (int64_t)s * ldv + c0);
+        a = feat + (int64_t)(chunk + j) * FE_PAD;
+      }
+      if constexpr (!(kAttnDbg & 4)) {
+        if (what & 2) {
+#pragma unroll
+          for (int f = 0; f < FE_PAD; ++f) fr[f] = a[f];
+        }
+      }
+    };
+    if constexpr (kEarlyRing != 0) {  // 1: K, V and the features; 2: the K slices only (V + features behind the qw set-up)
+      if (beg < end) {
+#pragma unroll
+        for (int st = 0; st < PF; ++st) fetch(st, kb[st], vb[st], fb[st], kEarlyRing == 2 ? 1 : 3);
+      }
+    }
     // qw[f] = (1/LPH) * sum over the head's channels of q[c] * W'[c][f]  (pre-divided: every lane of the
     // head adds the same edge-feature term before the head butterfly).
     float qw[FE_PAD], sf[FE_PAD];
@@ -261,41 +353,25 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt
       }
       qw[f] = group_sum<LPH>(t) * (1.0f / LPH);  // pre-divided: every lane of the head adds the same edge-feature term
       sf[f] = 0.f;
+      // with the K|V ring already in flight the W' reads must not all be hoisted to the top (registers): groups of kQwGroup features
+      if constexpr (kEarlyRing != 0 && kQwGroup > 0) {
+        if (f % kQwGroup == kQwGroup - 1) asm volatile("" ::: "memory");
+      }
     }
     float m = -INFINITY, l = 0.f;
 
-    // Edge loop in chunks of 64: the source ids of a chunk are fetched with ONE coalesced load (lane j holds
-    // row[chunk + j]) and broadcast with v_readlane, so row loads never wait on a dependent scalar load.
-    for (int chunk = beg; chunk < end; chunk += 64) {
-      const int n = min(64, end - chunk);
-      const int my_src = (lane < n) ? row[chunk + lane] : 0;
-      Raw kb[PF], vb[PF];
-      float fb[PF][FE_PAD];
-      auto fetch = [&](int j, Raw& kr, Raw& vr, float (&fr)[FE_PAD]) {
-        j = min(j, n - 1);  // refills past the end re-read the last edge: an UNCONDITIONAL load keeps the ring registers
-                            // free of select/copy code (a conditional one made the compiler wait for the load at once)
-        const int s = (kAttnDbg & 32) ? (__builtin_amdgcn_readlane(my_src, j) & 1) : __builtin_amdgcn_readlane(my_src, j);
-        const float* a;  // wave-uniform address -> scalar loads
-        if constexpr (KVADJ) {
-          // v = the D columns after k in the same buffer (the fused projection's layout): ONE address and an immediate
-          // offset; the row offset in 32 bits (checked at launch) - 13 scalar instructions fewer per edge, and this
-          // kernel is bound by instruction issue
-          const T* kp = k + (uint32_t)((uint32_t)s * (uint32_t)ldk) + c0;
-          kr = *reinterpret_cast<const Raw*>(kp);
-          vr = *reinterpret_cast<const Raw*>(kp + 64 * VEC);
-          a = feat + (int64_t)(chunk + j) * FE_PAD;
-        } else {
-          kr = *reinterpret_cast<const Raw*>(k + (int64_t)s * ldk + c0);
-          vr = *reinterpret_cast<const Raw*>(v + (int64_t)s * ldv + c0);
-          a = feat + (int64_t)(chunk + j) * FE_PAD;
-        }
-        if constexpr (!(kAttnDbg & 4)) {
+    for (; chunk < end; chunk += 64) {
+      if (chunk != beg) {
+        n = min(64, end - chunk);
+        my_src = (lane < n) ? row[chunk + lane] : 0;
+      }
+      if (kEarlyRing == 0 || chunk != beg) {
 #pragma unroll
-          for (int f = 0; f < FE_PAD; ++f) fr[f] = a[f];
-        }
-      };
+        for (int st = 0; st < PF; ++st) fetch(st, kb[st], vb[st], fb[st]);
+      } else if constexpr (kEarlyRing == 2) {
 #pragma unroll
-      for (int st = 0; st < PF; ++st) fetch(st, kb[st], vb[st], fb[st]);
+        for (int st = 0; st < PF; ++st) fetch(st, kb[st], vb[st], fb[st], 2);
+      }
       for (int j0 = 0; j0 < n; j0 += PF) {
 #pragma unroll
         for (int st = 0; st < PF; ++st) {
