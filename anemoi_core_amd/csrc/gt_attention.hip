@@ -55,6 +55,13 @@ constexpr int kQwGroup = ANEMOI_ATTN_QW_GROUP;
 #define ANEMOI_ATTN_SCALAR_PF 1
 #endif
 constexpr bool kScalarPf = ANEMOI_ATTN_SCALAR_PF != 0;
+// ANEMOI_ATTN_HDR_AHEAD: the NEXT destination's q slice and source ids are requested behind the edge loop, in front of the W' * sum(p a)
+// epilogue and the store (1), and the first destination's beside the W' staging loads as well (2); needs ANEMOI_ATTN_SCALAR_PF.
+#ifndef ANEMOI_ATTN_HDR_AHEAD
+#define ANEMOI_ATTN_HDR_AHEAD 0
+#endif
+constexpr int kHdrAhead = ANEMOI_ATTN_HDR_AHEAD;
+static_assert(kHdrAhead == 0 || (kScalarPf && !kEarlyHdr), "ANEMOI_ATTN_HDR_AHEAD needs ANEMOI_ATTN_SCALAR_PF=1 and ANEMOI_ATTN_EARLY_HDR=0");
 #ifndef ANEMOI_ATTN_PF
 #define ANEMOI_ATTN_PF 3
 #endif
@@ -241,6 +248,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt
       const int idx = threadIdx.x + it * 64 * kWavesPerBlock;
       tmp[it] = idx < kTotal ? reinterpret_cast<const float4*>(w_packed)[idx] : float4{0.f, 0.f, 0.f, 0.f};
     }
+    if constexpr (kHdrAhead == 2) {
+      if (i0 < d_hi) {
+        h_d = n_d, h_beg = n_beg, h_end = n_end;
+        load_header(i0, h_d, h_beg, h_end, h_q, h_src);
+      }
+    }
     if constexpr (kEarlyHdr) {
       if (i0 < d_hi) { if constexpr (kScalarPf) { h_d = n_d, h_beg = n_beg, h_end = n_end; } load_header(i0, h_d, h_beg, h_end, h_q, h_src); }
     }
@@ -260,6 +273,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt
   if constexpr (kEarlyHdr && (kAttnDbg & 16) != 0) {
     if (i0 < d_hi) { if constexpr (kScalarPf) { h_d = n_d, h_beg = n_beg, h_end = n_end; } load_header(i0, h_d, h_beg, h_end, h_q, h_src); }
   }
+  if constexpr (kHdrAhead == 1 || (kHdrAhead == 2 && (kAttnDbg & 16) != 0)) {
+    if (i0 < d_hi) {
+      h_d = n_d, h_beg = n_beg, h_end = n_end;
+      load_header(i0, h_d, h_beg, h_end, h_q, h_src);
+    }
+  }
   __syncthreads();
   const float* wl = w_lds + lane * L::kChunk;
 
@@ -274,10 +293,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt
     // W' lives in LDS and is re-read per destination: without this barrier the compiler hoists all VEC*FE_PAD values
     // into registers across the loop (256 VGPRs, 1 wave/SIMD) and the kernel becomes latency-bound.
     asm volatile("" ::: "memory");
-    if constexpr (kScalarPf) {
+    if constexpr (kScalarPf && kHdrAhead == 0) {
       h_d = n_d, h_beg = n_beg, h_end = n_end;
     }
-    if (!kEarlyHdr || i != i0) load_header(i, h_d, h_beg, h_end, h_q, h_src);
+    if constexpr (kHdrAhead == 0) {
+      if (!kEarlyHdr || i != i0) load_header(i, h_d, h_beg, h_end, h_q, h_src);
+    }
     if constexpr (kScalarPf) {
       if (i + waves_in_xcd < d_hi) load_scalars(i + waves_in_xcd, n_d, n_beg, n_end);
     }
@@ -415,6 +436,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt
       }
     }
 
+    if constexpr (kHdrAhead != 0) {  // the next destination's q slice and source ids travel beside the epilogue
+      if (i + waves_in_xcd < d_hi) {
+        h_d = n_d, h_beg = n_beg, h_end = n_end;
+        load_header(i + waves_in_xcd, h_d, h_beg, h_end, h_q, h_src);
+      }
+    }
     asm volatile("" ::: "memory");
     const float inv = (end > beg) ? 1.0f / l : 0.f;
     float o[VEC];
