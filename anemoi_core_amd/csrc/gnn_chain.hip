@@ -701,6 +701,10 @@ static int node_chain_launch(const void* x, int64_t ld_x, const void* agg, int64
                  "gnn_node_chain_fwd: operand alignment / leading dimensions");
   NodeChainArgs a{x, ld_x, agg, ld_a, (const char*)wa, ba, (const char*)wb, bb, (const char*)wc, bc, ln_w, ln_b, eps, x_out, ld_o,
                   (const char*)wt, bt, t_out_features / kCh, t_out, ld_t, n_rows, chain_rows_per_tile(n_rows), 0};
+  // ANEMOI_GNN_NODE_ROWS: rows per panel of this launch alone (A/B of the even-spread rule against full 48-row panels on fewer CUs,
+  // the rule that won for gt_chain2_kernel; profiles/r05_gnn_node_rows_ab.txt)
+  static const int node_rows = env_int(getenv("ANEMOI_GNN_NODE_ROWS"), 0, 0, kPanel);
+  if (node_rows > 0) a.rows_per_tile = node_rows;
   a.seg_ptr = seg_ptr;
   a.n_tiles = (n_rows + a.rows_per_tile - 1) / a.rows_per_tile;
   const int grid = a.n_tiles < 256 ? a.n_tiles : 256;
