@@ -62,6 +62,13 @@ constexpr bool kScalarPf = ANEMOI_ATTN_SCALAR_PF != 0;
 #endif
 constexpr int kHdrAhead = ANEMOI_ATTN_HDR_AHEAD;
 static_assert(kHdrAhead == 0 || (kScalarPf && !kEarlyHdr), "ANEMOI_ATTN_HDR_AHEAD needs ANEMOI_ATTN_SCALAR_PF=1 and ANEMOI_ATTN_EARLY_HDR=0");
+// ANEMOI_ATTN_FSPLIT (heads of 4 lanes, FE_PAD % 4 == 0): the edge-feature terms of a head are shared out among its four lanes (FE_PAD / 4
+// features per lane, fetched by one per-lane vector load; the head butterfly that finishes <q, k> adds the shares up, the weighted feature
+// sums are kept per lane and gathered with quad broadcasts once per destination).  Round 3 built this on the three-deep ring and measured
+// it slower (profiles/r03_attention_fsplit_ab.txt); on the two-deep ring it fits the register budget: profiles/r05_attention_fsplit_ab.txt.
+#ifndef ANEMOI_ATTN_FSPLIT
+#define ANEMOI_ATTN_FSPLIT 0
+#endif
 #ifndef ANEMOI_ATTN_PF
 #define ANEMOI_ATTN_PF 3
 #endif
@@ -200,6 +207,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt
   extern __shared__ __attribute__((aligned(16))) float w_lds[];  // [64][kChunk]
   const int lane = threadIdx.x & 63;
   const int c0 = lane * VEC;
+  constexpr bool FS = ANEMOI_ATTN_FSPLIT != 0 && LPH == 4 && FE_PAD % 4 == 0 && !(kAttnDbg & 4);
+  constexpr int FPL = FS ? FE_PAD / LPH : 1;  // features a lane carries (FSPLIT)
+  const int hl = lane & (LPH - 1);            // this lane's place in its head
 
   // XCD-aware persistent schedule.  Workgroup b runs on XCD b % 8 (observed dispatch order; only speed depends on
   // it).  Each XCD gets one CONTIGUOUS slice of the destination range, so the K/V rows its waves gather (the mesh
@@ -318,7 +328,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt
     int chunk = beg, n = min(64, end - beg), my_src = h_src;  // the first chunk's ids came with the header
     Raw kb[PF], vb[PF];
     float fb[PF][FE_PAD];
-    auto fetch = [&](int j, Raw& kr, Raw& vr, float (&fr)[FE_PAD], int what = 3) {  // what: 1 = the K slice, 2 = V + features
+    float fv[PF][FPL];
+    auto fetch = [&](int j, Raw& kr, Raw& vr, float (&fr)[FE_PAD], float (&fvr)[FPL], int what = 3) {  // what: 1 = the K slice, 2 = V + features
       j = min(j, n - 1);  // refills past the end re-read the last edge: an UNCONDITIONAL load keeps the ring registers
                           // free of select/copy code (a conditional one made the compiler wait for the load at once)
       const int s = (kAttnDbg & 32) ? (__builtin_amdgcn_readlane(my_src, j) & 1) : __builtin_amdgcn_readlane(my_src, j);
@@ -336,7 +347,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt
         if (what & 2) vr = *reinterpret_cast<const Raw*>(v + (int64_t)s * ldv + c0);
         a = feat + (int64_t)(chunk + j) * FE_PAD;
       }
-      if constexpr (!(kAttnDbg & 4)) {
+      if constexpr (FS) {
+        if (what & 2) {  // this lane's FPL features of the edge: uniform base + per-lane offset -> one vector load per lane
+          struct __attribute__((packed, aligned(4))) Feats {
+            float v[FPL];
+          };
+          const Feats t = *reinterpret_cast<const Feats*>(a + hl * FPL);
+#pragma unroll
+          for (int f = 0; f < FPL; ++f) fvr[f] = t.v[f];
+        }
+      } else if constexpr (!(kAttnDbg & 4)) {
         if (what & 2) {
 #pragma unroll
           for (int f = 0; f < FE_PAD; ++f) fr[f] = a[f];
@@ -346,7 +366,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt
     if constexpr (kEarlyRing != 0) {  // 1: K, V and the features; 2: the K slices only (V + features behind the qw set-up)
       if (beg < end) {
 #pragma unroll
-        for (int st = 0; st < PF; ++st) fetch(st, kb[st], vb[st], fb[st], kEarlyRing == 2 ? 1 : 3);
+        for (int st = 0; st < PF; ++st) fetch(st, kb[st], vb[st], fb[st], fv[st], kEarlyRing == 2 ? 1 : 3);
       }
     }
     // qw[f] = (1/LPH) * sum over the head's channels of q[c] * W'[c][f]  (pre-divided: every lane of the
@@ -372,11 +392,23 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt
 #pragma unroll
         for (int j = 0; j < VEC; ++j) t = fmaf(qv[j], wl[f * VEC + j], t);
       }
-      qw[f] = group_sum<LPH>(t) * (1.0f / LPH);  // pre-divided: every lane of the head adds the same edge-feature term
+      // pre-divided: every lane of the head adds the same edge-feature term (FSPLIT: each lane its own share of it, undivided)
+      qw[f] = group_sum<LPH>(t) * (FS ? 1.0f : 1.0f / LPH);
       sf[f] = 0.f;
       // with the K|V ring already in flight the W' reads must not all be hoisted to the top (registers): groups of kQwGroup features
       if constexpr (kEarlyRing != 0 && kQwGroup > 0) {
         if (f % kQwGroup == kQwGroup - 1) asm volatile("" ::: "memory");
+      }
+    }
+    float qws[FPL], sfs[FPL];  // FSPLIT: this lane's share of qw (features hl * FPL + i) and of the weighted feature sums
+    if constexpr (FS) {
+#pragma unroll
+      for (int i = 0; i < FPL; ++i) {
+        float sel = qw[i];
+#pragma unroll
+        for (int g = 1; g < LPH; ++g) sel = (hl == g) ? qw[g * FPL + i] : sel;
+        qws[i] = sel;
+        sfs[i] = 0.f;
       }
     }
     float m = -INFINITY, l = 0.f;
@@ -388,10 +420,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt
       }
       if (kEarlyRing == 0 || chunk != beg) {
 #pragma unroll
-        for (int st = 0; st < PF; ++st) fetch(st, kb[st], vb[st], fb[st]);
+        for (int st = 0; st < PF; ++st) fetch(st, kb[st], vb[st], fb[st], fv[st]);
       } else if constexpr (kEarlyRing == 2) {
 #pragma unroll
-        for (int st = 0; st < PF; ++st) fetch(st, kb[st], vb[st], fb[st], 2);
+        for (int st = 0; st < PF; ++st) fetch(st, kb[st], vb[st], fb[st], fv[st], 2);
       }
       for (int j0 = 0; j0 < n; j0 += PF) {
 #pragma unroll
@@ -400,6 +432,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt
           if (j < n) {
             float dot = dot_rows<T, VEC>(q_raw, kb[st]);
             if constexpr (kAttnDbg & 4) {
+            } else if constexpr (FS) {  // this lane's share of the feature term; the head butterfly below adds the shares up
+              float fs = 0.f;
+#pragma unroll
+              for (int f = 0; f < FPL; ++f) fs = fmaf(fv[st][f], qws[f], fs);
+              dot += fs;
             } else if constexpr (FE_PAD % 2 == 0) {  // feature pairs on packed FMAs (scalar-register pairs as loaded)
               f32x2 d2[2] = {{dot, 0.f}, {0.f, 0.f}};  // two chains: dependent packed FMAs back to back cost a wait state each
 #pragma unroll
@@ -418,19 +455,27 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt
               l *= corr;
 #pragma unroll
               for (int jj = 0; jj < VEC; ++jj) acc[jj] *= corr;
+              if constexpr (FS) {
 #pragma unroll
-              for (int f = 0; f < FE_PAD; ++f) sf[f] *= corr;
+                for (int f = 0; f < FPL; ++f) sfs[f] *= corr;
+              } else {
+#pragma unroll
+                for (int f = 0; f < FE_PAD; ++f) sf[f] *= corr;
+              }
               m = m_new;
             }
             const float p = __builtin_amdgcn_exp2f((dot - m) * sl2e);
             l += p;
 #pragma unroll
             for (int jj = 0; jj < VEC; ++jj) acc[jj] = fmaf(p, to_float(vb[st].v[jj]), acc[jj]);
-            if constexpr (!(kAttnDbg & 4)) {
+            if constexpr (FS) {
+#pragma unroll
+              for (int f = 0; f < FPL; ++f) sfs[f] = fmaf(p, fv[st][f], sfs[f]);
+            } else if constexpr (!(kAttnDbg & 4)) {
 #pragma unroll
               for (int f = 0; f < FE_PAD; ++f) sf[f] = fmaf(p, fb[st][f], sf[f]);
             }
-            fetch(j + PF, kb[st], vb[st], fb[st]);
+            fetch(j + PF, kb[st], vb[st], fb[st], fv[st]);
           }
         }
       }
@@ -443,6 +488,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt
       }
     }
     asm volatile("" ::: "memory");
+    if constexpr (FS) {  // the head's weighted feature sums, all of them in every lane again: quad broadcasts
+#pragma unroll
+      for (int i = 0; i < FPL; ++i) {
+        sf[0 * FPL + i] = dpp_f<0x00>(sfs[i]);
+        sf[1 * FPL + i] = dpp_f<0x55>(sfs[i]);
+        sf[2 * FPL + i] = dpp_f<0xAA>(sfs[i]);
+        sf[3 * FPL + i] = dpp_f<0xFF>(sfs[i]);
+      }
+    }
     const float inv = (end > beg) ? 1.0f / l : 0.f;
     float o[VEC];
     if constexpr (VEC % 2 == 0) {
