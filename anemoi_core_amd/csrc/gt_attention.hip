@@ -47,10 +47,6 @@ constexpr bool kEarlyHdr = ANEMOI_ATTN_EARLY_HDR != 0;
 #define ANEMOI_ATTN_EARLY_RING 0
 #endif
 constexpr int kEarlyRing = ANEMOI_ATTN_EARLY_RING;
-#ifndef ANEMOI_ATTN_QW_GROUP
-#define ANEMOI_ATTN_QW_GROUP 4
-#endif
-constexpr int kQwGroup = ANEMOI_ATTN_QW_GROUP;
 #ifndef ANEMOI_ATTN_SCALAR_PF
 #define ANEMOI_ATTN_SCALAR_PF 1
 #endif
@@ -65,7 +61,8 @@ static_assert(kHdrAhead == 0 || (kScalarPf && !kEarlyHdr), "ANEMOI_ATTN_HDR_AHEA
 // ANEMOI_ATTN_FSPLIT (heads of 4 lanes, FE_PAD % 4 == 0): the edge-feature terms of a head are shared out among its four lanes (FE_PAD / 4
 // features per lane, fetched by one per-lane vector load; the head butterfly that finishes <q, k> adds the shares up, the weighted feature
 // sums are kept per lane and gathered with quad broadcasts once per destination).  Round 3 built this on the three-deep ring and measured
-// it slower (profiles/r03_attention_fsplit_ab.txt); on the two-deep ring it fits the register budget: profiles/r05_attention_fsplit_ab.txt.
+// it slower (profiles/r03_attention_fsplit_ab.txt); on the reordered kernel with a two-deep ring it needs 74 VGPRs (six waves) and wins 7 % of
+// the res-6 launch back to back but LOSES 1.0-1.5 % inside the forward (profiles/r05_attention_fsplit_ab.txt): default 0.
 #ifndef ANEMOI_ATTN_FSPLIT
 #define ANEMOI_ATTN_FSPLIT 0
 #endif
@@ -395,10 +392,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt
       // pre-divided: every lane of the head adds the same edge-feature term (FSPLIT: each lane its own share of it, undivided)
       qw[f] = group_sum<LPH>(t) * (FS ? 1.0f : 1.0f / LPH);
       sf[f] = 0.f;
-      // with the K|V ring already in flight the W' reads must not all be hoisted to the top (registers): groups of kQwGroup features
-      if constexpr (kEarlyRing != 0 && kQwGroup > 0) {
-        if (f % kQwGroup == kQwGroup - 1) asm volatile("" ::: "memory");
-      }
     }
     float qws[FPL], sfs[FPL];  // FSPLIT: this lane's share of qw (features hl * FPL + i) and of the weighted feature sums
     if constexpr (FS) {
