@@ -9,7 +9,7 @@ import ctypes as C
 import os
 import threading
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libanemoi_hip.so")
 
 F32, BF16, F16 = 0, 1, 2
@@ -71,16 +71,25 @@ SIGNATURES = {
     "anemoi_peer_export": ([_p, _p], C.c_int),
     "anemoi_peer_open": ([_p, C.POINTER(_p)], C.c_int),
     "anemoi_peer_close": ([_p], C.c_int),
-    "anemoi_gt_chain_fwd": ([_p, C.c_int, _p], C.c_int),
     "anemoi_gt_chain_rows_per_tile": ([_i32], C.c_int),
     "anemoi_gt_chain2_fwd": ([_p, C.c_int, _p], C.c_int),
+    "anemoi_gt_rowchain_fwd": ([_p, C.c_int, _p], C.c_int),
+    "anemoi_gt_cluster_chain_fwd": ([_p, C.c_int, _p], C.c_int),
+    "anemoi_gt_cluster_chain_workspace_bytes": ([], _i64),
     "anemoi_gnn_edge_chain_fwd": ([_p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _i64, _i32, _i32, C.c_int, _p], C.c_int),
-    "anemoi_gnn_edge_chain_timeline": ([_p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _i64, _i32, _p, _p], C.c_int),
     "anemoi_gnn_mlp_chain_fwd": ([_p, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _i64, _p, _i64, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_gnn_node_chain_segsum_fwd": ([_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _i64, _p, _p, _i32, _p, _i64, _i32, _i32,
                                           C.c_int, _p], C.c_int),
     "anemoi_gnn_node_chain_fwd": ([_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _i64, _p, _p, _i32, _p, _i64, _i32, _i32, C.c_int, _p], C.c_int),
     "anemoi_peer_exchange_rows": ([_p, _i64, _p, _p, _i32, _i32, _i32, _p, _p, _i64, _p], C.c_int),
+}
+
+
+# entry points of the EXPERIMENTS build only (csrc/experiments/anemoi_hip_experiments.h; lib/libanemoi_hip_exp.so): bound when the loaded
+# library has them, used by tools/ only
+EXPERIMENT_SIGNATURES = {
+    "anemoi_gt_chain_fwd": ([_p, C.c_int, _p], C.c_int),
+    "anemoi_gnn_edge_chain_timeline": ([_p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _i64, _i32, _p, _p], C.c_int),
 }
 
 
@@ -117,6 +126,11 @@ def load(path: str | None = None):
                 raise HipLibraryError(f"{path} does not export {name}; rebuild the library") from e
             fn.argtypes = argtypes
             fn.restype = restype
+        for name, (argtypes, restype) in EXPERIMENT_SIGNATURES.items():
+            fn = getattr(lib, name, None)
+            if fn is not None:
+                fn.argtypes = argtypes
+                fn.restype = restype
         got = lib.anemoi_hip_abi_version()
         if got != ABI_VERSION:
             raise HipLibraryError(f"{path}: ABI version {got}, expected {ABI_VERSION}; rebuild the library")

@@ -19,7 +19,12 @@ LIBPATH = os.path.join(LIBDIR, "libanemoi_hip.so")
 EXT_PATH = os.path.join(LIBDIR, "libanemoi_torch.so")
 INCLUDE = os.path.join(REPO, "include")
 
-SOURCES = ["lib.cpp", "gt_attention.hip", "gt_attention_bwd.hip", "rowwise.hip", "rowwise_bwd.hip", "linear.hip", "wgrad.hip", "peer.hip", "gt_chain.hip", "gt_chain2.hip", "gnn_chain.hip", "gnn_chain2.hip"]
+SOURCES = ["lib.cpp", "gt_attention.hip", "gt_attention_bwd.hip", "rowwise.hip", "rowwise_bwd.hip", "linear.hip", "wgrad.hip", "peer.hip", "gt_chain2.hip", "gt_rowchain.hip", "gt_cluster_chain.hip", "gnn_chain.hip"]
+# `--experiments`: the same sources compiled with -DANEMOI_EXPERIMENTS (timing switches that change what a kernel computes, in-kernel
+# timeline instantiations) plus the measured-and-superseded kernels under csrc/experiments/ -> lib/libanemoi_hip_exp.so, selected with
+# ANEMOI_HIP_LIB=<that path> by the A/B scripts in tools/.  Never the default: the product library carries none of it.
+EXPERIMENT_SOURCES = ["experiments/gt_chain.hip", "experiments/gnn_chain2.hip"]
+EXP_LIBPATH = os.path.join(LIBDIR, "libanemoi_hip_exp.so")
 ARCH = "gfx950"
 
 
@@ -37,18 +42,42 @@ def _newer(target: str, deps: list[str]) -> bool:
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
-def build_library(force: bool = False, verbose: bool = True, extra_flags: tuple[str, ...] = ()) -> str:
+def _deps(path: str, dirs: list[str], seen: set | None = None) -> list[str]:
+    """The source and every project header it includes (recursively): a header edit rebuilds only the translation units that see it."""
+    import re
+
+    seen = set() if seen is None else seen
+    if path in seen:
+        return []
+    seen.add(path)
+    out = [path]
+    for inc in re.findall(r'^\s*#include\s+"([^"]+)"', open(path).read(), flags=re.M):
+        for d in [os.path.dirname(path), *dirs]:
+            cand = os.path.join(d, inc)
+            if os.path.exists(cand):
+                out += _deps(cand, dirs, seen)
+                break
+    return out
+
+
+def build_library(force: bool = False, verbose: bool = True, extra_flags: tuple[str, ...] = (), experiments: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
-    objdir = os.path.join(LIBDIR, "obj")
+    objdir = os.path.join(LIBDIR, "obj_exp" if experiments else "obj")
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "chain_core.h"), os.path.join(CSRC, "chain2_core.h"), os.path.join(CSRC, "gnn_chain_args.h"), os.path.join(INCLUDE, "anemoi_hip.h")]
     flags = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I", INCLUDE, "-I", CSRC, "-Wall", "-Wno-unused-function", *extra_flags]
+    sources, libpath = SOURCES, LIBPATH
+    inc_dirs = [CSRC, INCLUDE] + ([os.path.join(CSRC, "experiments")] if experiments else [])
+    if experiments:
+        flags += ["-DANEMOI_EXPERIMENTS", "-I", os.path.join(CSRC, "experiments")]
+        headers.append(os.path.join(CSRC, "experiments", "anemoi_hip_experiments.h"))
+        sources, libpath = SOURCES + EXPERIMENT_SOURCES, EXP_LIBPATH
 
     def compile_one(src: str) -> str:
         path = os.path.join(CSRC, src)
-        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
-        if not force and _newer(obj, [path, *headers]):
+        obj = os.path.join(objdir, os.path.splitext(os.path.basename(src))[0] + ".o")
+        if not force and _newer(obj, _deps(path, inc_dirs)):
             return obj
         cmd = [hipcc, *flags, "-x", "hip", "-c", path, "-o", obj]
         if verbose:
@@ -56,15 +85,16 @@ def build_library(force: bool = False, verbose: bool = True, extra_flags: tuple[
         subprocess.run(cmd, check=True)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as ex:
-        objs = list(ex.map(compile_one, SOURCES))
-    if force or not _newer(LIBPATH, objs):
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIBPATH, *objs]
+    with ThreadPoolExecutor(max_workers=min(4, len(sources))) as ex:
+        objs = list(ex.map(compile_one, sources))
+    if force or not _newer(libpath, objs):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", libpath, *objs]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-    build_torch_extension(hipcc, force=force, verbose=verbose)
-    return LIBPATH
+    if not experiments:
+        build_torch_extension(hipcc, force=force, verbose=verbose)
+    return libpath
 
 
 def build_torch_extension(hipcc: str, force: bool = False, verbose: bool = True) -> str:
@@ -97,4 +127,4 @@ def build_torch_extension(hipcc: str, force: bool = False, verbose: bool = True)
 
 
 if __name__ == "__main__":
-    print(build_library(force="--force" in sys.argv))
+    print(build_library(force="--force" in sys.argv, experiments="--experiments" in sys.argv))

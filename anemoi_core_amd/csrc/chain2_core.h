@@ -1,5 +1,5 @@
-// Shared device code of the ROLE-SPLIT row-resident chain kernels (round 5; gt_chain2.hip: the GraphTransformer block tail, gnn_chain2.hip:
-// GraphConv's edge MLP).  The workgroup's eight waves form two groups of four (waves w and w + 4 share a SIMD); a wave owns a 48 x 128
+// Shared device code of the ROLE-SPLIT row-resident chain kernels (round 5; gt_chain2.hip: the GraphTransformer block tail; round 6:
+// gt_rowchain.hip: the mappers' embedding -> LayerNorm -> projection chains; experiments/gnn_chain2.hip: GraphConv's edge MLP).  The workgroup's eight waves form two groups of four (waves w and w + 4 share a SIMD); a wave owns a 48 x 128
 // output slab of its group's GEMM segment: 24 accumulator quads, the three A fragments of a K-step shared by eight column blocks, its
 // 8 KiB of weights per K-step through a register ring of only two K-steps (tools/role_split_probe.hip: one such group pulls the weight
 // stream through the CU's L1 path as fast as eight 64-column waves do, in 200 registers).  What the groups do differs per kernel; the
@@ -65,6 +65,135 @@ __device__ __forceinline__ void gemm128(const unsigned char* abuf, int lane, fra
 #pragma unroll
       for (int mi = 0; mi < 3; ++mi) fa[mi] = fn[mi];
       __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+// The same for a 48 x 64 tile (ONE 64-column slab of the image, acc[mi][0..3]) on the SAME ring registers, as four K-steps x 4 fragments:
+// K-step j of the stream sits in ring[j & 1][(j >> 1) * 4 + ni].  Used where all eight waves of the workgroup share ONE segment (the
+// projection: 512 columns = 8 waves x 64), so that its epilogue is spread over eight waves instead of four.  In its last group of four
+// K-steps the slots are refilled with the first fragments of the wave's NEXT segment in the layout gemm128 expects (two K-steps of the
+// two slabs `nxt`, `nxt + ns`); a gemm128 hands over to a gemm64 with ns = 8192 (K-steps 2, 3 of the one slab behind K-steps 0, 1).
+// ng: groups of four K-steps (K = 128 ng; 4 = the 512-wide segment; fewer: a narrow first GEMM on a zero-padded operand).
+template <typename T>
+__device__ __forceinline__ void gemm64(const unsigned char* abuf, int lane, frag8 (&ring)[2][8], const char* cur, const char* nxt, int64_t ns,
+                                       uint32_t loff, f32x4 (&acc)[3][8], int ng = 4) {
+  asm volatile("" : "+v"(lane));
+  const int x = lane & 15, ks = lane >> 4;
+  const unsigned char* arow = abuf + x * kRowBytes;
+  frag8 fa[3];
+#pragma unroll
+  for (int mi = 0; mi < 3; ++mi) fa[mi] = *reinterpret_cast<const frag8*>(arow + mi * 16 * kRowBytes + ((ks ^ x) << 4));
+  const int last = ng * 4 - 1;
+#pragma unroll 1
+  for (int q = 0; q < ng; ++q) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int st = q * 4 + j;
+      const int sn = st < last ? st + 1 : last;  // (the last step re-reads its own fragments: no branch in the stream)
+      frag8 fn[3];
+#pragma unroll
+      for (int mi = 0; mi < 3; ++mi) fn[mi] = *reinterpret_cast<const frag8*>(arow + mi * 16 * kRowBytes + (((sn * 4 + ks) ^ x) << 4));
+      __builtin_amdgcn_sched_barrier(0);
+      const char* pf = q < ng - 1 ? cur + (q + 1) * 16384 + j * 4096 : (j < 2 ? nxt + j * 4096 : nxt + ns + (j - 2) * 4096);
+      const gptr_t g0 = uniform_ptr(pf);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+#pragma unroll
+        for (int mi = 0; mi < 3; ++mi) acc[mi][ni] = cmfma<T>(ring[j & 1][(j >> 1) * 4 + ni], fa[mi], acc[mi][ni]);
+        ring[j & 1][(j >> 1) * 4 + ni] = *reinterpret_cast<gfrag_t>(g0 + loff + ni * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 3; ++mi) fa[mi] = fn[mi];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+// the wave's first weight fragments of a gemm64 segment (four K-steps of the one slab)
+__device__ __forceinline__ void ring_prologue64(frag8 (&ring)[2][8], const char* f0, uint32_t loff) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const gptr_t g0 = uniform_ptr(f0 + j * 4096);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      ring[j & 1][(j >> 1) * 4 + ni] = *reinterpret_cast<gfrag_t>(g0 + loff + ni * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+// The wave's 48 x 64 block (acc[mi][0..3], wave w8 of eight: columns 64 w8 ..) + vec[column] + the values the panel buffer `dst` holds at
+// the same positions (the projection's bias and the skip rows), rounded to the model dtype back into `dst`; acc keeps the ROUNDED values;
+// per-wave (mean, M2) of every row over the wave's 64 columns -> red[row][w8].
+template <typename T>
+__device__ __forceinline__ void round_rows64_add_stats(f32x4 (&acc)[3][8], unsigned char* dst, float* red, int lane, int w8, const unsigned char* vec) {
+  const LaneCtx lc = lane_ctx(lane, w8);
+#pragma unroll
+  for (int mi = 0; mi < 3; ++mi) {
+    unsigned char* drow = dst + (mi * 16 + lc.x) * kRowBytes;
+    u32x2 rb[4], rr[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      rb[ni] = *reinterpret_cast<const u32x2*>(vec + (w8 * 64 + ni * 16 + lc.g * 4) * 2);
+      rr[ni] = *reinterpret_cast<const u32x2*>(drow + lc.coff[ni]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      float o[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
+      float b[4], r[4];
+      unpack4<T>(rb[ni], b);
+      unpack4<T>(rr[ni], r);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] += b[k] + r[k];
+      const u32x2 pk = pack4<T>(o);
+      *reinterpret_cast<u32x2*>(drow + lc.coff[ni]) = pk;
+      unpack4<T>(pk, o);
+      acc[mi][ni] = f32x4{o[0], o[1], o[2], o[3]};
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) s += (acc[mi][ni][0] + acc[mi][ni][1]) + (acc[mi][ni][2] + acc[mi][ni][3]);
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    const float mw = s * (1.0f / 64.0f);
+    float q = 0.f;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = acc[mi][ni][r] - mw;
+        q = fmaf(d, d, q);
+      }
+    q += __shfl_xor(q, 16, 64);
+    q += __shfl_xor(q, 32, 64);
+    if (lc.g == 0) *reinterpret_cast<float2*>(red + ((mi * 16 + lc.x) * 8 + w8) * 2) = make_float2(mw, q);
+  }
+}
+// LayerNorm without the affine part from eight 64-column partials per row (merged in wave order, Chan et al.): the rounded values in
+// acc[mi][0..3] normalised and stored (model dtype) into the panel buffer `dst`.
+template <typename T>
+__device__ __forceinline__ void normalise_rows64(const f32x4 (&acc)[3][8], const float* red, float eps, unsigned char* dst, int lane, int w8) {
+  const LaneCtx lc = lane_ctx(lane, w8);
+#pragma unroll
+  for (int mi = 0; mi < 3; ++mi) {
+    const f32x4* pr = reinterpret_cast<const f32x4*>(red + (mi * 16 + lc.x) * 16);
+    const f32x4 p0 = pr[0], p1 = pr[1], p2 = pr[2], p3 = pr[3];
+    const float mu = (((p0[0] + p0[2]) + (p1[0] + p1[2])) + ((p2[0] + p2[2]) + (p3[0] + p3[2]))) * 0.125f;
+    float m2 = ((p0[1] + p0[3]) + (p1[1] + p1[3])) + ((p2[1] + p2[3]) + (p3[1] + p3[3]));
+    const float d0 = p0[0] - mu, d1 = p0[2] - mu, d2 = p1[0] - mu, d3 = p1[2] - mu;
+    const float d4 = p2[0] - mu, d5 = p2[2] - mu, d6 = p3[0] - mu, d7 = p3[2] - mu;
+    m2 = fmaf(64.0f, ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) + ((d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7)), m2);
+    const float rstd = rsqrtf(m2 * (1.0f / (float)kCh) + eps);
+    const float nm = -mu * rstd;
+    unsigned char* drow = dst + (mi * 16 + lc.x) * kRowBytes;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      float o[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = fmaf(acc[mi][ni][r], rstd, nm);
+      *reinterpret_cast<u32x2*>(drow + lc.coff[ni]) = pack4<T>(o);
     }
   }
 }
@@ -310,20 +439,6 @@ template <bool PART>
 __device__ __forceinline__ void touch_done(Warm& w) {
   if constexpr (PART) asm volatile("" : "+v"(w.v[0]), "+v"(w.v[1]), "+v"(w.v[2]));
   else asm volatile("" : "+v"(w.v[0]));
-}
-
-// A barrier among the FOUR waves of one group (the hardware barrier counts all eight): a monotonic LDS counter.  LDS operations of a
-// wave complete in order, so whoever sees a wave's increment sees what it wrote before.  Bounded: a miscount must not hang the GPU.
-__device__ __forceinline__ void group4_barrier(unsigned* ctr, unsigned& epoch, int lane) {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  epoch += 4;
-  if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  for (int it = 0; it < (1 << 16); ++it) {
-    const unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-    if ((int)(v - epoch) >= 0) break;
-    __builtin_amdgcn_s_sleep(1);
-  }
-  asm volatile("" ::: "memory");
 }
 
 }  // namespace anemoi

@@ -171,6 +171,18 @@ inline int env_int(const char* e, int dflt, int lo, int hi) {
   return (int)v;
 }
 
+// Switches that exist for timing experiments only - some of them make a kernel skip part of its work, i.e. return WRONG results - are
+// compiled into the library only with -DANEMOI_EXPERIMENTS (`python -m anemoi_core_amd.build --experiments` -> lib/libanemoi_hip_exp.so,
+// together with csrc/experiments/*.hip and the in-kernel timeline instantiations).  In the product library they are constants: no
+// environment variable can change what a kernel computes, and `nm` / `strings` of the .so show none of their names (tests/test_abi_cpu.py).
+#ifdef ANEMOI_EXPERIMENTS
+constexpr bool kExperiments = true;
+#define ANEMOI_EXPERIMENT_ENV(name, dflt, lo, hi) ::anemoi::env_int(getenv(name), dflt, lo, hi)
+#else
+constexpr bool kExperiments = false;
+#define ANEMOI_EXPERIMENT_ENV(name, dflt, lo, hi) (dflt)
+#endif
+
 struct PerDeviceOnce {
   std::once_flag flag[64];
   // Runs f once per device and returns only after it HAS run (a second thread waits instead of launching ahead of the

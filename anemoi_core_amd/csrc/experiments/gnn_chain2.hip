@@ -13,11 +13,29 @@
 // MEASURED (profiles/r05_gnn_edge_chain_role_split.txt): parity-green and SLOWER than the symmetric kernel - 212 against 195 us at
 // 81 840 rows (a lock-step two-role form with three 48-row buffers, built first: 198-205 us).  The chain is bound by the CU's L1 path
 // times the number of passes over the 1.5 MB of weights, and 40 / 48-row panels need 7-8 passes where the symmetric kernel's 64-row
-// panels need 5.  ANEMOI_GNN_CHAIN_V2=1 selects this kernel; the default stays the symmetric one.
+// panels need 5.  EXPERIMENTS BUILD ONLY (python -m anemoi_core_amd.build --experiments -> lib/libanemoi_hip_exp.so, then
+// ANEMOI_HIP_LIB=.../libanemoi_hip_exp.so ANEMOI_GNN_CHAIN_V2=1 selects this kernel); the product library does not contain it.
 #include "chain2_core.h"
 #include "gnn_chain_args.h"
 
 namespace anemoi {
+
+// A barrier among the FOUR waves of one group (the hardware barrier counts all eight): a monotonic LDS counter.  LDS operations of a
+// wave complete in order, so whoever sees a wave's increment sees what it wrote before.  Bounded: a miscount must not hang the GPU - and must not go unnoticed either (it traps).
+__device__ __forceinline__ void group4_barrier(unsigned* ctr, unsigned& epoch, int lane) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  epoch += 4;
+  if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  bool ok = false;
+  for (int it = 0; it < (1 << 16); ++it) {
+    const unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    if ((int)(v - epoch) >= 0) { ok = true; break; }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  if (!ok) __builtin_trap();  // a miscount must neither hang the GPU nor carry on over an incomplete panel: the launch FAILS (check_launch / the next sync)
+  asm volatile("" ::: "memory");
+}
+
 
 constexpr int kG2RedOff = 2 * kBufBytes;                     // per group [48 rows][4 waves][2] fp32 LayerNorm partials
 constexpr int kG2VecOff = kG2RedOff + 2 * kPanel * 4 * 2 * 4;  // b_0 | b_1 | b_2 | gamma | beta (16-bit)
@@ -234,6 +252,9 @@ static int launch2(const EdgeChainArgs& a, hipStream_t st) {
 
 int launch_edge_chain2(const EdgeChainArgs& a0, int dtype, void* stream, bool mlp) {
   EdgeChainArgs a = a0;
+  // this kernel copies the per-column vectors as 16-byte pieces (the symmetric kernel, whose entry points validate the operands, reads 8-byte ones)
+  const auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  ANEMOI_REQUIRE(al16(a.b0) && al16(a.b1) && al16(a.b2) && al16(a.ln_g) && al16(a.ln_b), "gnn_edge_chain2: the bias / LayerNorm vectors must be 16-byte aligned");
   // experiments (timing only, results are garbage): bit 0 no GELU arithmetic, 1 no gathered rows, 2 no residual rows, 3 no global stores
   static const int dbg = env_int(getenv("ANEMOI_EDGE_CHAIN2_DBG"), 0, 0, 15);
   a.dbg = dbg;

@@ -29,11 +29,46 @@ constexpr int kWavesPerBlock = ANEMOI_ATTN_WPB;
 #endif
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 // Where a destination's loads are requested (profiles/r05_attention_header_ab.txt, same-box A/Bs): the source ids travel WITH the q slice,
-// ahead of the qw set-up (-6 % of the launch), and the scalar part of the next header (id, edge range) one destination ahead.  The
-// round-5 variants that were measured slower or equal - first header beside the W' staging, first ring fill ahead of the qw set-up,
-// next header behind the edge loop, the lane split of the feature terms, the timing-only ablation builds - live in
-// csrc/experiments/gt_attention_r05_variants.hip (tools/build_alt.sh builds them into an alternative library for same-box A/Bs).
-constexpr int kAttnPF = 3;  // edges of K|V rows in flight per wave (modulo-unrolled ring, counted waits)
+// ahead of the qw set-up (-6 % of the launch), and the scalar part of the next header one destination ahead (ANEMOI_ATTN_SCALAR_PF).
+// ANEMOI_ATTN_EARLY_HDR (first header beside the W' staging) and ANEMOI_ATTN_EARLY_RING (1: first K|V ring fill, 2: its K slices only,
+// ahead of the qw set-up) were built and measured slower - they cost the fifth resident wave or spill - and default to 0.
+// Timing-only ablations of the fused-edge kernel (tools/ab_attn_ablate.sh; results are WRONG with any bit set, default 0):
+// 1 = no qw set-up per destination, 2 = no W' * sum(p a) at the end, 4 = no per-edge feature terms (score, sums, scalar loads),
+// 16 = no W' staging, 32 = every edge gathers source row 0 (no cache misses in the gather).
+#ifndef ANEMOI_ATTN_DBG
+#define ANEMOI_ATTN_DBG 0
+#endif
+constexpr int kAttnDbg = ANEMOI_ATTN_DBG;
+#ifndef ANEMOI_ATTN_EARLY_HDR
+#define ANEMOI_ATTN_EARLY_HDR 0
+#endif
+constexpr bool kEarlyHdr = ANEMOI_ATTN_EARLY_HDR != 0;
+#ifndef ANEMOI_ATTN_EARLY_RING
+#define ANEMOI_ATTN_EARLY_RING 0
+#endif
+constexpr int kEarlyRing = ANEMOI_ATTN_EARLY_RING;
+#ifndef ANEMOI_ATTN_SCALAR_PF
+#define ANEMOI_ATTN_SCALAR_PF 1
+#endif
+constexpr bool kScalarPf = ANEMOI_ATTN_SCALAR_PF != 0;
+// ANEMOI_ATTN_HDR_AHEAD: the NEXT destination's q slice and source ids are requested behind the edge loop, in front of the W' * sum(p a)
+// epilogue and the store (1), and the first destination's beside the W' staging loads as well (2); needs ANEMOI_ATTN_SCALAR_PF.
+#ifndef ANEMOI_ATTN_HDR_AHEAD
+#define ANEMOI_ATTN_HDR_AHEAD 0
+#endif
+constexpr int kHdrAhead = ANEMOI_ATTN_HDR_AHEAD;
+static_assert(kHdrAhead == 0 || (kScalarPf && !kEarlyHdr), "ANEMOI_ATTN_HDR_AHEAD needs ANEMOI_ATTN_SCALAR_PF=1 and ANEMOI_ATTN_EARLY_HDR=0");
+// ANEMOI_ATTN_FSPLIT (heads of 4 lanes, FE_PAD % 4 == 0): the edge-feature terms of a head are shared out among its four lanes (FE_PAD / 4
+// features per lane, fetched by one per-lane vector load; the head butterfly that finishes <q, k> adds the shares up, the weighted feature
+// sums are kept per lane and gathered with quad broadcasts once per destination).  Round 3 built this on the three-deep ring and measured
+// it slower (profiles/r03_attention_fsplit_ab.txt); on the reordered kernel with a two-deep ring it needs 74 VGPRs (six waves) and wins 7 % of
+// the res-6 launch back to back but LOSES 1.0-1.5 % inside the forward (profiles/r05_attention_fsplit_ab.txt): default 0.
+#ifndef ANEMOI_ATTN_FSPLIT
+#define ANEMOI_ATTN_FSPLIT 0
+#endif
+#ifndef ANEMOI_ATTN_PF
+#define ANEMOI_ATTN_PF 3
+#endif
 
 template <int VEC>
 struct EdgeRow {
@@ -151,6 +186,14 @@ struct WLayout {
   static constexpr int kFloats = 64 * kChunk;
 };
 
+// (An FSPLIT variant - the FE_PAD edge-feature terms of a head shared out among its LPH lanes, FE_PAD / LPH per lane, fetched by
+// one per-lane vector load instead of scalar loads - lived here in commits 99a7806..49471db: parity-green, 8 of ~45 VALU slots per
+// edge fewer, and SLOWER on MI355X, 26.7 -> 29.7 us at res 5 and 91.8 -> 95.2 us at res 6 (profiles/r03_attention_fsplit_ab.txt):
+// the third vector-memory instruction per edge costs more than the VALU slots it frees.  Removed again.)
+// (Also tried, round 3: the PREFIX of a wave's next destination - work-order position and colptr words as scalar loads, the source ids
+// of its first 64 in-edges by LDS-DMA into a wave-private slot, so that no register is held during the flight - requested while the
+// current destination is worked on.  Parity-green; 96 VGPRs + 2 spilled at 5 waves per SIMD (100 without the cap = 4 waves), and
+// the O96 forward went from 2.99-3.00 to 3.02-3.03 ms on the same box in two placements of the request.  Not kept.)
 template <typename T, int VEC, int LPH, int FE_PAD, bool KVADJ>
 __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt_attn_fused_edge_fwd_kernel(
     const T* __restrict__ q, int64_t ldq, const T* __restrict__ k, int64_t ldk, const T* __restrict__ v, int64_t ldv,
@@ -161,6 +204,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt
   extern __shared__ __attribute__((aligned(16))) float w_lds[];  // [64][kChunk]
   const int lane = threadIdx.x & 63;
   const int c0 = lane * VEC;
+  constexpr bool FS = ANEMOI_ATTN_FSPLIT != 0 && LPH == 4 && FE_PAD % 4 == 0 && !(kAttnDbg & 4);
+  constexpr int FPL = FS ? FE_PAD / LPH : 1;  // features a lane carries (FSPLIT)
+  const int hl = lane & (LPH - 1);            // this lane's place in its head
 
   // XCD-aware persistent schedule.  Workgroup b runs on XCD b % 8 (observed dispatch order; only speed depends on
   // it).  Each XCD gets one CONTIGUOUS slice of the destination range, so the K/V rows its waves gather (the mesh
@@ -175,9 +221,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt
   const int d_hi = min(n_dst, d_lo + per_xcd);
 
   using Raw = Vec<T, VEC>;  // a row slice as loaded (converted to fp32 only when consumed)
-  // The header of a destination: its id and edge range (scalar registers, requested ONE DESTINATION AHEAD - the first one's in front of
-  // the W' staging - so that a destination starts with its q slice and source ids, not with colptr), its q row slice and the source
-  // ids of its first 64 in-edges.
+  // The header of a destination: its id, its edge range, its q row slice and the source ids of its first 64 in-edges.  The FIRST
+  // destination's header is requested beside the W' staging loads (ANEMOI_ATTN_EARLY_HDR, default on): its two dependent trips
+  // (colptr -> source ids) overlap the staging round trip instead of following the workgroup barrier.
   const int i0 = d_lo + wave_in_xcd;
   int h_d = 0, h_beg = 0, h_end = 0, h_src = 0;
   Raw h_q;
@@ -186,11 +232,20 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt
     beg = __builtin_amdgcn_readfirstlane(colptr[d]);
     end = __builtin_amdgcn_readfirstlane(colptr[d + 1]);
   };
+  auto load_header = [&](int i, int& d, int& beg, int& end, Raw& qr, int& src) {
+    if constexpr (!kScalarPf) load_scalars(i, d, beg, end);
+    qr = *reinterpret_cast<const Raw*>(q + (int64_t)d * ldq + c0);
+    src = (lane < end - beg) ? row[beg + lane] : 0;
+  };
+  // ANEMOI_ATTN_SCALAR_PF: the scalar part of a header (id, edge range: scalar registers only) is requested one destination ahead -
+  // the first one's in front of the W' staging - so that a destination starts with its q slice and source ids, not with colptr.
   int n_d = 0, n_beg = 0, n_end = 0;
-  if (i0 < d_hi) load_scalars(i0, n_d, n_beg, n_end);
+  if constexpr (kScalarPf) {
+    if (i0 < d_hi) load_scalars(i0, n_d, n_beg, n_end);
+  }
   // Stage W' = [W_e | b_e | 0] (fp32 [D][FE_PAD], packed once on the host side of the ABI) into LDS: all 16-byte
   // loads are issued before the first write (one memory round trip per workgroup).
-  {
+  if constexpr (!(kAttnDbg & 16)) {
     constexpr int kQ = FE_PAD / 4;                 // float4 per channel row
     constexpr int kTotal = 64 * VEC * kQ;          // float4 in the image
     constexpr int kIter = (kTotal + 64 * kWavesPerBlock - 1) / (64 * kWavesPerBlock);
@@ -199,6 +254,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt
     for (int it = 0; it < kIter; ++it) {
       const int idx = threadIdx.x + it * 64 * kWavesPerBlock;
       tmp[it] = idx < kTotal ? reinterpret_cast<const float4*>(w_packed)[idx] : float4{0.f, 0.f, 0.f, 0.f};
+    }
+    if constexpr (kHdrAhead == 2) {
+      if (i0 < d_hi) {
+        h_d = n_d, h_beg = n_beg, h_end = n_end;
+        load_header(i0, h_d, h_beg, h_end, h_q, h_src);
+      }
+    }
+    if constexpr (kEarlyHdr) {
+      if (i0 < d_hi) { if constexpr (kScalarPf) { h_d = n_d, h_beg = n_beg, h_end = n_end; } load_header(i0, h_d, h_beg, h_end, h_q, h_src); }
     }
 #pragma unroll
     for (int it = 0; it < kIter; ++it) {
@@ -213,12 +277,21 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt
       }
     }
   }
+  if constexpr (kEarlyHdr && (kAttnDbg & 16) != 0) {
+    if (i0 < d_hi) { if constexpr (kScalarPf) { h_d = n_d, h_beg = n_beg, h_end = n_end; } load_header(i0, h_d, h_beg, h_end, h_q, h_src); }
+  }
+  if constexpr (kHdrAhead == 1 || (kHdrAhead == 2 && (kAttnDbg & 16) != 0)) {
+    if (i0 < d_hi) {
+      h_d = n_d, h_beg = n_beg, h_end = n_end;
+      load_header(i0, h_d, h_beg, h_end, h_q, h_src);
+    }
+  }
   __syncthreads();
   const float* wl = w_lds + lane * L::kChunk;
 
   const float sl2e = scale * 1.4426950408889634f;  // p = 2^((s' - m') * scale * log2 e)
   const float thr = kDeferThr / scale;
-  constexpr int PF = kAttnPF;
+  constexpr int PF = ANEMOI_ATTN_PF;     // edges in flight per wave (modulo-unrolled: no register rotation, counted waits)
 
   // `order` (optional): the destination processed at position i.  The ~768 destinations an XCD works on at one moment are
   // then a compact patch of the mesh instead of a whole latitude ring, so the K|V rows they gather fit that XCD's L2
@@ -227,10 +300,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt
     // W' lives in LDS and is re-read per destination: without this barrier the compiler hoists all VEC*FE_PAD values
     // into registers across the loop (256 VGPRs, 1 wave/SIMD) and the kernel becomes latency-bound.
     asm volatile("" ::: "memory");
-    h_d = n_d, h_beg = n_beg, h_end = n_end;
-    h_q = *reinterpret_cast<const Raw*>(q + (int64_t)h_d * ldq + c0);
-    h_src = (lane < h_end - h_beg) ? row[h_beg + lane] : 0;
-    if (i + waves_in_xcd < d_hi) load_scalars(i + waves_in_xcd, n_d, n_beg, n_end);
+    if constexpr (kScalarPf && kHdrAhead == 0) {
+      h_d = n_d, h_beg = n_beg, h_end = n_end;
+    }
+    if constexpr (kHdrAhead == 0) {
+      if (!kEarlyHdr || i != i0) load_header(i, h_d, h_beg, h_end, h_q, h_src);
+    }
+    if constexpr (kScalarPf) {
+      if (i + waves_in_xcd < d_hi) load_scalars(i + waves_in_xcd, n_d, n_beg, n_end);
+    }
     const int d = h_d, beg = h_beg, end = h_end;
     const Raw q_raw = h_q;
     float qv[VEC], acc[VEC];
@@ -242,29 +320,52 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt
     // Scores are kept in units of 1/scale (s' = <q, k + e>, the softmax argument is scale * s'): the scale rides in the
     // exponent's multiplier (one multiply per edge less).
     // Edge loop in chunks of 64: the source ids of a chunk are fetched with ONE coalesced load (lane j holds
-    // row[chunk + j]) and broadcast with v_readlane, so row loads never wait on a dependent scalar load.
+    // row[chunk + j]) and broadcast with v_readlane, so row loads never wait on a dependent scalar load.  The ring of the FIRST
+    // chunk is filled here, ahead of the qw set-up (ANEMOI_ATTN_EARLY_RING): the K|V round trip runs beside that arithmetic.
     int chunk = beg, n = min(64, end - beg), my_src = h_src;  // the first chunk's ids came with the header
     Raw kb[PF], vb[PF];
     float fb[PF][FE_PAD];
-    auto fetch = [&](int j, Raw& kr, Raw& vr, float (&fr)[FE_PAD]) {
+    float fv[PF][FPL];
+    auto fetch = [&](int j, Raw& kr, Raw& vr, float (&fr)[FE_PAD], float (&fvr)[FPL], int what = 3) {  // what: 1 = the K slice, 2 = V + features
       j = min(j, n - 1);  // refills past the end re-read the last edge: an UNCONDITIONAL load keeps the ring registers
                           // free of select/copy code (a conditional one made the compiler wait for the load at once)
-      const int s = __builtin_amdgcn_readlane(my_src, j);
-      const float* a = feat + (int64_t)(chunk + j) * FE_PAD;  // wave-uniform address -> scalar loads
+      const int s = (kAttnDbg & 32) ? (__builtin_amdgcn_readlane(my_src, j) & 1) : __builtin_amdgcn_readlane(my_src, j);
+      const float* a;  // wave-uniform address -> scalar loads
       if constexpr (KVADJ) {
         // v = the D columns after k in the same buffer (the fused projection's layout): ONE address and an immediate
         // offset; the row offset in 32 bits (checked at launch) - 13 scalar instructions fewer per edge, and this
         // kernel is bound by instruction issue
         const T* kp = k + (uint32_t)((uint32_t)s * (uint32_t)ldk) + c0;
-        kr = *reinterpret_cast<const Raw*>(kp);
-        vr = *reinterpret_cast<const Raw*>(kp + 64 * VEC);
+        if (what & 1) kr = *reinterpret_cast<const Raw*>(kp);
+        if (what & 2) vr = *reinterpret_cast<const Raw*>(kp + 64 * VEC);
+        a = feat + (int64_t)(chunk + j) * FE_PAD;
       } else {
-        kr = *reinterpret_cast<const Raw*>(k + (int64_t)s * ldk + c0);
-        vr = *reinterpret_cast<const Raw*>(v + (int64_t)s * ldv + c0);
+        if (what & 1) kr = *reinterpret_cast<const Raw*>(k + (int64_t)s * ldk + c0);
+        if (what & 2) vr = *reinterpret_cast<const Raw*>(v + (int64_t)s * ldv + c0);
+        a = feat + (int64_t)(chunk + j) * FE_PAD;
       }
+      if constexpr (FS) {
+        if (what & 2) {  // this lane's FPL features of the edge: uniform base + per-lane offset -> one vector load per lane
+          struct __attribute__((packed, aligned(4))) Feats {
+            float v[FPL];
+          };
+          const Feats t = *reinterpret_cast<const Feats*>(a + hl * FPL);
 #pragma unroll
-      for (int f = 0; f < FE_PAD; ++f) fr[f] = a[f];
+          for (int f = 0; f < FPL; ++f) fvr[f] = t.v[f];
+        }
+      } else if constexpr (!(kAttnDbg & 4)) {
+        if (what & 2) {
+#pragma unroll
+          for (int f = 0; f < FE_PAD; ++f) fr[f] = a[f];
+        }
+      }
     };
+    if constexpr (kEarlyRing != 0) {  // 1: K, V and the features; 2: the K slices only (V + features behind the qw set-up)
+      if (beg < end) {
+#pragma unroll
+        for (int st = 0; st < PF; ++st) fetch(st, kb[st], vb[st], fb[st], fv[st], kEarlyRing == 2 ? 1 : 3);
+      }
+    }
     // qw[f] = (1/LPH) * sum over the head's channels of q[c] * W'[c][f]  (pre-divided: every lane of the
     // head adds the same edge-feature term before the head butterfly).
     float qw[FE_PAD], sf[FE_PAD];
@@ -273,6 +374,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt
       // W' is stored [feature][channel] per lane: the VEC channels of a feature are contiguous (16-byte LDS reads) and
       // the channel pairs map onto packed FMAs without shuffles, here and in the final W' * sum(p a)
       float t = 0.f;
+      if constexpr (kAttnDbg & 1) {
+        qw[f] = qv[f % VEC];
+        sf[f] = 0.f;
+        continue;
+      }
       if constexpr (VEC % 2 == 0) {
         f32x2 t2 = {0.f, 0.f};
 #pragma unroll
@@ -283,8 +389,20 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt
 #pragma unroll
         for (int j = 0; j < VEC; ++j) t = fmaf(qv[j], wl[f * VEC + j], t);
       }
-      qw[f] = group_sum<LPH>(t) * (1.0f / LPH);
+      // pre-divided: every lane of the head adds the same edge-feature term (FSPLIT: each lane its own share of it, undivided)
+      qw[f] = group_sum<LPH>(t) * (FS ? 1.0f : 1.0f / LPH);
       sf[f] = 0.f;
+    }
+    float qws[FPL], sfs[FPL];  // FSPLIT: this lane's share of qw (features hl * FPL + i) and of the weighted feature sums
+    if constexpr (FS) {
+#pragma unroll
+      for (int i = 0; i < FPL; ++i) {
+        float sel = qw[i];
+#pragma unroll
+        for (int g = 1; g < LPH; ++g) sel = (hl == g) ? qw[g * FPL + i] : sel;
+        qws[i] = sel;
+        sfs[i] = 0.f;
+      }
     }
     float m = -INFINITY, l = 0.f;
 
@@ -293,15 +411,26 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt
         n = min(64, end - chunk);
         my_src = (lane < n) ? row[chunk + lane] : 0;
       }
+      if (kEarlyRing == 0 || chunk != beg) {
 #pragma unroll
-      for (int st = 0; st < PF; ++st) fetch(st, kb[st], vb[st], fb[st]);
+        for (int st = 0; st < PF; ++st) fetch(st, kb[st], vb[st], fb[st], fv[st]);
+      } else if constexpr (kEarlyRing == 2) {
+#pragma unroll
+        for (int st = 0; st < PF; ++st) fetch(st, kb[st], vb[st], fb[st], fv[st], 2);
+      }
       for (int j0 = 0; j0 < n; j0 += PF) {
 #pragma unroll
         for (int st = 0; st < PF; ++st) {
           const int j = j0 + st;
           if (j < n) {
             float dot = dot_rows<T, VEC>(q_raw, kb[st]);
-            if constexpr (FE_PAD % 2 == 0) {  // feature pairs on packed FMAs (scalar-register pairs as loaded)
+            if constexpr (kAttnDbg & 4) {
+            } else if constexpr (FS) {  // this lane's share of the feature term; the head butterfly below adds the shares up
+              float fs = 0.f;
+#pragma unroll
+              for (int f = 0; f < FPL; ++f) fs = fmaf(fv[st][f], qws[f], fs);
+              dot += fs;
+            } else if constexpr (FE_PAD % 2 == 0) {  // feature pairs on packed FMAs (scalar-register pairs as loaded)
               f32x2 d2[2] = {{dot, 0.f}, {0.f, 0.f}};  // two chains: dependent packed FMAs back to back cost a wait state each
 #pragma unroll
               for (int f = 0; f < FE_PAD; f += 2)
@@ -319,23 +448,48 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt
               l *= corr;
 #pragma unroll
               for (int jj = 0; jj < VEC; ++jj) acc[jj] *= corr;
+              if constexpr (FS) {
 #pragma unroll
-              for (int f = 0; f < FE_PAD; ++f) sf[f] *= corr;
+                for (int f = 0; f < FPL; ++f) sfs[f] *= corr;
+              } else {
+#pragma unroll
+                for (int f = 0; f < FE_PAD; ++f) sf[f] *= corr;
+              }
               m = m_new;
             }
             const float p = __builtin_amdgcn_exp2f((dot - m) * sl2e);
             l += p;
 #pragma unroll
             for (int jj = 0; jj < VEC; ++jj) acc[jj] = fmaf(p, to_float(vb[st].v[jj]), acc[jj]);
+            if constexpr (FS) {
 #pragma unroll
-            for (int f = 0; f < FE_PAD; ++f) sf[f] = fmaf(p, fb[st][f], sf[f]);
-            fetch(j + PF, kb[st], vb[st], fb[st]);
+              for (int f = 0; f < FPL; ++f) sfs[f] = fmaf(p, fv[st][f], sfs[f]);
+            } else if constexpr (!(kAttnDbg & 4)) {
+#pragma unroll
+              for (int f = 0; f < FE_PAD; ++f) sf[f] = fmaf(p, fb[st][f], sf[f]);
+            }
+            fetch(j + PF, kb[st], vb[st], fb[st], fv[st]);
           }
         }
       }
     }
 
+    if constexpr (kHdrAhead != 0) {  // the next destination's q slice and source ids travel beside the epilogue
+      if (i + waves_in_xcd < d_hi) {
+        h_d = n_d, h_beg = n_beg, h_end = n_end;
+        load_header(i + waves_in_xcd, h_d, h_beg, h_end, h_q, h_src);
+      }
+    }
     asm volatile("" ::: "memory");
+    if constexpr (FS) {  // the head's weighted feature sums, all of them in every lane again: quad broadcasts
+#pragma unroll
+      for (int i = 0; i < FPL; ++i) {
+        sf[0 * FPL + i] = dpp_f<0x00>(sfs[i]);
+        sf[1 * FPL + i] = dpp_f<0x55>(sfs[i]);
+        sf[2 * FPL + i] = dpp_f<0xAA>(sfs[i]);
+        sf[3 * FPL + i] = dpp_f<0xFF>(sfs[i]);
+      }
+    }
     const float inv = (end > beg) ? 1.0f / l : 0.f;
     float o[VEC];
     if constexpr (VEC % 2 == 0) {
@@ -343,7 +497,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt
 #pragma unroll
       for (int j = 0; j < VEC; j += 2) o2[j / 2] = f32x2{acc[j], acc[j + 1]};
 #pragma unroll
-      for (int f = 0; f < FE_PAD; ++f) {
+      for (int f = 0; f < ((kAttnDbg & 2) ? 0 : FE_PAD); ++f) {
         const f32x2 s2 = {sf[f], sf[f]};
 #pragma unroll
         for (int j = 0; j < VEC; j += 2) o2[j / 2] = __builtin_elementwise_fma(s2, *reinterpret_cast<const f32x2*>(wl + f * VEC + j), o2[j / 2]);

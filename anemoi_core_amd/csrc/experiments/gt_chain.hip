@@ -22,6 +22,7 @@
 // LayerNorm is the real thing (fp32 statistics of the rounded 16-bit rows, per-wave (mean, M2) partials merged with Chan's
 // formula: no E[x^2] - mean^2 cancellation), its output rounded to the model dtype as the reference's autocast does.
 #include "chain_core.h"
+#include "anemoi_hip_experiments.h"
 
 namespace anemoi {
 
@@ -382,21 +383,6 @@ static int launch_chain(const ChainArgs& a, hipStream_t st) {
 }  // namespace anemoi
 
 using namespace anemoi;
-
-extern "C" int anemoi_gt_chain_rows_per_tile(int32_t n_rows) {
-  // One round (the rows fit 256 panels): the TALLEST panels, i.e. the fewest CUs - every busy CU streams the whole layer's weights whatever
-  // its panel's height, and the CUs of an XCD share that L2's bandwidth: 10 242 rows as 214 panels of 48 instead of 250 of 41 is 4 % of the
-  // O96 forward (profiles/r05_chain2_touch_coverage.txt; it needs the warm-up's shares to follow the workgroup count, chain2_core.h).
-  // Several rounds: whole rounds of panels over the 256 CUs, panels as even as the 48-row limit allows.
-  static const int forced = env_int(getenv("ANEMOI_CHAIN_ROWS"), 0, 0, kPanel);
-  if (forced > 0) return forced;
-  if (n_rows <= 0) return kPanel;
-  const int64_t rounds = ((int64_t)n_rows + 256 * kPanel - 1) / (256 * kPanel);
-  static const int balanced = env_int(getenv("ANEMOI_CHAIN_BALANCED"), 0, 0, 1);
-  if (rounds == 1 || !balanced) return kPanel;
-  const int64_t r = ((int64_t)n_rows + 256 * rounds - 1) / (256 * rounds);
-  return (int)(r < 1 ? 1 : (r > kPanel ? kPanel : r));
-}
 
 extern "C" int anemoi_gt_chain_fwd(const anemoi_gt_chain_args_t* p, anemoi_dtype_t dtype, void* stream) {
   ANEMOI_REQUIRE(p != nullptr, "gt_chain_fwd: null argument block");

@@ -1,3 +1,5 @@
+// NOT BUILT (kept for the record, round 6): gt_chain2.hip with the projection as a step of all eight waves - see the note in csrc/gt_chain2.hip and
+// profiles/r06_chain2_shared_projection_ab.txt (instrumented launch faster, forwards slower).  To A/B it: copy over csrc/gt_chain2.hip and rebuild.
 // Role-split row-resident layer chain for gfx950 (round 5): the row-local part of a GraphTransformer block in ONE launch, as
 // csrc/gt_chain.hip computes it -
 //
@@ -16,24 +18,21 @@
 // K-steps, pulls the layer's 6.5 MiB through the CU's L1 path as fast as eight waves do (66 us per layer, 103 GB/s per CU), in 200
 // registers; two such groups on the layer's schedule with GELU / convert / LDS-write epilogues and a barrier per step: 74 us.
 //
-// Roles.  Group A (waves 0-3): projection, the MLP's first Linear chunk by chunk (+ GELU), the even chunks of the trailing
-// projection.  Group B (waves 4-7; wave w + 4 shares a SIMD with wave w): the MLP's second Linear, accumulating over the hidden
-// chunks A produces (the two accumulator sets of the round-4 kernel's software pipeline now live in two different waves: 96
-// registers each), the x2 epilogue, the odd chunks of the trailing projection.  Per panel, one s_barrier per step:
+// Roles.  The projection is shared by ALL EIGHT waves (round 6: a 48 x 64 tile each, csrc/chain2_core.h gemm64 - its epilogue, x1 and the
+// LayerNorm, then costs an eighth of the panel per wave instead of a quarter with the other group idle).  Group A (waves 0-3): the MLP's
+// first Linear chunk by chunk (+ GELU), the even chunks of the trailing projection.  Group B (waves 4-7; wave w + 4 shares a SIMD with
+// wave w): the MLP's second Linear, accumulating over the hidden chunks A produces (the two accumulator sets of the round-4 kernel's
+// software pipeline now live in two different waves: 96 registers each), the x2 epilogue, the odd chunks of the trailing projection.
+// Per panel, one s_barrier per step:
 //
 //     S0  A: attention rows -> bufB            B: skip rows -> bufC
-//     S1  A: P = attn Wp^T, acc initialised with b_p + x; x1 rounded -> bufC, per-wave row statistics
-//     S2  A: LayerNorm (no affine) of x1 from registers -> bufB      B: acc2 = b_2 + x1 (from bufC)
+//     S1  all: P = attn Wp^T (64 columns per wave); x1 = P + b_p + x rounded -> bufC (over the skip rows), per-wave row statistics
+//     S2  all: LayerNorm (no affine) of x1 from registers -> bufB      B: acc2 = b_2 + x1 (from bufC)
 //     M_t (t = 0..hc)   A: M1(t): acc = d1[t]; GEMM on bufB; GELU -> h_t (bufA / bufC alternating)      B: M2(t-1): acc2 += h_(t-1) W2_t^T
 //                       (t = hc, B: x2 rounded -> the free h buffer, per-wave row statistics)
 //     S8  A: x2 rows [+ latent skip] -> global, whole 1-KiB rows      B: LayerNorm (no affine) of x2 from registers -> bufB
 //     Q_c A: chunk 2c, B: chunk 2c+1 of the trailing projection: acc = dq[chunk]; GEMM on bufB; rounded -> the group's own h buffer ->
 //         whole 256-byte row pieces to global
-//
-// (Round 6 built the projection as a step of ALL EIGHT waves - 48 x 64 tiles, gemm64 of chain2_core.h, x1 and the LayerNorm an eighth of the
-// panel per wave; twice: skip rows through group B before the first barrier, and all rows six per wave with the skip rows parked in registers
-// under the GEMM.  The instrumented launch got faster (91.9 against 95.3 us: projection 3.9-4.8 us, x1 2.0, LayerNorm 1.5-2.1) and the forwards
-// SLOWER on the same box: O96 +1.1 % / +1.6 %, res 6 +-0 / +1.4 % - profiles/r06_chain2_shared_projection_ab.txt.  This is the round-5 schedule.)
 //
 // LayerNorm.  The statistics are the plain fp32 LayerNorm statistics of the ROUNDED 16-bit rows (per-wave (mean, M2) over 128 columns,
 // merged with Chan's formula: no E[x^2] - mean^2 cancellation); the normalised row (x - mean) * rstd is rounded to the model dtype
@@ -66,8 +65,8 @@ struct Chain2Args {
   unsigned long long* timeline;             // developer aid (TL instantiation only): [workgroups][8 waves][kTl2Slots] s_memtime stamps
 };
 constexpr int kTl2Slots = 48;
-constexpr int kRed2Off = 3 * kBufBytes;                   // [48 rows][4 waves][2] fp32 LayerNorm partials
-constexpr int kVecOff = kRed2Off + kPanel * 4 * 2 * 4;    // the per-column vectors (16-bit)
+constexpr int kRed2Off = 3 * kBufBytes;                   // [48 rows][8 waves][2] fp32 LayerNorm partials (x1: eight 64-column waves; x2: four 128-column waves, [48][4][2] in the first 1 536 bytes)
+constexpr int kVecOff = kRed2Off + kPanel * 8 * 2 * 4;    // the per-column vectors (16-bit)
 constexpr int kVecMaxElems = 6144;                        // 12 KiB: 512 + hidden + 512 + q_out <= 6144 (hidden = q_out = 2048: 5120)
 constexpr int kChain2Smem = kVecOff + kVecMaxElems * 2;
 constexpr int kVecMaxElemsTl = 5120;                      // the instrumented instantiation gives 2 KiB of the vector region to its stamps
@@ -79,7 +78,16 @@ struct Ctx2 {
   int lane, wq, wave;
   uint32_t loff;
   int tl_n;
+  int tile0, tile_step, tile_end;  // this workgroup's panels: tile0, tile0 + tile_step, ... < tile_end
 };
+// Which panels a workgroup takes: b, b + grid, ...  (Round 6 also built an XCD-contiguous order - each XCD one contiguous range of panels,
+// the eighth of the node range whose attention rows the fused attention kernel's workgroups of the same XCD have just written - and measured
+// it: O96 +-0, res 6 -0.5 %, N320 -0.3 %, inside the run-to-run spread; not kept, profiles/r06_chain2_shared_projection_ab.txt.)
+__device__ __forceinline__ void tile_schedule(Ctx2& c, int n_tiles) {
+  c.tile0 = (int)blockIdx.x;
+  c.tile_step = (int)gridDim.x;
+  c.tile_end = n_tiles;
+}
 template <bool TL>
 __device__ __forceinline__ void stamp2(Ctx2& c, unsigned char* smem) {
   if constexpr (TL) {
@@ -116,7 +124,62 @@ __device__ __forceinline__ void set_chunk_prio(int on, int k) {
 }
 
 // Both roles execute the SAME number of s_barrier per panel (the hardware barrier counts arrivals, not program locations):
-// S0 | P GEMM | x1 | S2 | hc + 1 MLP steps | S8 | one behind the trailing projection (if any).
+// S0 | x1 | S2 | hc + 1 MLP steps | S8 | one behind the trailing projection (if any).
+
+// Six whole rows of the panel per wave (rows 6 w8 ..), eight waves: the FIRST panel's rows come in through all eight waves - the attention
+// rows into bufB before the first barrier, the skip rows requested right behind it and parked in registers under the projection GEMM (the
+// in-kernel timeline of the first shared-projection build: 7.5 us until both row sets were in LDS, 4.3 us for the attention rows alone).
+struct Rows6 {
+  u32x4 v[6];
+  template <typename T>
+  __device__ __forceinline__ void request(const T* src, int64_t ld, int r0, int nr, int lane, int w8) {
+    asm volatile("" : "+v"(lane), "+s"(w8));
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v[i] = stream_load(reinterpret_cast<const u32x4*>(src + (int64_t)(r0 + min(w8 * 6 + i, nr - 1)) * ld + lane * 8));
+  }
+  __device__ __forceinline__ void store(unsigned char* dst, int nr, int lane, int w8) {
+    asm volatile("" : "+v"(lane), "+s"(w8));
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int row = w8 * 6 + i;
+      *reinterpret_cast<u32x4*>(dst + row * kRowBytes + ((lane ^ (row & 15)) << 4)) = row < nr ? v[i] : u32x4{0u, 0u, 0u, 0u};
+    }
+  }
+};
+
+// S1 + S2, all eight waves (w8 = the wave's number in the workgroup = its 64-column slab of the projection): P on the attention rows in bufB
+// with the accumulators started at zero, then + b_p + the skip rows in bufC; x1 (rounded) over the skip rows it was computed from (each
+// lane rewrites the positions it read); LayerNorm_mlp(x1) without its affine part -> bufB (every wave has read the attention rows).
+// `after_gemm`: what the role queues behind its GEMM (group A: the L2 warm-up of the first MLP segments).  FIRST (the workgroup's first
+// panel): the skip rows are requested here, ride in registers under the GEMM and go to bufC behind it (one barrier more).
+template <typename T, bool TL, bool FIRST, typename After>
+__device__ __forceinline__ void projection_phase(const Chain2Args& a, Ctx2& c, unsigned char* smem, frag8 (&ring)[2][8], f32x4 (&acc)[3][8], const char* nxt,
+                                                 int64_t ns, int r0, int nr, After after_gemm) {
+  unsigned char* const bufB = smem + kBufBytes;
+  unsigned char* const bufC = smem + 2 * kBufBytes;
+  float* const red = reinterpret_cast<float*>(smem + kRed2Off);
+  const int w8 = __builtin_amdgcn_readfirstlane(c.wave);
+  stamp2<TL>(c, smem);
+  Rows6 skip;
+  if constexpr (FIRST) skip.request((const T*)a.xres, a.ld_x, r0, nr, c.lane, w8);
+#pragma unroll
+  for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  gemm64<T>(bufB, c.lane, ring, a.wp + (int64_t)w8 * kSlab, nxt, ns, c.loff, acc);
+  after_gemm();
+  stamp2<TL>(c, smem);
+  if constexpr (FIRST) {
+    skip.store(bufC, nr, c.lane, w8);
+    lds_barrier();  // the skip rows are in LDS
+  }
+  round_rows64_add_stats<T>(acc, bufC, red, c.lane, w8, smem + kVecOff);
+  stamp2<TL>(c, smem);
+  lds_barrier();  // x1 and the partials are complete; every wave is behind its last read of the attention rows
+  normalise_rows64<T>(acc, red, a.eps1, bufB, c.lane, w8);
+  stamp2<TL>(c, smem);
+}
+
 template <typename T, bool TL, bool PART>
 __device__ __forceinline__ void role_a(const Chain2Args& a, Ctx2& c, unsigned char* smem) {
   const int hc = a.hc, qc = a.qc, lane = c.lane, wq = __builtin_amdgcn_readfirstlane(c.wq);
@@ -124,12 +187,10 @@ __device__ __forceinline__ void role_a(const Chain2Args& a, Ctx2& c, unsigned ch
   // bufA: the even hidden chunks (x2 / group A's staged projection outputs when hc is even); bufB: the A operand of P, M1 and the
   // trailing projection (attention rows, LN(x1), LN'(x2)); bufC: skip rows, then x1, then the odd hidden chunks
   unsigned char* const bufB = smem + kBufBytes;
-  unsigned char* const bufC = smem + 2 * kBufBytes;
-  float* const red = reinterpret_cast<float*>(smem + kRed2Off);
   const unsigned char* const vec = smem + kVecOff;
   auto hbuf = [&](int t) { return smem + (t & 1) * (2 * kBufBytes); };
   const int64_t s1 = kSlab;
-  const char* const wpw = a.wp + (int64_t)(2 * wq) * kSlab;
+  const char* const wpw = a.wp + (int64_t)wq * kSlab;  // this wave's slab of the projection (wave w of eight: slab w)
   const int one = (dbg & 8) ? 0 : 1;  // (dbg & 8: every chunk reads chunk 0's weights - a 2-MB weight set that stays in the L2, timing experiments only)
   auto w1c = [&](int k) { return a.w1 + (int64_t)(8 * k * one + 2 * wq) * kSlab; };
   auto wqc = [&](int k) { return a.wq + (int64_t)(8 * k * one + 2 * wq) * kSlab; };
@@ -146,50 +207,40 @@ __device__ __forceinline__ void role_a(const Chain2Args& a, Ctx2& c, unsigned ch
     if (wq < 2) { if (sa != nullptr) touch_share<PART>(warm, sa, kSlab, wq & 1, lane); }
     else if (sb != nullptr) touch_share<PART>(warm, sb, pb, wq & 1, lane);
   };
-  // S0 of the first panel (peeled: straight-line code, so that the stores of the rows wait for the rows only): the attention rows ->
-  // bufB, requested AHEAD of the vectors, the warm-up and the weight ring's first fragments - loads return in order
+  // S0 of the first panel: the attention rows -> bufB through all eight waves (six rows each), requested AHEAD of the warm-up and the weight
+  // ring's first fragments - loads return in order
   {
-    const int r0 = (int)blockIdx.x * a.rows_per_tile;
-    load_rows12<T>((const T*)a.attn, a.ld_attn, r0, min(a.rows_per_tile, a.n_rows - r0), bufB, lane, wq, [&] {
-      stamp2<TL>(c, smem);  // rows requested
-      ring_prologue(ring, wpw, s1, c.loff);
-      // this CU's share of the projection's weights (waves 0, 1) and of M1(0)'s (waves 2, 3)
-      if (a.warm) touch_share<PART>(warm, wq < 2 ? a.wp : a.w1, kSlab, wq & 1, lane);
-      stamp2<TL>(c, smem);  // everything requested
-    });
+    const int r0 = c.tile0 * a.rows_per_tile;
+    const int nr0 = min(a.rows_per_tile, a.n_rows - r0);
+    Rows6 rows;
+    rows.request((const T*)a.attn, a.ld_attn, r0, nr0, lane, wq);
+    stamp2<TL>(c, smem);  // rows requested
+    ring_prologue64(ring, wpw, c.loff);
+    // this CU's share of the projection's weights (waves 0, 1) and of M1(0)'s (waves 2, 3)
+    if (a.warm) touch_share<PART>(warm, wq < 2 ? a.wp : a.w1, kSlab, wq & 1, lane);
+    stamp2<TL>(c, smem);  // everything requested
+    rows.store(bufB, nr0, lane, wq);
     stamp2<TL>(c, smem);  // rows stored
     lds_barrier();
   }
-  for (int tile = blockIdx.x;;) {
+  bool first = true;
+  for (int tile = c.tile0;;) {
     const int r0 = tile * a.rows_per_tile;
     const int nr = min(a.rows_per_tile, a.n_rows - r0);
-    stamp2<TL>(c, smem);
-    // S1: the projection on the attention rows alone - the skip rows and the per-column vectors come in through group B meanwhile (the
-    // CU's memory pipe holds ~64 wave-instructions: every load in front of the first MFMA costs its share of a 2-us round, in-kernel
-    // timeline) - then + b_p + x; x1 (rounded) over the skip rows it was computed from (each lane rewrites the positions it read)
-#pragma unroll
-    for (int mi = 0; mi < 3; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 8; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    gemm128<T>(bufB, lane, ring, wpw, s1, w1c(0), s1, c.loff, acc);
-    touch(seg_a(0), hc > 1 ? seg_a(1) : nullptr, kSlab);  // M1(0) (4 us away) and M1(1)
-    stamp2<TL>(c, smem);
-    lds_barrier();  // group B's skip rows and vectors are in LDS
-    round_rows<T, true, true>(acc, bufC, red, lane, wq, vec, 0);
-    stamp2<TL>(c, smem);
-    lds_barrier();
-    // S2: LayerNorm_mlp(x1) without its affine part -> bufB (every wave has read the attention rows)
-    if (dbg & 2) round_rows<T, false>(acc, bufB, nullptr, lane, wq);
-    else normalise_rows<T>(acc, red, a.eps1, bufB, lane, wq);
-    stamp2<TL>(c, smem);
+    auto after = [&] { touch(seg_a(0), hc > 1 ? seg_a(1) : nullptr, kSlab); };  // M1(0) (4 us away) and M1(1)
+    if (first) projection_phase<T, TL, true>(a, c, smem, ring, acc, w1c(0), s1, r0, nr, after);
+    else projection_phase<T, TL, false>(a, c, smem, ring, acc, w1c(0), s1, r0, nr, after);
+    first = false;
     lds_barrier();
     // the MLP's first Linear, chunk by chunk (+ GELU); step hc is group B's alone
     for (int t = 0; t < hc; ++t) {
       stamp2<TL>(c, smem);
       init_acc<T, false>(acc, vec, 512 + 512 * t, nullptr, lane, wq);
+      // (behind the last chunk: the first chunk of the trailing projection, or the next panel's projection slab in gemm64's ring layout)
       const char* nxt = t + 1 < hc ? w1c(t + 1) : (qc > 0 ? wqc(0) : wpw);
+      const int64_t ns = (t + 1 < hc || qc > 0) ? s1 : 8192;
       if (kExperiments && a.prio_a == 1) __builtin_amdgcn_s_setprio(2);
-      gemm128<T>(bufB, lane, ring, w1c(t), s1, nxt, s1, c.loff, acc);
+      gemm128<T>(bufB, lane, ring, w1c(t), s1, nxt, ns, c.loff, acc);
       if (kExperiments && a.prio_a == 1) __builtin_amdgcn_s_setprio(0);
       touch(t == 0 ? nullptr : seg_a(t + 1), a.w2 + (int64_t)t * kSlab, sw2);  // the next step's M1(t + 1) (t = 0: touched behind P) and M2(t)
       stamp2<TL>(c, smem);
@@ -200,8 +251,8 @@ __device__ __forceinline__ void role_a(const Chain2Args& a, Ctx2& c, unsigned ch
     }
     stamp2<TL>(c, smem);
     if (qc > 1) touch(hc == 1 ? seg_a(hc) : nullptr, a.wq + (int64_t)8 * kSlab, kSlab);  // group B's first chunk of the trailing projection (Q0: behind M1(hc - 1))
-    const int tile_next = tile + (int)gridDim.x;
-    if (qc == 0 && tile_next < a.n_tiles) {
+    const int tile_next = tile + c.tile_step;
+    if (qc == 0 && tile_next < c.tile_end) {
       // nothing to do in this step and bufB free (every wave of the group is behind its last M1 segment): the NEXT panel's attention rows
       const int rn = tile_next * a.rows_per_tile;
       load_rows12<T>((const T*)a.attn, a.ld_attn, rn, min(a.rows_per_tile, a.n_rows - rn), bufB, lane, wq, [] {});
@@ -245,7 +296,7 @@ __device__ __forceinline__ void role_a(const Chain2Args& a, Ctx2& c, unsigned ch
       stamp2<TL>(c, smem);
       init_acc<T, false>(acc, vec, 1024 + 512 * hc + 512 * k, nullptr, lane, wq);
       set_chunk_prio(kExperiments && a.prio_q, k);
-      gemm128<T>(bufB, lane, ring, wqc(k), s1, k + 2 < qc ? wqc(k + 2) : wpw, s1, c.loff, acc);
+      gemm128<T>(bufB, lane, ring, wqc(k), s1, k + 2 < qc ? wqc(k + 2) : wpw, k + 2 < qc ? s1 : 8192, c.loff, acc);
       if (kExperiments && a.prio_q) __builtin_amdgcn_s_setprio(0);
       touch(k + 2 < qc ? a.wq + (int64_t)(8 * (k + 2)) * kSlab : nullptr, k + 3 < qc ? a.wq + (int64_t)(8 * (k + 3)) * kSlab : nullptr, kSlab);
       stamp2<TL>(c, smem);
@@ -255,13 +306,13 @@ __device__ __forceinline__ void role_a(const Chain2Args& a, Ctx2& c, unsigned ch
     }
     if (qc > 0) lds_barrier();  // (the groups' chunks are independent of each other: one barrier behind them all, for the next panel's S0)
     tile = tile_next;
-    if (tile >= a.n_tiles) break;
-    // S0 of the next panel (without a trailing projection its rows came in during step hc, two barriers ago)
+    if (tile >= c.tile_end) break;
+    // S0 of the next panel (without a trailing projection its attention rows came in during step hc)
     if (qc > 0) {
       const int rn = tile * a.rows_per_tile;
       load_rows12<T>((const T*)a.attn, a.ld_attn, rn, min(a.rows_per_tile, a.n_rows - rn), bufB, lane, wq, [] {});
-      lds_barrier();
     }
+    lds_barrier();
   }
   touch_done<PART>(warm);
 }
@@ -279,32 +330,35 @@ __device__ __forceinline__ void role_b(const Chain2Args& a, Ctx2& c, unsigned ch
   auto hbuf = [&](int t) { return smem + (t & 1) * (2 * kBufBytes); };
   const int64_t s1 = kSlab, s2 = (int64_t)hc * kSlab;
   const int one = (dbg & 8) ? 0 : 1;
+  const char* const wpw = a.wp + (int64_t)(4 + wq) * kSlab;  // this wave's slab of the projection (wave w of eight: slab w)
   auto w2c = [&](int k) { return a.w2 + (int64_t)(2 * wq) * s2 + (int64_t)(k * one) * kSlab; };
   auto wqc = [&](int k) { return a.wq + (int64_t)(8 * k * one + 2 * wq) * kSlab; };
   frag8 ring[2][8];
   f32x4 acc[3][8];
-  lds_barrier();  // S0 is group A's (the attention rows)
-  for (int tile = blockIdx.x;;) {
+  // S0 of the first panel: this group's half of the attention rows -> bufB (rows 24 ..: six per wave), and behind them the per-column
+  // vectors -> LDS and the weight ring's first fragments; the skip rows follow in the projection phase
+  {
+    const int r0 = c.tile0 * a.rows_per_tile;
+    const int nr0 = min(a.rows_per_tile, a.n_rows - r0);
+    Rows6 rows;
+    VecCopy vc0, vc1;
+    rows.request((const T*)a.attn, a.ld_attn, r0, nr0, lane, 4 + wq);
+    vc0.request(a, wq * 64 + lane);
+    vc1.request(a, 256 + wq * 64 + lane);
+    ring_prologue64(ring, wpw, c.loff);
+    rows.store(bufB, nr0, lane, 4 + wq);
+    vc0.store(a, wq * 64 + lane, smem);
+    vc1.store(a, 256 + wq * 64 + lane, smem);
+    stamp2<TL>(c, smem);
+    lds_barrier();
+  }
+  bool first = true;
+  for (int tile = c.tile0;;) {
     const int r0 = tile * a.rows_per_tile;
     const int nr = min(a.rows_per_tile, a.n_rows - r0);
-    stamp2<TL>(c, smem);
-    // beside the projection: the skip rows -> bufC; in the first panel also the per-column vectors -> LDS and the weight ring's first fragments
-    if (tile == (int)blockIdx.x) {
-      VecCopy vc0, vc1;
-      load_rows12<T>((const T*)a.xres, a.ld_x, r0, nr, bufC, lane, wq, [&] {
-        vc0.request(a, wq * 64 + lane);
-        vc1.request(a, 256 + wq * 64 + lane);
-      });
-      vc0.store(a, wq * 64 + lane, smem);
-      vc1.store(a, 256 + wq * 64 + lane, smem);
-      ring_prologue(ring, w2c(0), s2, c.loff);
-    } else {
-      load_rows12<T>((const T*)a.xres, a.ld_x, r0, nr, bufC, lane, wq, [] {});
-    }
-    stamp2<TL>(c, smem);
-    lds_barrier();  // the skip rows are in LDS
-    lds_barrier();  // x1 is group A's
-    stamp2<TL>(c, smem);
+    if (first) projection_phase<T, TL, true>(a, c, smem, ring, acc, w2c(0), s2, r0, nr, [] {});
+    else projection_phase<T, TL, false>(a, c, smem, ring, acc, w2c(0), s2, r0, nr, [] {});
+    first = false;
     // S2: x2's accumulators start at b_2 + x1
     init_acc<T, true>(acc, vec, 512 + 512 * hc, bufC, lane, wq);
     stamp2<TL>(c, smem);
@@ -314,8 +368,9 @@ __device__ __forceinline__ void role_b(const Chain2Args& a, Ctx2& c, unsigned ch
     // the MLP's second Linear, accumulating over the hidden chunks as group A delivers them
     for (int t = 1; t <= hc; ++t) {
       stamp2<TL>(c, smem);
-      const char* nxt = t < hc ? w2c(t) : (qc > 1 ? wqc(1) : w2c(0));
-      const int64_t ns = (t < hc || qc <= 1) ? s2 : s1;
+      // (behind the last chunk: this group's first chunk of the trailing projection, or the next panel's projection slab in gemm64's ring layout)
+      const char* nxt = t < hc ? w2c(t) : (qc > 1 ? wqc(1) : wpw);
+      const int64_t ns = t < hc ? s2 : (qc > 1 ? s1 : 8192);
       // In the dual steps group A is the critical path (its GEMM, then its GELU) while both groups pull weights through the same memory pipe:
       // this group starts its stream a little later, so that A's GEMM gets the pipe first and A's GELU runs beside the bulk of THIS GEMM
       if (kExperiments && t < hc)
@@ -339,7 +394,7 @@ __device__ __forceinline__ void role_b(const Chain2Args& a, Ctx2& c, unsigned ch
       init_acc<T, false>(acc, vec, 1024 + 512 * hc + 512 * k, nullptr, lane, wq);
       const bool last = k + 2 >= qc;
       set_chunk_prio(kExperiments && a.prio_q, k);
-      gemm128<T>(bufB, lane, ring, wqc(k), s1, last ? w2c(0) : wqc(k + 2), last ? s2 : s1, c.loff, acc);
+      gemm128<T>(bufB, lane, ring, wqc(k), s1, last ? wpw : wqc(k + 2), last ? 8192 : s1, c.loff, acc);
       if (kExperiments && a.prio_q) __builtin_amdgcn_s_setprio(0);
       stamp2<TL>(c, smem);
       round_rows<T, false>(acc, hbuf(hc + 1), nullptr, lane, wq);
@@ -347,9 +402,14 @@ __device__ __forceinline__ void role_b(const Chain2Args& a, Ctx2& c, unsigned ch
       stamp2<TL>(c, smem);
     }
     if (qc > 0) lds_barrier();
-    tile += (int)gridDim.x;
-    if (tile >= a.n_tiles) break;
-    if (qc > 0) lds_barrier();  // S0 of the next panel is group A's
+    tile += c.tile_step;
+    if (tile >= c.tile_end) break;
+    // S0 of the next panel: its skip rows -> bufC (x2 and the staged chunks have left the h buffers)
+    {
+      const int rn = tile * a.rows_per_tile;
+      load_rows12<T>((const T*)a.xres, a.ld_x, rn, min(a.rows_per_tile, a.n_rows - rn), bufC, lane, wq, [] {});
+    }
+    lds_barrier();
   }
 }
 
@@ -366,7 +426,8 @@ __global__ __launch_bounds__(512, 1) void gt_chain2_kernel(Chain2Args a) {
   c.loff = c.lane * 16;
   c.tl_n = 0;
   stamp2<TL>(c, smem);  // 0: entry
-  if ((int)blockIdx.x >= a.n_tiles) return;
+  tile_schedule(c, a.n_tiles);
+  if (c.tile0 >= c.tile_end) return;
   if (c.wave < 4) {
     if (kExperiments && a.prio_a == 2) __builtin_amdgcn_s_setprio(2);
     role_a<T, TL, PART>(a, c, smem);

@@ -45,7 +45,8 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4;
   const uint32_t loff = lane * 16;
-  const int flip = (a.dbg & 16) ? (wave >> 2) : -1;  // (experiment: alternating issue priority of the two waves of a SIMD, chain_core.h)
+  const int dbg = kExperiments ? a.dbg : 0;  // (timing experiments: compiled out of the product library)
+  const int flip = (dbg & 16) ? (wave >> 2) : -1;  // (experiment: alternating issue priority of the two waves of a SIMD, chain_core.h)
   const int nq0 = MLP ? a.k0_groups : 4;  // K of the first GEMM / 128
   const int nslots = nq0 * 16;            // 16-byte slots per panel row
   const char* const w0 = a.w0 + (int64_t)wave * (nq0 * 16384);
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
           const T* r2 = (const T*)a.g2 + (int64_t)i2[mi] * a.ld_g2 + wave * 64 + lc.g * 4;
 #pragma unroll
           for (int ni = 0; ni < 4; ++ni) {
-            if (a.dbg & 4) {  // (timing experiment: no gathered rows)
+            if (dbg & 4) {  // (timing experiment: no gathered rows)
               ga[mi][ni] = gb[mi][ni] = u32x2{0u, 0u};
             } else {
               ga[mi][ni] = *reinterpret_cast<const u32x2*>(r1 + ni * 16);
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) t[r] = (acc[mi][ni][r] + bias[r]) + (t1[r] + t2[r]);  // the association of linear.hip's gather-add epilogue
           }
-          if (!(a.dbg & 1)) {
+          if (!(dbg & 1)) {
             gelu_fast2(t[0], t[1]);
             gelu_fast2(t[2], t[3]);
           }
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
         unpack4<T>(pb[ni], bias);
 #pragma unroll
         for (int r = 0; r < 4; ++r) t[r] = acc[mi][ni][r] + bias[r];
-        if (!(a.dbg & 1)) {
+        if (!(dbg & 1)) {
           gelu_fast2(t[0], t[1]);
           gelu_fast2(t[2], t[3]);
         }
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(512, 1) void gnn_edge_chain_kernel(EdgeChainArgs a)
           for (int r = 0; r < 4; ++r) o[r] = fmaf((acc[mi][ni][r] - mean[mi]) * rstd[mi], gv[r], bv[r]) + ev[r];  // edge_ln_res_segsum's arithmetic
           pk[mi][ni] = pack4<T>(o);
         }
-      store_block_via_strip<T, NB>(pk, bufH + wave * (kERows * 128), (T*)a.e_new + (int64_t)r0 * a.ld_o + wave * 64, a.ld_o, (a.dbg & 8) ? 0 : nr, lane, wave);
+      store_block_via_strip<T, NB>(pk, bufH + wave * (kERows * 128), (T*)a.e_new + (int64_t)r0 * a.ld_o + wave * 64, a.ld_o, (dbg & 8) ? 0 : nr, lane, wave);
     }
     stamp();  // + 7: LayerNorm + residual applied, rows stored through the strips
     if (!more) break;
@@ -607,9 +608,11 @@ extern "C" int anemoi_gnn_edge_chain_fwd(const void* e, int64_t ld_e, const void
   // round 5: ANEMOI_GNN_CHAIN_V2=1 selects the two-group launch (gnn_chain2.hip): built, parity-green, and slower than the symmetric
   // kernel below (212 against 195 us at 81 840 rows: its 40 / 48-row panels need 7-8 passes over the weights instead of 5,
   // profiles/r05_gnn_edge_chain_role_split.txt) - kept for the A/B
+#ifdef ANEMOI_EXPERIMENTS
   static const int v2 = env_int(getenv("ANEMOI_GNN_CHAIN_V2"), 0, 0, 1);
   if (v2) return launch_edge_chain2(a, dtype, stream, false);
-  static const int dbg = env_int(getenv("ANEMOI_EDGE_CHAIN_DBG"), 0, 0, 31);
+#endif
+  static const int dbg = ANEMOI_EXPERIMENT_ENV("ANEMOI_EDGE_CHAIN_DBG", 0, 0, 31);
   a.dbg = dbg;
   a.n_tiles = (n_rows + a.rows_per_tile - 1) / a.rows_per_tile;
   const int grid = a.n_tiles < 256 ? a.n_tiles : 256;
@@ -626,6 +629,7 @@ extern "C" int anemoi_gnn_edge_chain_fwd(const void* e, int64_t ld_e, const void
   return check_launch("gnn_edge_chain_kernel");
 }
 
+#ifdef ANEMOI_EXPERIMENTS
 // Developer aid: the same launch through the instrumented instantiation (shader-clock stamps at the phase boundaries of every panel,
 // all waves, a workgroup's first five panels) - tools/edge_chain_timeline.py.  timeline: [min(256, panels)][8][48] uint64.
 extern "C" int anemoi_gnn_edge_chain_timeline(const void* e, int64_t ld_e, const void* g1, int64_t ld_g1, const int32_t* idx1, const void* g2,
@@ -641,7 +645,7 @@ extern "C" int anemoi_gnn_edge_chain_timeline(const void* e, int64_t ld_e, const
   EdgeChainArgs a{e, ld_e, g1, ld_g1, idx1, g2, ld_g2, idx2, (const char*)w0, b0, (const char*)w1, b1, (const char*)w2, b2, ln_w, ln_b, eps, e_new, ld_o,
                   n_rows, chain_rows_per_tile(n_rows, kERows), 0, 0};
   a.timeline = timeline;
-  static const int dbg = env_int(getenv("ANEMOI_EDGE_CHAIN_DBG"), 0, 0, 31);
+  static const int dbg = ANEMOI_EXPERIMENT_ENV("ANEMOI_EDGE_CHAIN_DBG", 0, 0, 31);
   a.dbg = dbg;
   a.n_tiles = (n_rows + a.rows_per_tile - 1) / a.rows_per_tile;
   const int grid = a.n_tiles < 256 ? a.n_tiles : 256;
@@ -651,6 +655,7 @@ extern "C" int anemoi_gnn_edge_chain_timeline(const void* e, int64_t ld_e, const
   hipLaunchKernelGGL((gnn_edge_chain_kernel<bf16_t, false, true>), dim3(grid), dim3(512), smem, as_stream(stream), a);
   return check_launch("gnn_edge_chain_kernel<timeline>");
 }
+#endif
 
 extern "C" int anemoi_gnn_mlp_chain_fwd(const void* x, int64_t ld_x, int32_t in_features, const void* w0, const void* b0, const void* w1, const void* b1,
                                         const void* w2, const void* b2, const void* ln_w, const void* ln_b, float eps, const void* res, int64_t ld_res,
@@ -668,8 +673,10 @@ extern "C" int anemoi_gnn_mlp_chain_fwd(const void* x, int64_t ld_x, int32_t in_
   a.res = res;
   a.ld_res = ld_res;
   a.k0_groups = in_features / 128;
+#ifdef ANEMOI_EXPERIMENTS
   static const int v2 = env_int(getenv("ANEMOI_GNN_CHAIN_V2"), 0, 0, 1);
   if (v2) return launch_edge_chain2(a, dtype, stream, true);
+#endif
   a.n_tiles = (n_rows + a.rows_per_tile - 1) / a.rows_per_tile;
   const int grid = a.n_tiles < 256 ? a.n_tiles : 256;
   hipStream_t st = as_stream(stream);
@@ -703,7 +710,7 @@ static int node_chain_launch(const void* x, int64_t ld_x, const void* agg, int64
                   (const char*)wt, bt, t_out_features / kCh, t_out, ld_t, n_rows, chain_rows_per_tile(n_rows), 0};
   // ANEMOI_GNN_NODE_ROWS: rows per panel of this launch alone (A/B of the even-spread rule against full 48-row panels on fewer CUs,
   // the rule that won for gt_chain2_kernel; profiles/r05_gnn_node_rows_ab.txt)
-  static const int node_rows = env_int(getenv("ANEMOI_GNN_NODE_ROWS"), 0, 0, kPanel);
+  static const int node_rows = ANEMOI_EXPERIMENT_ENV("ANEMOI_GNN_NODE_ROWS", 0, 0, kPanel);
   if (node_rows > 0) a.rows_per_tile = node_rows;
   a.seg_ptr = seg_ptr;
   a.n_tiles = (n_rows + a.rows_per_tile - 1) / a.rows_per_tile;

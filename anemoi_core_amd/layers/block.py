@@ -40,27 +40,24 @@ _LN_FOLD = os.environ.get("ANEMOI_LN_FOLD", "1") == "1"
 # 8-way sharded mesh 1.50 / 1.50 ms, 10 242 nodes 3.09 / 3.00 ms.  (Until late round 3 the small-tile consumer lost 60 us per launch to
 # ONE lane walking a tail row load by load, which had made the fold look slower below 4 096 rows.)  Not below 512 rows: not measured.
 _LN_FOLD_MIN_ROWS = int(os.environ.get("ANEMOI_LN_FOLD_MIN_ROWS", "512"))
-# Round 4: the row-local part of a block (projection + skip, LayerNorm, MLP, the NEXT block's LayerNorm + q|k|v|self projection)
-# as ONE launch that keeps a 48-row panel in LDS and streams the weights (ops.gt_layer_chain, csrc/gt_chain.hip) instead of four
-# GEMM launches with the LayerNorm fold between them: 105-115 us per launch against 108 us for the four launches at 10 242 rows (all
-# eight waves in the same phase: every epilogue with the MFMA pipe and the weight stream idle), a win only for the N320 decoder's
-# 542 080 rows, whose [N, 2048] hidden activations then never exist.
+# The row-local tail of a block (projection + skip, LayerNorm, MLP + skip, the NEXT block's LayerNorm + q|k|v|self projection) as ONE
+# launch that keeps a 48-row panel in LDS and streams the weights (ops.gt_layer_chain2, csrc/gt_chain2.hip: the workgroup's waves in two
+# groups working different GEMM segments, the LayerNorms' affine parts folded into the weights here, once per parameter version, each CU
+# warming the L2 with its share of the next step's weights) instead of four GEMM launches with the LayerNorm fold between them.
+# Where it wins (measured): from ~4 200 rows on - one panel per CU (the hidden mesh of res 5: O96 forward 2.98 -> 2.57 ms), four
+# rounds of panels (res 6; the O96 decoder's 40 320 rows), the N320 decoder's 45 rounds.  Below, a launch costs the same ~75-90 us (every
+# busy CU streams all of the layer's weights for its 48 rows, and few CUs are busy) while the GEMM launches shrink with the rows: 2 562
+# hidden nodes 1.91 ms per forward on the launches against 2.30 ms on the chain - and a rank's share of a sharded mesh is that small
+# (2 ranks: 5 121 + 277 rows 2.39 -> 2.16 ms on the chain; 4 ranks: 2 561 + 260 rows 1.59 -> 1.84 ms; profiles/r05_rank_floor_gate.txt).
+# ANEMOI_LAYER_CHAIN=1: every eligible block; =0: never; ANEMOI_LAYER_CHAIN_MIN_ROWS: the gate (4 096 rows).
 _chain_env = os.environ.get("ANEMOI_LAYER_CHAIN", "")
 _LAYER_CHAIN = _chain_env != "0"
-# Round 5: the role-split form of that launch (ops.gt_layer_chain2, csrc/gt_chain2.hip: the workgroup's waves in two groups working
-# different GEMM segments, the LayerNorms' affine parts folded into the weights here, once per parameter version, each CU warming the L2
-# with its share of the next step's weights).  It replaces the round-4 kernel; ANEMOI_LAYER_CHAIN_V2=0 keeps that one (same-box A/B).
-_LAYER_CHAIN_V2 = os.environ.get("ANEMOI_LAYER_CHAIN_V2", "1") != "0"
-# Where the role-split launch wins (measured): from ~7 000 rows on - one panel per CU (the hidden meshes of res 5:
-# O96 forward 2.98 -> 2.57 ms), four rounds of panels (res 6: 8.65 -> 8.12 ms; the O96 decoder's 40 320 rows: 2.59 -> 2.55 ms), the N320
-# decoder's 45 rounds (14.7 -> 13.9 ms).  Below, a launch costs the same ~75-90 us (every busy CU streams all of the layer's weights for
-# its 48 rows, and few CUs are busy) while the GEMM launches shrink with the rows: 2 562 hidden nodes 1.91 ms per forward on the launches
-# against 2.30 ms on the chain, 642 nodes 1.67 / 2.36 ms - and a rank's share of a sharded mesh is that small.  The round-4 kernel keeps
-# its gate (>= 100 000 rows).  ANEMOI_LAYER_CHAIN=1: every eligible block; =0: never; ANEMOI_LAYER_CHAIN_MIN_ROWS: the gate.
-# Since the L2 warm-up's shares follow the workgroup count (every weight line warm at any grid size) the break-even sits near 4 200 rows:
-# a rank's share of the res-5 mesh at 2 ranks (5 121 + 277 rows) 2.39 -> 2.16 ms per forward on the chain, at 4 ranks (2 561 + 260 rows)
-# 1.59 -> 1.84 ms (tools/rank_floor.py, profiles/r05_rank_floor_gate.txt) - the gate moved from 7 168 to 4 096 rows.
-_LAYER_CHAIN_MIN_ROWS = int(os.environ.get("ANEMOI_LAYER_CHAIN_MIN_ROWS", "0" if _chain_env == "1" else ("4096" if _LAYER_CHAIN_V2 else "100000")))
+_LAYER_CHAIN_MIN_ROWS = int(os.environ.get("ANEMOI_LAYER_CHAIN_MIN_ROWS", "0" if _chain_env == "1" else "4096"))
+# Below that gate (round 6): the CLUSTER chain (ops.gt_cluster_chain, csrc/gt_cluster_chain.hip) - four CUs of one XCD share a 48-row panel
+# as a tensor-parallel group over the MLP's hidden width, so that a block tail of a few thousand rows (a rank's share of a sharded mesh,
+# the hidden meshes of res 3 / 4) puts four times as many CUs to work, each streaming 2 MiB of weights instead of 6.5.  ANEMOI_CLUSTER_CHAIN=0:
+# the LayerNorm-fold GEMM launches below the gate, as in round 5.
+_CLUSTER_CHAIN = os.environ.get("ANEMOI_CLUSTER_CHAIN", "1") != "0"
 
 
 _IDENTITY: dict = {}
@@ -114,20 +111,6 @@ class _FusedWeights:
             d = (b if ln.bias is None else w @ ln.bias.float() + b).contiguous()
         self._cache["ln:" + tag] = (sig, (ws, c, d))
         return ws, c, d
-
-    def frag(self, tag: str, linears: list) -> tuple[Tensor, Tensor]:
-        """(fragment-major image of cat[W...], cat[b...]) for ops.gt_layer_chain; rebuilt only when a parameter changes."""
-        ps = [p for lin in linears for p in (lin.weight, lin.bias) if p is not None]
-        sig = tuple((p.data_ptr(), version(p), p.dtype, str(p.device)) for p in ps)
-        hit = self._cache.get("frag:" + tag)
-        if hit is not None and hit[0] == sig:
-            return hit[1], hit[2]
-        with torch.no_grad():
-            w = torch.cat([lin.weight for lin in linears], dim=0) if len(linears) > 1 else linears[0].weight
-            b = torch.cat([lin.bias if lin.bias is not None else lin.weight.new_zeros(lin.out_features) for lin in linears]).contiguous()
-            wf = ops.pack_weight_frag(w)
-        self._cache["frag:" + tag] = (sig, wf, b)
-        return wf, b
 
     def derived(self, tag: str, params: list, builder):
         """``builder()`` cached until one of ``params`` changes (fragment-major images of weight slices / stacks)."""
@@ -355,12 +338,16 @@ class GraphTransformerBaseBlock(BaseBlock):
                 and x.dtype != torch.float32 and x.is_cuda
                 and not (torch.is_grad_enabled() and (x.requires_grad or ln.weight.requires_grad)))
 
-    def _chain_ok(self, ln, x: Tensor) -> bool:
+    def _chain_ok(self, ln, x: Tensor, cluster: bool = False) -> bool:
         """The row-resident chain kernel takes this block's projection / LayerNorm / MLP: inference, 16-bit, 512 channels, plain
-        affine LayerNorm, Linear-GELU-Linear MLP with a hidden width that is a multiple of 512."""
+        affine LayerNorm, Linear-GELU-Linear MLP with a hidden width that is a multiple of 512.  ``cluster``: the same question for the
+        cluster chain, which takes the row counts BELOW the chain's gate (and a hidden width of 2048)."""
         mlp = self.node_dst_mlp
+        if cluster and not (_CLUSTER_CHAIN and 0 < x.shape[0] < _LAYER_CHAIN_MIN_ROWS and mlp.mlp_implementation == "mlp" and len(mlp.mlp) == 3
+                            and mlp.mlp[0].weight.shape[0] == 4 * ops.CHAIN_CHANNELS):
+            return False
         return (_LAYER_CHAIN and x.is_cuda and x.dtype != torch.float32
-                and x.shape[0] >= _LAYER_CHAIN_MIN_ROWS
+                and (cluster or x.shape[0] >= _LAYER_CHAIN_MIN_ROWS)
                 and type(ln).__name__ in ("LayerNorm", "AutocastLayerNorm") and ln.weight is not None
                 and mlp.mlp_implementation == "mlp" and len(mlp.mlp) == 3 and mlp.layer_norm is None
                 and self.projection.weight.shape == (ops.CHAIN_CHANNELS, ops.CHAIN_CHANNELS) and self.projection.bias is not None
@@ -392,10 +379,15 @@ class GraphTransformerBaseBlock(BaseBlock):
             return self._post_attention(attn_plus_self, x_skip, cond, chain) + extra
         ln, mlp = self.layer_norm_mlp_dst, self.node_dst_mlp
         plain_mlp = mlp.mlp_implementation == "mlp" and len(mlp.mlp) == 3 and mlp.layer_norm is None
-        if cond is None and self._chain_ok(ln, attn_plus_self) and attn_plus_self.shape == x_skip.shape and (extra is None or extra.shape == x_skip.shape):
+        cluster = cond is None and self._chain_ok(ln, attn_plus_self, cluster=True)
+        if (cond is None and (cluster or self._chain_ok(ln, attn_plus_self)) and attn_plus_self.shape == x_skip.shape
+                and (extra is None or extra.shape == x_skip.shape)):
             nb = next_block if (next_block is not None and chain is not None and extra is None and next_block._qkvs_chain_ok(x_skip)) else None
             hidden = mlp.mlp[0].weight.shape[0]
-            if _LAYER_CHAIN_V2 and ops.gt_layer_chain2_supported(attn_plus_self, hidden, 0 if nb is None else 4 * nb.attn_channels):
+            supported = ops.gt_cluster_chain_supported if cluster else ops.gt_layer_chain2_supported
+            if nb is not None and not supported(attn_plus_self, hidden, 4 * nb.attn_channels):
+                nb = None  # the per-column vectors of tail + trailing projection do not fit the kernel's LDS region: the tail alone
+            if supported(attn_plus_self, hidden, 0 if nb is None else 4 * nb.attn_channels):
                 lin1, lin2 = mlp.mlp[0], mlp.mlp[2]
                 qlins = [] if nb is None else [nb.lin_query, nb.lin_key, nb.lin_value, nb.lin_self]
                 lnq = None if nb is None else nb.layer_norm_attention
@@ -416,25 +408,14 @@ class GraphTransformerBaseBlock(BaseBlock):
                             torch.cat(parts).to(lin1.weight.dtype).contiguous(), wqg)
 
                 wp, w1g, w2, vec, wqg = self._fused.derived("chain2" if nb is None else f"chain2:{id(nb)}", params, build)
-                res = ops.gt_layer_chain2(attn_plus_self, x_skip, wp, w1g, w2, vec, hidden, ln.eps, extra=extra, wqg=wqg,
-                                          q_out_features=0 if nb is None else 4 * nb.attn_channels, lnq_eps=1e-5 if lnq is None else lnq.eps)
+                res = (ops.gt_cluster_chain if cluster else ops.gt_layer_chain2)(
+                    attn_plus_self, x_skip, wp, w1g, w2, vec, hidden, ln.eps, extra=extra, wqg=wqg,
+                    q_out_features=0 if nb is None else 4 * nb.attn_channels, lnq_eps=1e-5 if lnq is None else lnq.eps)
                 if nb is not None:
                     chain["qkvs_x"], chain["qkvs"] = res
                     return res[0]
                 return res
-            wp, bp = self._fused.frag("proj", [self.projection])
-            w1, b1 = self._fused.frag("mlp1", [mlp.mlp[0]])
-            w2, b2 = self._fused.frag("mlp2", [mlp.mlp[2]])
-            kw = {}
-            if nb is not None:
-                kw["wq"], kw["bq"] = nb._fused.frag("qkvs", [nb.lin_query, nb.lin_key, nb.lin_value, nb.lin_self])
-                lnq = nb.layer_norm_attention
-                kw["lnq_w"], kw["lnq_b"], kw["lnq_eps"] = lnq.weight, lnq.bias, lnq.eps
-            res = ops.gt_layer_chain(attn_plus_self, x_skip, wp, bp, ln.weight, ln.bias, ln.eps, w1, b1, w2, b2, extra=extra, **kw)
-            if kw:
-                chain["qkvs_x"], chain["qkvs"] = res  # the next block's projections, already computed from ITS LayerNorm of our output
-                return res[0]
-            return res
+            # (a hidden width whose vectors do not fit the kernel's LDS region: the GEMM launches below)
         if plain_mlp and self._ln_fold_ok(ln, attn_plus_self):
             r = ops.linear_with_row_stats(attn_plus_self, self.projection.weight, self.projection.bias, x_skip)
             if r is not None:
@@ -499,14 +480,17 @@ class GraphTransformerMapperBlock(GraphTransformerBaseBlock):
         # LayerNorm + projection per side; with the row statistics left by the mapper's embedding (``ln_stats``, inference) the
         # LayerNorm is applied inside the projection GEMM from raw rows
         st = layer_kwargs.get("ln_stats") or {}
-        qs = kv = None
+        # (the mapper's row chain launches computed a side's projection together with its embedding: layers/mapper.py)
+        qs, kv = st.get("proj:dst"), st.get("proj:src")
+        if cond is not None:
+            qs = kv = None
         if cond is None:
             e = st.get("dst")
-            if e is not None and e[0] is x_dst and self._ln_fold_ok(ln_d, x_dst):
+            if qs is None and e is not None and e[0] is x_dst and self._ln_fold_ok(ln_d, x_dst):
                 ws, c, d = self._fused.ln_folded("qs", [self.lin_query, self.lin_self], ln_d)
                 qs = ops.linear_ln_folded(x_dst, ws, c, d, e[1], ln_d.eps)
             e = st.get("src")
-            if e is not None and e[0] is x_src and self._ln_fold_ok(ln_s, x_src):
+            if kv is None and e is not None and e[0] is x_src and self._ln_fold_ok(ln_s, x_src):
                 ws, c, d = self._fused.ln_folded("kv", [self.lin_key, self.lin_value], ln_s)
                 kv = ops.linear_ln_folded(x_src, ws, c, d, e[1], ln_s.eps)
         if qs is None:

@@ -13,6 +13,7 @@ Differences that do not change results:
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -32,6 +33,19 @@ from .kernels import PaddedLinear
 from .mlp import MLP
 from .utils import compute_mlp_hidden_dim, load_layer_kernels
 from ..utils.tensors import version
+
+
+# One side of a mapper (node embedding -> the block's LayerNorm -> its fused k|v or q|self projection) as ONE row-resident launch
+# (ops.gt_row_chain, csrc/gt_rowchain.hip) instead of the embedding GEMM + the LayerNorm-fold GEMM with the embedded rows written and read
+# back in between.  ANEMOI_ROW_CHAIN=0: off; ANEMOI_ROW_CHAIN_MIN_ROWS: the gate (a launch streams ~1.2 MB of weights per 48-row panel: it
+# needs enough panels to put most CUs to work).
+_ROW_CHAIN = os.environ.get("ANEMOI_ROW_CHAIN", "1") != "0"
+_ROW_CHAIN_MIN_ROWS = int(os.environ.get("ANEMOI_ROW_CHAIN_MIN_ROWS", "4096"))
+# ... and, measured (tools/rowchain_time.py, profiles/r06_rowchain.txt): the launch re-streams its weights once per round of 48-row panels
+# (~21 us per round), the two GEMMs share each weight tile among 160 rows - between ~16 000 and ~260 000 rows the GEMM pair is as fast or
+# faster (40 320 rows: 84-86 against 75-83 us), below (one round: 10 242 rows 23 against 27 us, 5 040 rows 20 against 34) and far above
+# (542 080 rows 951 against 1 069 us: there the 555-MB round trip of the embedded rows dominates the GEMMs) the launch wins.
+_ROW_CHAIN_GEMM_BAND = tuple(int(v) for v in os.environ.get("ANEMOI_ROW_CHAIN_GEMM_BAND", "16384:262144").split(":"))
 
 
 class _LocalGraphCache:
@@ -125,10 +139,55 @@ class GraphTransformerBaseMapper(BaseMapper):
         self.emb_nodes_dst = self.layer_factory.Linear(self.in_channels_dst, self.hidden_dim)
         self._emb_src, self._emb_dst = PaddedLinear(), PaddedLinear()
 
+    def _row_chain_ok(self, x: Tensor, lin, ln, projs: list) -> bool:
+        """The embedding -> LayerNorm -> projection chain launch (ops.gt_row_chain) takes this side: inference, 16-bit, 512 channels, a
+        plain affine LayerNorm, rows whose width is a multiple of 8 (the model pads its inputs), enough rows to fill the chip."""
+        if not (_ROW_CHAIN and x.is_cuda and x.dim() == 2 and x.dtype != torch.float32 and x.shape[0] >= _ROW_CHAIN_MIN_ROWS
+                and not (_ROW_CHAIN_GEMM_BAND[0] < x.shape[0] < _ROW_CHAIN_GEMM_BAND[1])
+                and self.hidden_dim == ops.CHAIN_CHANNELS and type(ln).__name__ in ("LayerNorm", "AutocastLayerNorm") and ln.weight is not None):
+            return False
+        q_out = sum(p.out_features for p in projs)
+        mods = [lin, ln, *projs]
+        if not (lin.in_features <= x.shape[1] and lin.bias is not None and ops.gt_row_chain_supported(x, q_out)
+                and all(p.in_features == ops.CHAIN_CHANNELS for p in projs)
+                and all(q is None or q.dtype == x.dtype for m in mods for q in m.parameters())):
+            return False
+        return not (torch.is_grad_enabled() and (x.requires_grad or any(q.requires_grad for m in mods for q in m.parameters())))
+
+    def _row_chain(self, x: Tensor, lin, side: str, want_x: bool):
+        """(embedded rows or None, the block's fused projection of that side) in one launch, or None if the shapes do not fit."""
+        blk = self.proc
+        ln = blk.layer_norm_attention_src if side == "src" else blk.layer_norm_attention_dest
+        projs = [blk.lin_key, blk.lin_value] if side == "src" else [blk.lin_query, blk.lin_self]
+        if not self._row_chain_ok(x, lin, ln, projs):
+            return None
+        params = [lin.weight, lin.bias, ln.weight, ln.bias] + [q for m in projs for q in (m.weight, m.bias)]
+        K = x.shape[1]
+
+        def build():
+            w = lin.weight if lin.in_features == K else torch.nn.functional.pad(lin.weight, (0, K - lin.in_features))  # (rows that carry alignment zeros)
+            wq = torch.cat([m.weight for m in projs], dim=0)
+            bq = torch.cat([m.bias if m.bias is not None else m.weight.new_zeros(m.out_features) for m in projs])
+            wqg, dq = ops.fold_layer_norm(wq, bq, ln.weight, ln.bias)
+            return ops.pack_embedding_frag(w), ops.pack_weight_frag(wqg), torch.cat([lin.bias.float(), dq]).to(x.dtype).contiguous(), wq.shape[0]
+
+        we, wqg, vec, q_out = blk._fused.derived(f"rowchain:{side}:{K}", params, build)
+        return ops.gt_row_chain(x, we, wqg, vec, q_out, ln.eps, want_x_out=want_x)
+
     def _embed(self, padded: PaddedLinear, x: Tensor, lin, side: str, ln_stats: Optional[dict]) -> Tensor:
-        """The node embedding; with ``ln_stats`` (inference) it also leaves the row statistics of its output there when the
-        block's LayerNorm on that side can be folded into the GEMM behind it."""
+        """The node embedding.  With ``ln_stats`` (inference): where the shapes fit, embedding, the block's LayerNorm on that side and its
+        fused projection run as ONE row-resident launch (``ln_stats["proj:" + side]`` = the projection; the embedded SOURCE rows are not
+        even written unless the block updates them) - else the embedding leaves the row statistics of its output there when the block's
+        LayerNorm on that side can be folded into the GEMM behind it."""
         ln = self.proc.layer_norm_attention_src if side == "src" else self.proc.layer_norm_attention_dest
+        if ln_stats is not None:
+            want_x = side == "dst" or self.proc.update_src_nodes
+            r = self._row_chain(x, lin, side, want_x)
+            if r is not None:
+                y, proj = r
+                ln_stats["proj:" + side] = proj
+                # (source rows nobody reads: an empty [N, 0] stand-in keeps the row count the block's graph plumbing looks at)
+                return y if y is not None else x.new_empty((x.shape[0], 0))
         if ln_stats is not None and x.is_cuda and x.dtype != torch.float32 and self.proc._ln_fold_ok(ln, x):
             y, stats = padded.with_row_stats(x, lin)
             if stats is not None:

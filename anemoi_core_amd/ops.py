@@ -760,11 +760,11 @@ def linear_ln_folded(x: Tensor, w_scaled: Tensor, c: Tensor, d: Tensor, stats: T
 
 
 # ------------------------------------------------------------------------------------------ row-resident layer chain
-CHAIN_CHANNELS = 512  # csrc/gt_chain.hip is built for 8 waves x 64 columns
+CHAIN_CHANNELS = 512  # the chain kernels (csrc/gt_chain2.hip, gnn_chain.hip) are built for this width: 4 waves x 128 / 8 waves x 64 columns
 
 
 def pack_weight_frag(weight: Tensor) -> Tensor:
-    """Fragment-major image of a Linear weight [O, K] (O % 64 == 0, K % 32 == 0) for ``gt_layer_chain``: one contiguous KiB per
+    """Fragment-major image of a Linear weight [O, K] (O % 64 == 0, K % 32 == 0) for the chain kernels: one contiguous KiB per
     MFMA B fragment, [O/64 slabs][K/32 k-steps][4 column blocks][4 k-slots][16 rows][8] (include/anemoi_hip.h).  A pure
     re-ordering (torch view + permute), made once per parameter version."""
     O, K = weight.shape
@@ -774,59 +774,9 @@ def pack_weight_frag(weight: Tensor) -> Tensor:
     return w.permute(0, 3, 1, 4, 2, 5).contiguous().reshape(-1)
 
 
-class _ChainArgs(_lib.C.Structure):
-    _p, _i64, _i32, _f = _lib.C.c_void_p, _lib.C.c_int64, _lib.C.c_int32, _lib.C.c_float
-    _fields_ = [("attn", _p), ("ld_attn", _i64), ("x_res", _p), ("ld_x", _i64), ("wp", _p), ("bp", _p),
-                ("ln1_w", _p), ("ln1_b", _p), ("ln1_eps", _f), ("w1", _p), ("b1", _p), ("hidden", _i32), ("w2", _p), ("b2", _p),
-                ("extra", _p), ("ld_extra", _i64), ("x_out", _p), ("ld_out", _i64),
-                ("lnq_w", _p), ("lnq_b", _p), ("lnq_eps", _f), ("wq", _p), ("bq", _p), ("q_out_features", _i32),
-                ("q_out", _p), ("ld_q", _i64), ("n_rows", _i32), ("channels", _i32), ("rows_per_tile", _i32), ("timeline", _p)]
-
-
 def gt_layer_chain_supported(x: Tensor, hidden: int, q_out: int = 0) -> bool:
     return (x.is_cuda and x.dim() == 2 and x.shape[1] == CHAIN_CHANNELS and x.dtype in (torch.bfloat16, torch.float16)
             and hidden > 0 and hidden % CHAIN_CHANNELS == 0 and q_out % CHAIN_CHANNELS == 0)
-
-
-def gt_layer_chain(attn: Tensor, x_res: Tensor, wp: Tensor, bp: Tensor, ln1_w: Tensor, ln1_b: Optional[Tensor], ln1_eps: float,
-                   w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, *, extra: Optional[Tensor] = None,
-                   lnq_w: Optional[Tensor] = None, lnq_b: Optional[Tensor] = None, lnq_eps: float = 1e-5,
-                   wq: Optional[Tensor] = None, bq: Optional[Tensor] = None, rows_per_tile: int = 0, timeline: Optional[Tensor] = None):
-    """The row-local part of a GraphTransformer block in ONE launch (anemoi_gt_chain_fwd, csrc/gt_chain.hip):
-
-        x1 = attn Wp^T + bp + x_res;  h = GELU(LN(x1; ln1) W1^T + b1);  x_out = h W2^T + b2 + x1 [+ extra]
-        q_out = LN(x_out; lnq) Wq^T + bq        (optional: the NEXT block's LayerNorm + fused q|k|v|self projection)
-
-    ``wp, w1, w2, wq`` are fragment-major images (``pack_weight_frag``), biases / LayerNorm vectors in the model dtype.
-    Returns ``x_out`` or ``(x_out, q_out)``.  Inference only (no autograd)."""
-    _dev(attn, x_res, wp, bp, ln1_w, ln1_b, w1, b1, w2, b2, extra, lnq_w, lnq_b, wq, bq)
-    N, D = attn.shape
-    dt = attn.dtype
-    hidden = b1.shape[0]
-    if D != CHAIN_CHANNELS or dt not in (torch.bfloat16, torch.float16):
-        raise NotImplementedError(f"gt_layer_chain: {D} channels / {dt} (built for {CHAIN_CHANNELS} channels, 16-bit dtypes)")
-    if tuple(x_res.shape) != (N, D) or (extra is not None and tuple(extra.shape) != (N, D)):
-        raise ValueError("gt_layer_chain: attn, x_res and extra must have the same [N, channels] shape")
-    for name, w, numel in (("wp", wp, D * D), ("w1", w1, hidden * D), ("w2", w2, D * hidden)):
-        if w.dim() != 1 or w.numel() != numel or w.dtype != dt or not w.is_contiguous():
-            raise ValueError(f"gt_layer_chain: {name} must be the contiguous fragment-major image ({numel} x {dt}) made by pack_weight_frag")
-    q_out_f = 0
-    if wq is not None:
-        if bq is None or lnq_w is None:
-            raise ValueError("gt_layer_chain: the trailing projection needs wq, bq and lnq_w")
-        q_out_f = bq.shape[0]
-        if wq.dim() != 1 or wq.numel() != q_out_f * D or wq.dtype != dt or not wq.is_contiguous():
-            raise ValueError("gt_layer_chain: wq must be the contiguous fragment-major image made by pack_weight_frag")
-    x_out = torch.empty((N, D), dtype=dt, device=attn.device)
-    q_out = torch.empty((N, q_out_f), dtype=dt, device=attn.device) if q_out_f else None
-    (ap, lda), (xp, ldx), (ep, lde) = _rows(attn, "attn", dt), _rows(x_res, "x_res", dt), _rows(extra, "extra", dt)
-    a = _ChainArgs(ap, lda, xp, ldx, wp.data_ptr(), _vec(bp, "bp", D, dt), _vec(ln1_w, "ln1_w", D, dt), _vec(ln1_b, "ln1_b", D, dt), float(ln1_eps),
-                   w1.data_ptr(), _vec(b1, "b1", hidden, dt), hidden, w2.data_ptr(), _vec(b2, "b2", D, dt), ep, lde, x_out.data_ptr(), D,
-                   _vec(lnq_w, "lnq_w", D, dt), _vec(lnq_b, "lnq_b", D, dt), float(lnq_eps), 0 if wq is None else wq.data_ptr(),
-                   _vec(bq, "bq", q_out_f, dt) if q_out_f else 0, q_out_f, 0 if q_out is None else q_out.data_ptr(), q_out_f, N, D, int(rows_per_tile),
-                   0 if timeline is None else timeline.data_ptr())
-    _lib.check(_lib.load().anemoi_gt_chain_fwd(_lib.C.byref(a), _dt(attn), _stream()), "gt_chain_fwd")
-    return x_out if q_out is None else (x_out, q_out)
 
 
 class _Chain2Args(_lib.C.Structure):
@@ -891,6 +841,119 @@ def gt_layer_chain2(attn: Tensor, x_res: Tensor, wp: Tensor, w1g: Tensor, w2: Te
                     q_out_features, N, D, int(rows_per_tile), 0 if timeline is None else timeline.data_ptr())
     _lib.check(_lib.load().anemoi_gt_chain2_fwd(_lib.C.byref(a), _dt(attn), _stream()), "gt_chain2_fwd")
     return x_out if q_out is None else (x_out, q_out)
+
+
+class _ClusterChainArgs(_lib.C.Structure):
+    _p, _i64, _i32, _f = _lib.C.c_void_p, _lib.C.c_int64, _lib.C.c_int32, _lib.C.c_float
+    _fields_ = [("attn", _p), ("ld_attn", _i64), ("x_res", _p), ("ld_x", _i64), ("wp", _p), ("w1", _p), ("hidden", _i32), ("w2", _p),
+                ("wq", _p), ("q_out_features", _i32), ("vec", _p), ("ln1_eps", _f), ("lnq_eps", _f), ("extra", _p), ("ld_extra", _i64),
+                ("x_out", _p), ("ld_out", _i64), ("q_out", _p), ("ld_q", _i64), ("ln_out", _p), ("ld_ln", _i64), ("workspace", _p),
+                ("workspace_bytes", _i64), ("n_rows", _i32), ("channels", _i32)]
+
+
+_CLUSTER_WS: dict = {}
+
+
+def _cluster_workspace(device) -> Tensor:
+    """The cluster chain's exchange workspace (counters + partial-sum slots), zeroed ONCE - its counters are monotonic across launches
+    (csrc/gt_cluster_chain.hip).  Launches that share a workspace must be ordered: one per (device, stream) for eager launches and one
+    for launches recorded into hipGraphs (a replay is ordered like one stream).  Allocated on first eager use - run a forward eagerly
+    before capturing it, as every capture needs anyway."""
+    capturing = torch.cuda.is_current_stream_capturing()
+    key = (str(device), "graph" if capturing else torch.cuda.current_stream(device).cuda_stream)
+    ws = _CLUSTER_WS.get(key)
+    if ws is None:
+        if capturing:
+            raise RuntimeError("gt_cluster_chain: its workspace must exist before hipGraph capture (run the forward once eagerly)")
+        n = _lib.load().anemoi_gt_cluster_chain_workspace_bytes()
+        ws = _CLUSTER_WS[key] = torch.zeros(n // 4, dtype=torch.int32, device=device)
+        _CLUSTER_WS.setdefault((str(device), "graph"), torch.zeros(n // 4, dtype=torch.int32, device=device))
+    return ws
+
+
+def gt_cluster_chain_supported(x: Tensor, hidden: int, q_out: int = 0) -> bool:
+    return gt_layer_chain_supported(x, hidden, q_out) and hidden == 4 * CHAIN_CHANNELS and q_out <= 4 * CHAIN_CHANNELS
+
+
+def gt_cluster_chain(attn: Tensor, x_res: Tensor, wp: Tensor, w1g: Tensor, w2: Tensor, vec: Tensor, hidden: int, ln1_eps: float, *,
+                     extra: Optional[Tensor] = None, wqg: Optional[Tensor] = None, q_out_features: int = 0, lnq_eps: float = 1e-5,
+                     ln_out: Optional[Tensor] = None):
+    """``gt_layer_chain2`` for block tails of a few thousand rows (anemoi_gt_cluster_chain_fwd, csrc/gt_cluster_chain.hip): four CUs of one
+    XCD share a 48-row panel as a tensor-parallel group over the MLP's hidden width and exchange the second Linear's partial sums once.
+    Same operands (``hidden`` must be 2048); ``ln_out`` (optional, [N, 512]): receives LN'(x2) WITHOUT its affine part.  Returns ``x_out``
+    or ``(x_out, q_out)``.  Inference only (no autograd)."""
+    _dev(attn, x_res, wp, w1g, w2, vec, extra, wqg, ln_out)
+    N, D = attn.shape
+    dt = attn.dtype
+    if not gt_cluster_chain_supported(attn, hidden, q_out_features):
+        raise NotImplementedError(f"gt_cluster_chain: {D} channels / {dt} / hidden={hidden} / q_out={q_out_features}")
+    if tuple(x_res.shape) != (N, D) or (extra is not None and tuple(extra.shape) != (N, D)) or (ln_out is not None and tuple(ln_out.shape) != (N, D)):
+        raise ValueError("gt_cluster_chain: attn, x_res, extra and ln_out must have the same [N, channels] shape")
+    if extra is not None and (q_out_features or ln_out is not None):
+        raise ValueError("gt_cluster_chain: a trailing projection / LayerNorm output and a second residual exclude each other")
+    for name, w, numel in (("wp", wp, D * D), ("w1g", w1g, hidden * D), ("w2", w2, D * hidden), ("wqg", wqg, q_out_features * D)):
+        if w is None and numel == 0:
+            continue
+        if w is None or w.dim() != 1 or w.numel() != numel or w.dtype != dt or not w.is_contiguous():
+            raise ValueError(f"gt_cluster_chain: {name} must be the contiguous fragment-major image ({numel} x {dt}) made by pack_weight_frag")
+    if vec.dim() != 1 or vec.numel() != 2 * D + hidden + q_out_features or vec.dtype != dt or not vec.is_contiguous():
+        raise ValueError(f"gt_cluster_chain: vec must be contiguous [{2 * D + hidden + q_out_features}] {dt} = cat[bp, d1, b2, dq]")
+    ws = _cluster_workspace(attn.device)
+    x_out = torch.empty((N, D), dtype=dt, device=attn.device)
+    q_out = torch.empty((N, q_out_features), dtype=dt, device=attn.device) if q_out_features else None
+    (ap, lda), (xp, ldx), (ep, lde), (lp, ldl) = _rows(attn, "attn", dt), _rows(x_res, "x_res", dt), _rows(extra, "extra", dt), _rows(ln_out, "ln_out", dt)
+    a = _ClusterChainArgs(ap, lda, xp, ldx, wp.data_ptr(), w1g.data_ptr(), hidden, w2.data_ptr(), 0 if wqg is None else wqg.data_ptr(), q_out_features,
+                          vec.data_ptr(), float(ln1_eps), float(lnq_eps), ep, lde, x_out.data_ptr(), D, 0 if q_out is None else q_out.data_ptr(),
+                          q_out_features, lp, ldl, ws.data_ptr(), ws.numel() * 4, N, D)
+    _lib.check(_lib.load().anemoi_gt_cluster_chain_fwd(_lib.C.byref(a), _dt(attn), _stream()), "gt_cluster_chain_fwd")
+    return x_out if q_out is None else (x_out, q_out)
+
+
+class _RowChainArgs(_lib.C.Structure):
+    _p, _i64, _i32, _f = _lib.C.c_void_p, _lib.C.c_int64, _lib.C.c_int32, _lib.C.c_float
+    _fields_ = [("x", _p), ("ld_x", _i64), ("in_features", _i32), ("we", _p), ("wq", _p), ("q_out_features", _i32), ("vec", _p), ("ln_eps", _f),
+                ("x_out", _p), ("ld_out", _i64), ("q_out", _p), ("ld_q", _i64), ("n_rows", _i32), ("channels", _i32), ("rows_per_tile", _i32)]
+
+
+def pack_embedding_frag(weight: Tensor) -> Tensor:
+    """Fragment-major image of an embedding weight [512, in] with its columns zero-padded to a multiple of 128 (``gt_row_chain``)."""
+    O, K = weight.shape
+    pad = (-K) % 128
+    w = weight.detach()
+    return pack_weight_frag(torch.nn.functional.pad(w, (0, pad)) if pad else w)
+
+
+def gt_row_chain_supported(x: Tensor, q_out: int) -> bool:
+    return (x.is_cuda and x.dim() == 2 and x.dtype in (torch.bfloat16, torch.float16) and 0 < x.shape[1] <= CHAIN_CHANNELS and x.shape[1] % 8 == 0
+            and x.stride(1) == 1 and x.stride(0) % 8 == 0 and q_out > 0 and q_out % CHAIN_CHANNELS == 0 and q_out <= 4 * CHAIN_CHANNELS)
+
+
+def gt_row_chain(x: Tensor, we: Tensor, wqg: Tensor, vec: Tensor, q_out_features: int, ln_eps: float, *, want_x_out: bool = True,
+                 rows_per_tile: int = 0):
+    """One side of a GraphTransformer mapper in ONE launch (anemoi_gt_rowchain_fwd, csrc/gt_rowchain.hip):
+
+        y = x We^T + be;   q_out = LN(y) Wq^T + bq
+
+    ``we``: ``pack_embedding_frag(We)``; ``wqg``: fragment-major image of ``Wq diag(gamma)``; ``vec = cat[be, Wq beta + bq]`` in the
+    model dtype (``fold_layer_norm``).  Returns ``(y or None, q_out)``.  Inference only (no autograd)."""
+    _dev(x, we, wqg, vec)
+    N, K = x.shape
+    dt, D = x.dtype, CHAIN_CHANNELS
+    if not gt_row_chain_supported(x, q_out_features):
+        raise NotImplementedError(f"gt_row_chain: x {tuple(x.shape)} {dt} / q_out={q_out_features} (16-bit rows of <= {D} columns, a multiple of 8; q_out a multiple of {D})")
+    kp = (K + 127) // 128 * 128
+    for name, w, numel in (("we", we, D * kp), ("wqg", wqg, q_out_features * D)):
+        if w.dim() != 1 or w.numel() != numel or w.dtype != dt or not w.is_contiguous():
+            raise ValueError(f"gt_row_chain: {name} must be the contiguous fragment-major image ({numel} x {dt})")
+    if vec.dim() != 1 or vec.numel() != D + q_out_features or vec.dtype != dt or not vec.is_contiguous():
+        raise ValueError(f"gt_row_chain: vec must be contiguous [{D + q_out_features}] {dt} = cat[be, dq]")
+    x_out = torch.empty((N, D), dtype=dt, device=x.device) if want_x_out else None
+    q_out = torch.empty((N, q_out_features), dtype=dt, device=x.device)
+    xp, ldx = _rows(x, "x", dt)
+    a = _RowChainArgs(xp, ldx, K, we.data_ptr(), wqg.data_ptr(), q_out_features, vec.data_ptr(), float(ln_eps),
+                      0 if x_out is None else x_out.data_ptr(), D, q_out.data_ptr(), q_out_features, N, D, int(rows_per_tile))
+    _lib.check(_lib.load().anemoi_gt_rowchain_fwd(_lib.C.byref(a), _dt(x), _stream()), "gt_rowchain_fwd")
+    return x_out, q_out
 
 
 def gnn_edge_chain(e: Tensor, g1: Tensor, idx1: Tensor, g2: Tensor, idx2: Tensor, w0: Tensor, b0: Tensor, w1: Tensor, b1: Tensor, w2: Tensor,
@@ -1125,9 +1188,16 @@ def graph_transformer_attention(q: Tensor, k: Tensor, v: Tensor, e: Tensor, row:
     q2, k2, v2, e2 = (t.contiguous().view(t.shape[0], H * Cc) for t in (q, k, v, e))
     csc = CSC(row=row.to(torch.int32).contiguous(), dst=edge_dst.to(torch.int32).contiguous(),
               colptr=colptr.to(torch.int32).contiguous(), n_src=k.shape[0], n_dst=N_dst)
+    if q.dtype != torch.float32:
+        # the reference keeps the UNROUNDED fp32 accumulator as out_saved and rounds a copy for the caller (triton/gt.py:416-426): the
+        # kernel's fp32 instantiation on the exactly upcast 16-bit operands produces that accumulator (same products, fp32 sums); the
+        # module path (layers/block.py) does not come through here - it runs the fused-edge kernel in the model dtype
+        saved, m = gt_attention(q2.float(), k2.float(), v2.float(), e2.float(), csc, H, return_lse=True)
+        saved = saved.view(N_dst, H, Cc)
+        return saved.to(q.dtype), saved, m
     out, m = gt_attention(q2, k2, v2, e2, csc, H, return_lse=True)
     out = out.view(N_dst, H, Cc)
-    return out, out.float() if out.dtype != torch.float32 else out.clone(), m
+    return out, out.clone(), m
 
 
 @graph_transformer_attention.register_fake
@@ -1143,7 +1213,9 @@ def graph_transformer_attention_backward(d_out: Tensor, q: Tensor, k: Tensor, v:
                                          row: Tensor, colptr: Tensor, rowptr: Tensor, edge_ids: Tensor,
                                          edge_dst: Tensor) -> tuple[Tensor, Tensor, Tensor, Tensor]:
     """Same signature as the reference's ``anemoi::graph_transformer_attention_backward`` (triton/gt.py:447-492):
-    returns (dQ, dK, dV, dE) shaped like q, k, v, e."""
+    returns (dQ, dK, dV, dE) shaped like q, k, v, e.  For 16-bit operands the kernels take ``out_saved`` ROUNDED to the model dtype (the
+    reference reads the fp32 accumulator in D = <dO, O>): one rounding of O, inside the stated 16-bit tolerance of the gradient tests
+    (tests/test_attention_backward_gpu.py); fp32 operands use it as it is."""
     N_dst, H, Cc = q.shape
     flat = lambda t: t.contiguous().view(t.shape[0], H * Cc)  # noqa: E731
     csc = CSC(row=row.to(torch.int32).contiguous(), dst=edge_dst.to(torch.int32).contiguous(),

@@ -133,15 +133,9 @@ def kernel_cases(model, g, args, dtype, device):
     if D == ops.CHAIN_CHANNELS and hid % ops.CHAIN_CHANNELS == 0 and dtype != torch.float32:
         # the row-resident chain: projection + LayerNorm + MLP + the next block's LayerNorm and q|k|v|self projection in ONE launch
         mlp, lnm = blk.node_dst_mlp, blk.layer_norm_mlp_dst
-        wp, bp = blk._fused.frag("proj", [blk.projection])
-        w1, b1 = blk._fused.frag("mlp1", [mlp.mlp[0]])
-        w2, b2 = blk._fused.frag("mlp2", [mlp.mlp[2]])
-        wq, bq = blk._fused.frag("qkvs", [blk.lin_query, blk.lin_key, blk.lin_value, blk.lin_self])
-        cases["gt_layer_chain(proj+mlp+next qkvs)"] = (
-            lambda: ops.gt_layer_chain(x, x, wp, bp, lnm.weight, lnm.bias, lnm.eps, w1, b1, w2, b2, lnq_w=ln.weight, lnq_b=ln.bias, lnq_eps=ln.eps, wq=wq, bq=bq),
-            "mfma", 2.0 * N * (D * D + 2 * D * hid + D * 4 * D))
+        wp, w2 = ops.pack_weight_frag(blk.projection.weight), ops.pack_weight_frag(mlp.mlp[2].weight)
         if ops.gt_layer_chain2_supported(x, hid, 4 * D):
-            # the role-split form (round 5: the default for blocks of >= 4 096 rows), the LayerNorms' affine parts folded into the weights
+            # role-split waves (the default for blocks of >= 4 096 rows), the LayerNorms' affine parts folded into the weights
             w1g, d1 = ops.fold_layer_norm(mlp.mlp[0].weight, mlp.mlp[0].bias, lnm.weight, lnm.bias)
             wq4, bq4 = blk._fused.get("qkvs", [blk.lin_query, blk.lin_key, blk.lin_value, blk.lin_self])
             wqg, dq = ops.fold_layer_norm(wq4, bq4, ln.weight, ln.bias)
@@ -304,23 +298,28 @@ def profile_forward(step, dtype, host_ms: float = 12.0):
         N, K, O = x.shape[0], w.shape[1], w.shape[0]
         return "linear_mfma_*", 2.0 * N * K * O, es * (N * K + O * K + N * O)
 
-    def chain_work(res_, a_, kw):
-        # the row-resident layer chain (csrc/gt_chain.hip): projection + MLP-1 + MLP-2 [+ the next block's q|k|v|self projection];
-        # compulsory bytes: attention rows and skip in, x2 [and the projections] out, every weight once (the hidden activations
-        # and the two LayerNorms never touch memory)
-        attn, b1 = a_[0], a_[8]
-        N, D, Hd = attn.shape[0], attn.shape[1], b1.shape[0]
-        Oq = kw["bq"].shape[0] if kw.get("bq") is not None else 0
-        extra = 1 if kw.get("extra") is not None else 0
-        return "gt_chain_kernel", 2.0 * N * (D * D + 2 * D * Hd + D * Oq), es * (N * D * (3 + extra) + N * Oq + D * D + 2 * D * Hd + D * Oq)
-
     def chain2_work(res_, a_, kw):
-        # the role-split layer chain (csrc/gt_chain2.hip): the same work and compulsory bytes as chain_work (+ the per-column vectors)
+        # the row-resident layer chain (csrc/gt_chain2.hip): projection + MLP-1 + MLP-2 [+ the next block's q|k|v|self projection];
+        # compulsory bytes: attention rows and skip in, x2 [and the projections] out, every weight once, the per-column vectors (the hidden
+        # activations and the two LayerNorms never touch memory)
         attn, vec, Hd = a_[0], a_[5], a_[6]
         N, D = attn.shape
         Oq = kw.get("q_out_features", 0)
         extra = 1 if kw.get("extra") is not None else 0
         return "gt_chain2_kernel", 2.0 * N * (D * D + 2 * D * Hd + D * Oq), es * (N * D * (3 + extra) + N * Oq + D * D + 2 * D * Hd + D * Oq + vec.numel())
+
+    def cluster_work(res_, a_, kw):
+        # the cluster chain (csrc/gt_cluster_chain.hip): the layer chain's work and compulsory bytes for block tails of few rows; what its four
+        # members compute redundantly (the projection) or move between them (the partial sums) is NOT algorithmic work
+        name, flops, byts = chain2_work(res_, a_, kw)
+        return "gt_cluster_chain_kernel", flops, byts
+
+    def rowchain_work(res_, a_, kw):
+        # a mapper side's embedding -> LayerNorm -> projection launch (csrc/gt_rowchain.hip): rows in, the projection [and the embedded rows] out
+        x, vec, Oq = a_[0], a_[3], a_[4]
+        N, K, D = x.shape[0], x.shape[1], 512
+        want = 1 if kw.get("want_x_out", True) else 0
+        return "gt_rowchain_kernel", 2.0 * N * (K * D + D * Oq), es * (N * K + N * D * want + N * Oq + K * D + D * Oq + vec.numel())
 
     def edge_chain_work(res_, a_, kw):
         # GraphConv's edge MLP (three [M x 512] -> 512 GEMMs in gather-add form) + LayerNorm + residual in one launch: e in, e' out,
@@ -361,7 +360,7 @@ def profile_forward(step, dtype, host_ms: float = 12.0):
 
     table = {"linear": ("linear", lin_work), "gt_attention_fused_edge": ("attn", attn_work), "layer_norm": ("ln", ln_work),
              "linear_with_row_stats": ("linear_stats", gemm_work), "linear_ln_folded": ("linear_lnfold", gemm_work),
-             "gt_layer_chain": ("chain", chain_work), "gt_layer_chain2": ("chain2", chain2_work), "gnn_edge_chain": ("edge_chain", edge_chain_work),
+             "gt_layer_chain2": ("chain2", chain2_work), "gt_cluster_chain": ("cluster", cluster_work), "gt_row_chain": ("rowchain", rowchain_work), "gnn_edge_chain": ("edge_chain", edge_chain_work),
              "gnn_node_chain": ("node_chain", node_chain_work), "gnn_mlp_chain": ("mlp_chain", mlp_chain_work), "segment_sum_rows": ("segrows", segrows_work),
              "edge_ln_residual_segment_sum": ("segsum", segsum_work), "gather_rows": ("gather", rows_work("gather_rows_kernel")),
              "gather_add_rows": ("gather_add", rows_work("gather_add_rows_kernel"))}

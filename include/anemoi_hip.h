@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ANEMOI_HIP_ABI_VERSION 12
+#define ANEMOI_HIP_ABI_VERSION 13
 
 typedef enum { ANEMOI_F32 = 0, ANEMOI_BF16 = 1, ANEMOI_F16 = 2 } anemoi_dtype_t;
 typedef enum { ANEMOI_ACT_NONE = 0, ANEMOI_ACT_GELU = 1 } anemoi_act_t;
@@ -358,8 +358,8 @@ int anemoi_peer_exchange_rows(const void* src, int64_t ld_src_bytes, const int32
                               int32_t n_peers, int32_t row_bytes, int32_t total_rows, uint32_t* local_flags, uint32_t* status,
                               int64_t timeout_ticks, void* stream);
 
-/* ---- row-resident layer chain (round 4) ---------------------------------------------------------------------------------
- * Everything of a GraphTransformerProcessorBlock that is local to a node row, after the edge attention, as ONE launch:
+/* ---- row-resident layer chain (csrc/gt_chain2.hip) -----------------------------------------------------------------------------
+ * Everything of a GraphTransformer block that is local to a node row, after the edge attention, as ONE launch:
  *     x1   = attn W_p^T + b_p + x_res                       projection + skip            (layers/block.py:1263-1266)
  *     h    = GELU(LayerNorm(x1; ln1) W_1^T + b_1)           node_dst_mlp, first Linear   (layers/block.py:1268-1271, layers/mlp.py:158-169)
  *     x2   = h W_2^T + b_2 + x1;  x_out = x2 [+ extra]      second Linear + skip [+ the model's latent skip, added to the ROUNDED
@@ -369,47 +369,25 @@ int anemoi_peer_exchange_rows(const void* src, int64_t ld_src_bytes, const int32
  *                                                           [lin_query; lin_key; lin_value; lin_self] (layers/block.py:1237-1245)
  * replacing four anemoi_linear_* launches per block (and the LayerNorm fold's statistics hand-off between them).  A workgroup keeps a
  * panel of <= 48 rows in LDS through the whole chain and streams the weights from L2 straight into MFMA operand registers; the
- * hidden activations [n_rows, hidden] are never written (csrc/gt_chain.hip).  LayerNorm here is the plain fp32 LayerNorm of the
- * rounded 16-bit rows with its output rounded to the model dtype - the arithmetic of the reference under autocast.
+ * hidden activations [n_rows, hidden] are never written.  The workgroup's eight waves form two groups of four that work DIFFERENT
+ * GEMM segments (group A: projection, MLP first Linear + GELU, even chunks of the trailing projection; group B: MLP second Linear, odd
+ * chunks), so that one group's epilogue runs beside the other group's MFMA and weight stream.
  *
  * Weights are FRAGMENT-MAJOR images made once per parameter version (ops.pack_weight_frag): for W [O, K] row-major (O % 64 == 0,
  * K % 32 == 0) the image is [O/64 slabs][K/32 k-steps][4 column blocks][4 k-slots][16 rows][8 elements], i.e. element
  * (slab, ks, ni, kslot, row, e) = W[slab*64 + ni*16 + row][ks*32 + kslot*8 + e] - one contiguous KiB per MFMA B fragment.
- * channels must be 512 (8 waves x 64 columns); hidden and q_out_features multiples of 512; 16-bit dtypes; all row pointers
- * 16-byte aligned.  rows_per_tile = 0 lets the library choose (anemoi_gt_chain_rows_per_tile). */
-typedef struct anemoi_gt_chain_args {
-  const void* attn;   int64_t ld_attn;    /* [n_rows, channels]   attention output + self term */
-  const void* x_res;  int64_t ld_x;       /* [n_rows, channels]   the block's input */
-  const void* wp;     const void* bp;     /* projection: fragment-major [channels, channels], bias [channels] */
-  const void* ln1_w;  const void* ln1_b;  float ln1_eps;  /* layer_norm_mlp_dst (ln1_b may be NULL) */
-  const void* w1;     const void* b1;     int32_t hidden; /* fragment-major [hidden, channels], bias [hidden] */
-  const void* w2;     const void* b2;     /* fragment-major [channels, hidden], bias [channels] */
-  const void* extra;  int64_t ld_extra;   /* optional [n_rows, channels] or NULL */
-  void* x_out;        int64_t ld_out;     /* [n_rows, channels] */
-  const void* lnq_w;  const void* lnq_b;  float lnq_eps;  /* the next block's layer_norm_attention (q_out_features > 0) */
-  const void* wq;     const void* bq;     int32_t q_out_features; /* fragment-major [q_out_features, channels], bias; 0: no trailing projection */
-  void* q_out;        int64_t ld_q;       /* [n_rows, q_out_features] */
-  int32_t n_rows;     int32_t channels;   int32_t rows_per_tile;
-  void* timeline;     /* NULL; developer aid: uint64 [min(256, panels)][8 waves][48] device buffer - the instrumented instantiation stamps the
-                         shader clock at every phase boundary of each workgroup's first panel (tools/chain_timeline.py) */
-} anemoi_gt_chain_args_t;
-int anemoi_gt_chain_fwd(const anemoi_gt_chain_args_t* args, anemoi_dtype_t dtype, void* stream);
-int anemoi_gt_chain_rows_per_tile(int32_t n_rows);
-
-/* ---- role-split row-resident layer chain (round 5; csrc/gt_chain2.hip) ------------------------------------------------------
- * The same block tail as anemoi_gt_chain_fwd (projection + skip, layer_norm_mlp_dst, node_dst_mlp + skip [+ latent skip], optionally the
- * NEXT block's layer_norm_attention + fused [q|k|v|self] projection: layers/block.py:1237-1273, encoder_processor_decoder.py:295-296),
- * with the workgroup's eight waves split into two groups of four that work DIFFERENT GEMM segments (group A: projection, MLP first
- * Linear + GELU, even chunks of the trailing projection; group B: MLP second Linear, odd chunks), so that one group's epilogue runs
- * beside the other group's MFMA and weight stream.  The two LayerNorms are computed as fp32 statistics of the rounded rows and applied
- * WITHOUT their affine part, the normalised row rounded to the model dtype; the affine part is folded by the caller into the Linear that
- * follows (ops.gt_layer_chain2 does it once per parameter version):
+ *
+ * The two LayerNorms are computed as fp32 statistics of the rounded rows and applied WITHOUT their affine part, the normalised row
+ * rounded to the model dtype; the affine part is folded by the caller into the Linear that follows (ops.gt_layer_chain2 does it once
+ * per parameter version):
  *     w1 = fragment-major image of W_1 diag(gamma_1) (rounded to the model dtype),   d1 = W_1 beta_1 + b_1
  *     wq = fragment-major image of W_q diag(gamma_q),                                 dq = W_q beta_q + b_q
  * and every bias enters as the START value of its GEMM's accumulators: vec = [b_p (512) | d1 (hidden) | b_2 (512) | dq (q_out_features)]
  * in the model dtype, kept in LDS (2*512 + hidden + q_out_features <= 6144, else ANEMOI_E_UNSUPPORTED).  extra and a trailing
- * projection exclude each other (the reference adds the latent skip behind the LAST block).  Images as for anemoi_gt_chain_fwd; all
- * leading dimensions multiples of 8 elements; channels must be 512. */
+ * projection exclude each other (the reference adds the latent skip behind the LAST block).  channels must be 512; hidden and
+ * q_out_features multiples of 512; 16-bit dtypes; all row pointers 16-byte aligned, all leading dimensions multiples of 8 elements.
+ * The projection is computed by all eight waves (64 columns each), then the groups split.  rows_per_tile = 0 lets the
+ * library choose (anemoi_gt_chain_rows_per_tile: 48). */
 typedef struct anemoi_gt_chain2_args {
   const void* attn;   int64_t ld_attn;    /* [n_rows, channels]   attention output + self term */
   const void* x_res;  int64_t ld_x;       /* [n_rows, channels]   the block's input */
@@ -423,9 +401,67 @@ typedef struct anemoi_gt_chain2_args {
   void* x_out;        int64_t ld_out;     /* [n_rows, channels] */
   void* q_out;        int64_t ld_q;       /* [n_rows, q_out_features] */
   int32_t n_rows;     int32_t channels;   int32_t rows_per_tile;
-  void* timeline;     /* NULL; developer aid: uint64 [min(256, panels)][8 waves][48] (tools/chain_timeline.py --v2) */
+  void* timeline;     /* must be NULL (ANEMOI_E_UNSUPPORTED otherwise); the experiments build of the library takes a uint64
+                         [min(256, panels)][8 waves][48] buffer for its instrumented instantiation (tools/chain2_timeline.py) */
 } anemoi_gt_chain2_args_t;
 int anemoi_gt_chain2_fwd(const anemoi_gt_chain2_args_t* args, anemoi_dtype_t dtype, void* stream);
+int anemoi_gt_chain_rows_per_tile(int32_t n_rows);
+
+/* ---- row-resident embedding chain of a GraphTransformer mapper side (round 6; csrc/gt_rowchain.hip) ---------------------------------
+ * One side of a GraphTransformer mapper in ONE launch:
+ *     y     = x W_e^T + b_e                       emb_nodes_src / emb_nodes_dst = Linear(in, 512)      (layers/mapper.py:556-566, 688-694)
+ *     q_out = LayerNorm(y) [W_a; W_b]^T + b       layer_norm_attention_src + [lin_key; lin_value] or
+ *                                                 layer_norm_attention_dest + [lin_query; lin_self]      (layers/block.py:981-984)
+ * replacing anemoi_linear_stats_fwd (the embedding GEMM + row statistics) and anemoi_linear_lnfold_fwd (the projection with the folded
+ * LayerNorm).  x_out = NULL: y is never written (the encoder's source side: the block returns the source rows untouched).
+ *   x  [n_rows, in_features], in_features a multiple of 8 up to 512;
+ *   we fragment-major image (see anemoi_gt_chain2_fwd) of W_e zero-padded to [512, 128 ceil(in_features / 128)];
+ *   wq fragment-major image of [W_a; W_b] diag(gamma) [q_out_features, 512] (the LayerNorm's affine part folded in by the caller,
+ *      ops.gt_row_chain), vec = [b_e (512) | W beta + b (q_out_features)] in the model dtype;
+ *   channels must be 512, q_out_features a multiple of 512 up to 2048, 16-bit dtypes, row pointers 16-byte aligned. */
+typedef struct anemoi_gt_rowchain_args {
+  const void* x;      int64_t ld_x;       int32_t in_features;
+  const void* we;                         /* fragment-major [channels, 128 ceil(in_features / 128)] */
+  const void* wq;     int32_t q_out_features; /* fragment-major [q_out_features, channels] */
+  const void* vec;                        /* [b_e | dq], model dtype, 16-byte aligned */
+  float ln_eps;
+  void* x_out;        int64_t ld_out;     /* optional [n_rows, channels] or NULL */
+  void* q_out;        int64_t ld_q;       /* [n_rows, q_out_features] */
+  int32_t n_rows;     int32_t channels;   int32_t rows_per_tile;  /* rows_per_tile = 0: 48 */
+} anemoi_gt_rowchain_args_t;
+int anemoi_gt_rowchain_fwd(const anemoi_gt_rowchain_args_t* args, anemoi_dtype_t dtype, void* stream);
+
+/* ---- cluster chain: the block tail for FEW rows (round 6; csrc/gt_cluster_chain.hip) ----------------------------------------------
+ * What anemoi_gt_chain2_fwd computes (same operands, same folded LayerNorms, same vec layout with hidden = 2048:
+ * [b_p 512 | d1 2048 | b_2 512 | dq q_out_features]), organised for block tails of a few thousand rows - a rank's share of a sharded
+ * mesh, small hidden meshes: FOUR CUs of one XCD own a 48-row panel as a tensor-parallel group over the MLP's hidden width (each streams
+ * the projection, one 512-column chunk of the first Linear, the matching K-slice of the second Linear and one chunk of the trailing
+ * projection: 2 MiB instead of 6.5 MiB per layer), exchange the second Linear's fp32 partial sums ONCE per panel through `workspace`
+ * (agent-scope stores / loads + an atomic counter per cluster) and add them in member order, so that every member holds the same x2.
+ * Replaces layers/block.py:1263-1273 (+ :1237-1245 of the next block) like the chain; hidden must be 2048, q_out_features <= 2048.
+ *   ln_out (nullable): LayerNorm_attn'(x2) WITHOUT its affine part [n_rows, 512] - what a sharded block sends to its halo peers;
+ *   workspace: anemoi_gt_cluster_chain_workspace_bytes() bytes, 128-byte aligned, ZERO at allocation and then owned by the library (the
+ *   cluster counters in it are monotonic across launches); one workspace per device and stream of launches.
+ * A cluster's four workgroups must be resident together (the launch uses at most one workgroup per CU); a member that waits for a
+ * partner for more than ~1 s traps: the launch fails, it never returns partial sums. */
+typedef struct anemoi_gt_cluster_chain_args {
+  const void* attn;   int64_t ld_attn;    /* [n_rows, channels]   attention output + self term */
+  const void* x_res;  int64_t ld_x;       /* [n_rows, channels]   the block's input */
+  const void* wp;                         /* projection, fragment-major [channels, channels] */
+  const void* w1;     int32_t hidden;     /* fragment-major [hidden, channels], layer_norm_mlp_dst's gamma folded in; hidden = 2048 */
+  const void* w2;                         /* fragment-major [channels, hidden] */
+  const void* wq;     int32_t q_out_features; /* fragment-major [q_out_features, channels], the next block's gamma folded in; 0: none */
+  const void* vec;                        /* [b_p | d1 | b_2 | dq], model dtype, 16-byte aligned */
+  float ln1_eps;      float lnq_eps;
+  const void* extra;  int64_t ld_extra;   /* optional [n_rows, channels] or NULL (not together with q_out / ln_out) */
+  void* x_out;        int64_t ld_out;     /* [n_rows, channels] */
+  void* q_out;        int64_t ld_q;       /* [n_rows, q_out_features] */
+  void* ln_out;       int64_t ld_ln;      /* optional [n_rows, channels] */
+  void* workspace;    int64_t workspace_bytes;
+  int32_t n_rows;     int32_t channels;
+} anemoi_gt_cluster_chain_args_t;
+int anemoi_gt_cluster_chain_fwd(const anemoi_gt_cluster_chain_args_t* args, anemoi_dtype_t dtype, void* stream);
+int64_t anemoi_gt_cluster_chain_workspace_bytes(void);
 
 /* ---- row-resident chains of the GraphConv (GNN) processor block (round 4; csrc/gnn_chain.hip) ------------------------------------
  * GraphConv (layers/conv.py:29-81) in its gather-add form, with an edge MLP of three Linears (mlp_extra_layers = 0):
@@ -434,19 +470,11 @@ int anemoi_gt_chain2_fwd(const anemoi_gt_chain2_args_t* args, anemoi_dtype_t dty
  * columns of the first Linear's weight.  ONE launch instead of three edge-level GEMMs + the LayerNorm / residual half of
  * anemoi_edge_ln_residual_segment_sum_fwd (whose arithmetic and rounding points it keeps: the GEMM outputs rounded to the model
  * dtype, one rounding of LayerNorm(z) + e); the scatter-sum over e_new is anemoi_segment_sum_rows.  w0 / w1 / w2 are fragment-major
- * images (see anemoi_gt_chain_fwd) of [512, 512] weights. */
+ * images (see anemoi_gt_chain2_fwd) of [512, 512] weights. */
 int anemoi_gnn_edge_chain_fwd(const void* e, int64_t ld_e, const void* g1, int64_t ld_g1, const int32_t* idx1, const void* g2, int64_t ld_g2,
                               const int32_t* idx2, const void* w0, const void* b0, const void* w1, const void* b1, const void* w2, const void* b2,
                               const void* ln_w, const void* ln_b, float eps, void* e_new, int64_t ld_o, int32_t n_rows, int32_t channels,
                               anemoi_dtype_t dtype, void* stream);
-/* Developer aid (tools/edge_chain_timeline.py): anemoi_gnn_edge_chain_fwd (bf16) through an instrumented instantiation that stamps the
- * shader clock at the phase boundaries of every panel - all 8 waves, a workgroup's first five panels.
- * timeline: uint64 [min(256, ceil(n_rows / 64))][8][48], slot 0 = kernel entry, then 8 slots per panel. */
-int anemoi_gnn_edge_chain_timeline(const void* e, int64_t ld_e, const void* g1, int64_t ld_g1, const int32_t* idx1, const void* g2,
-                                   int64_t ld_g2, const int32_t* idx2, const void* w0, const void* b0, const void* w1, const void* b1,
-                                   const void* w2, const void* b2, const void* ln_w, const void* ln_b, float eps, void* e_new,
-                                   int64_t ld_o, int32_t n_rows, unsigned long long* timeline, void* stream);
-
 /* An embedding MLP of the GNN mappers / processor as ONE launch (the edge chain without gathered rows):
  *   out = LayerNorm(W_2 gelu(W_1 gelu(W_0 x + b_0) + b_1) + b_2) [+ res]
  * Replaces: MLP.forward for `emb_edges` / `emb_nodes_src` / `emb_nodes_dst` (layers/mlp.py:29-100 as built at

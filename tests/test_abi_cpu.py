@@ -40,6 +40,24 @@ def test_library_loads_and_exports_all_symbols():
         assert hasattr(lib, name), name
 
 
+def test_product_library_carries_no_experiment_switches():
+    """switches that make a kernel skip work (timing experiments: ANEMOI_*_DBG, wave-priority / delay knobs, the
+    two-group GraphConv chain, the round-4 layer chain, in-kernel timelines) are compiled only into the experiments build
+    (-DANEMOI_EXPERIMENTS -> lib/libanemoi_hip_exp.so).  The product .so must not even contain their names, nor the experimental entry
+    points: no environment variable can change what a shipped kernel computes."""
+    if not os.path.exists(_lib.LIB_PATH):
+        from anemoi_core_amd.build import build_library
+
+        build_library(verbose=False)
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for name in (b"_DBG", b"ANEMOI_CHAIN2_PRIO", b"ANEMOI_CHAIN2_B_DELAY", b"ANEMOI_CHAIN2_WARM", b"ANEMOI_GNN_CHAIN_V2", b"ANEMOI_CHAIN_PRIO_YOUNG",
+                 b"anemoi_gt_chain_fwd", b"anemoi_gnn_edge_chain_timeline", b"gnn_edge_chain2_kernel", b"gt_chain_kernel"):
+        assert name not in blob, name
+    lib = _lib.load()
+    for name in _lib.EXPERIMENT_SIGNATURES:
+        assert not hasattr(lib, name), name
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setenv("ANEMOI_HIP_LIB", str(tmp_path / "nope.so"))

@@ -13,8 +13,15 @@ from gemm_sweep import timeit  # noqa: E402
 
 from anemoi_core_amd import ops  # noqa: E402
 
+SHAPES = {
+    "512": ((10242, 512, 2048), (10242, 512, 512), (10242, 2048, 512), (40320, 512, 2048), (40320, 2048, 512), (81840, 512, 512)),
+    # the reference's default width (config/model/graphtransformer.yaml:1): q|k|v|self, MLP-1, MLP-2, projection of a processor layer and the mapper sides
+    "1024": ((10242, 1024, 4096), (10242, 4096, 1024), (10242, 1024, 1024), (40320, 1024, 2048), (40320, 1024, 4096), (40320, 4096, 1024)),
+}
+
 if __name__ == "__main__":
-    for N, K, O in ((10242, 512, 2048), (10242, 512, 512), (10242, 2048, 512), (40320, 512, 2048), (40320, 2048, 512), (81840, 512, 512)):
+    which = sys.argv[1] if len(sys.argv) > 1 else "512"
+    for N, K, O in SHAPES[which]:
         x = torch.randn(N, K, device="cuda").to(torch.bfloat16)
         w = (torch.randn(O, K, device="cuda") / K**0.5).to(torch.bfloat16)
         b = torch.randn(O, device="cuda").to(torch.bfloat16)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Role-split layer chain (csrc/gt_chain2.hip) next to the round-4 chain (csrc/gt_chain.hip) on the same inputs: time per launch
-back to back, and the in-kernel timeline of the instrumented instantiation - shader-clock stamps of every wave at every step
+"""The layer chain (csrc/gt_chain2.hip): time per launch back to back (with the EXPERIMENTS build of the library - python -m
+anemoi_core_amd.build --experiments, ANEMOI_HIP_LIB=anemoi_core_amd/lib/libanemoi_hip_exp.so - also next to the round-4 chain,
+csrc/experiments/gt_chain.hip, on the same inputs), and - experiments build only - the in-kernel timeline of the instrumented instantiation - shader-clock stamps of every wave at every step
 boundary of each workgroup's first panel, medians over the workgroups, in microseconds (group A = waves 0-3, group B = waves 4-7).
 
     python tools/chain2_timeline.py [--rows 10242] [--no-q] [--no-timeline]
@@ -12,7 +13,11 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from anemoi_core_amd import ops  # noqa: E402
+from anemoi_core_amd import _lib, ops  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from experiments_ops import gt_layer_chain  # noqa: E402
+
+HAVE_EXPERIMENTS = hasattr(_lib.load(), "anemoi_gt_chain_fwd")
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, default=10242)
@@ -47,7 +52,7 @@ def v1():
     w = sets[it1[0] % L]
     it1[0] += 1
     kw1 = {} if args.no_q else dict(lnq_w=g1, lnq_b=be1, wq=w["wq"], bq=bq)
-    return ops.gt_layer_chain(attn, x, w["wp"], bp, g1, be1, 1e-5, w["w1"], b1, w["w2"], b2, rows_per_tile=args.rows_per_tile, **kw1)
+    return gt_layer_chain(attn, x, w["wp"], bp, g1, be1, 1e-5, w["w1"], b1, w["w2"], b2, rows_per_tile=args.rows_per_tile, **kw1)
 
 
 def v2(tl=None):
@@ -79,16 +84,17 @@ def timed(fn, n=20):
 
 
 for _ in range(300):  # the clocks of an idle GPU take milliseconds to ramp
-    v1()
+    v2()
 torch.cuda.synchronize()
-a, b = v1(), v2()
-a, b = (a, b) if args.no_q else (a[0], b[0])
-print(f"v2 against v1: max |dx2| {float((a.float() - b.float()).abs().max()):.4f} at scale {float(a.float().abs().max()):.2f}")
+if HAVE_EXPERIMENTS:
+    a, b = v1(), v2()
+    a, b = (a, b) if args.no_q else (a[0], b[0])
+    print(f"v2 against v1: max |dx2| {float((a.float() - b.float()).abs().max()):.4f} at scale {float(a.float().abs().max()):.2f}")
 for rep in range(3):
-    t1 = timed(v1)
+    t1 = timed(v1) if HAVE_EXPERIMENTS else float("nan")
     t2 = timed(v2)
     print(f"{N} rows, {L} weight sets, back to back: round-4 chain {t1:7.2f} us   role-split chain {t2:7.2f} us per launch")
-if args.no_timeline:
+if args.no_timeline or not HAVE_EXPERIMENTS:
     sys.exit(0)
 tl = torch.zeros(256, 8, 48, dtype=torch.int64, device=dev)
 for _ in range(50):
@@ -102,13 +108,13 @@ span = (tw[:nwg].max(2).values.max(1).values - tw[:nwg, :, 0].min(1).values).med
 mhz = span / wall_us
 print(f"instrumented launch {wall_us:.1f} us, {na} / {nb} stamps (group A / B), median workgroup span {span:.0f} ticks -> {mhz:.0f} ticks/us")
 hc, qc = HD // D, qf // D
-names_a = ["entry", "S0 rows requested", "S0 all requested", "S0 rows stored", "S0 panel in LDS", "S1 P GEMM", "S1 x1 -> bufC + stats", "S2 LN -> bufB"]
+names_a = ["entry", "S0 rows requested", "S0 all requested", "S0 rows stored", "S1 start (panel in LDS)", "S1 P GEMM (64 columns)", "S1 x1 -> bufC + stats", "S2 LN -> bufB"]
 for t in range(hc):
     names_a += [f"M{t} start", f"M{t} M1 GEMM", f"M{t} GELU -> h"]
 names_a += [f"M{hc} (idle) start", f"M{hc} passed", "S8 x2 -> global"]
 for k in range(0, qc, 2):
     names_a += [f"Q{k} start", f"Q{k} GEMM", f"Q{k} stores issued"]
-names_b = ["entry", "S0 passed", "skip rows, vectors, ring", "x1 barriers passed", "S2 acc2 = b2 + x1", "M0 (idle) start"]
+names_b = ["entry", "S0 skip rows, vectors, ring", "S1 start (panel in LDS)", "S1 P GEMM (64 columns)", "S1 x1 -> bufC + stats", "S2 LN -> bufB", "S2 acc2 = b2 + x1", "M0 (idle) start"]
 for t in range(1, hc + 1):
     names_b += [f"M{t} start", f"M{t} M2 GEMM"] + (["x2 -> buf + stats"] if t == hc else [])
 names_b += ["S8 LN' -> bufB"]

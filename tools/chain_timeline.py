@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""In-kernel timeline of the row-resident layer chain (csrc/gt_chain.hip, instrumented instantiation): shader-clock stamps of
+"""EXPERIMENTS BUILD ONLY (python -m anemoi_core_amd.build --experiments; ANEMOI_HIP_LIB=anemoi_core_amd/lib/libanemoi_hip_exp.so).
+In-kernel timeline of the round-4 row-resident layer chain (csrc/experiments/gt_chain.hip, instrumented instantiation): shader-clock stamps of
 wave 0 at every phase boundary of each workgroup's first panel, as medians over the workgroups, in microseconds.
 
     python tools/chain_timeline.py [--rows 10242] [--no-q]
@@ -12,6 +13,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from anemoi_core_amd import ops  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from experiments_ops import gt_layer_chain  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, default=10242)
@@ -27,7 +30,7 @@ bp, b1, b2, bq = r(D).to(dt) * 0.1, r(HD).to(dt) * 0.1, r(D).to(dt) * 0.1, r(4 *
 g1, be1 = torch.ones(D, device=dev, dtype=dt), torch.zeros(D, device=dev, dtype=dt)
 P = ops.pack_weight_frag
 kw = {} if args.no_q else dict(lnq_w=g1, lnq_b=be1, wq=P(wq), bq=bq)
-call = lambda tl=None: ops.gt_layer_chain(attn, x, P(wp), bp, g1, be1, 1e-5, P(w1), b1, P(w2), b2, rows_per_tile=args.rows_per_tile, timeline=tl, **kw)  # noqa: E731
+call = lambda tl=None: gt_layer_chain(attn, x, P(wp), bp, g1, be1, 1e-5, P(w1), b1, P(w2), b2, rows_per_tile=args.rows_per_tile, timeline=tl, **kw)  # noqa: E731
 for _ in range(400):  # ~50 ms of work: the clocks of an idle GPU take milliseconds to ramp (a cold launch runs at about half speed)
     call()
 torch.cuda.synchronize()

@@ -7,7 +7,7 @@ import sqlite3
 import sys
 
 FAMILIES = {"linear_mfma_*": "linear_mfma", "gt_attn_fused_edge_fwd_kernel": "gt_attn_fused_edge", "layernorm_fwd_kernel": "layernorm_fwd",
-            "edge_ln_res_segsum_kernel": "edge_ln_res_segsum", "gt_chain_kernel": "gt_chain_kernel<", "gt_chain2_kernel": "gt_chain2_kernel", "gnn_edge_chain_kernel": "gnn_edge_chain_kernel",
+            "edge_ln_res_segsum_kernel": "edge_ln_res_segsum", "gt_chain2_kernel": "gt_chain2_kernel", "gt_cluster_chain_kernel": "gt_cluster_chain_kernel", "gt_rowchain_kernel": "gt_rowchain_kernel", "gnn_edge_chain_kernel": "gnn_edge_chain_kernel",
             "gnn_node_chain_kernel": "gnn_node_chain_kernel", "segment_sum_rows_kernel": "segment_sum_rows_kernel"}
 
 
