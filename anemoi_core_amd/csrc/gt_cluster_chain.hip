@@ -40,7 +40,8 @@ struct ClusterArgs {
   const void* extra; int64_t ld_extra;
   void* xout;        int64_t ld_out;
   void* qout;        int64_t ld_q;
-  void* lnout;       int64_t ld_ln;  // optional: LN_attn'(x2) WITHOUT its affine part, [n_rows, 512] (a sharded block exchanges these rows)
+  void* lnout;       int64_t ld_ln;  // optional: LN_attn'(x2) WITHOUT its affine part, [n_rows, 512]
+  void* qout2;       int64_t ld_q2;  int q_split;  // optional: chunks >= q_split of the trailing projection go to qout2 (column 512 (chunk - q_split))
   float* scratch;                    // [clusters][2][4 members][8 waves][3][4][64 lanes][4] fp32
   unsigned* counters;                // [clusters], zero at allocation, then monotonic (4 per panel)
   int n_rows, rows_per_tile, n_tiles;
@@ -313,7 +314,8 @@ __global__ __launch_bounds__(512, 1) void gt_cluster_chain_kernel(ClusterArgs a)
       init_acc64<T>(acc, vec, 3072 + 512 * m, lane, w8);
       gemm64<T>(bufB, lane, ring, wqs, wps, 8192, loff, acc);
       round_rows64<T, false>(acc, bufH, lane, w8);
-      store_staged64<T>(bufH, (T*)a.qout + (int64_t)r0 * a.ld_q + m * kCh, a.ld_q, nr, lane, w8);
+      if (a.qout2 != nullptr && m >= a.q_split) store_staged64<T>(bufH, (T*)a.qout2 + (int64_t)r0 * a.ld_q2 + (m - a.q_split) * kCh, a.ld_q2, nr, lane, w8);
+      else store_staged64<T>(bufH, (T*)a.qout + (int64_t)r0 * a.ld_q + m * kCh, a.ld_q, nr, lane, w8);
     }
     if (!more) break;
     lds_barrier();  // every wave is behind its last read of bufB / bufH
@@ -354,7 +356,9 @@ extern "C" int anemoi_gt_cluster_chain_fwd(const anemoi_gt_cluster_chain_args_t*
   ANEMOI_REQUIRE(p->q_out_features >= 0 && p->q_out_features % kCh == 0 && p->q_out_features <= 4 * kCh,
                  "gt_cluster_chain_fwd: q_out_features=%d must be a multiple of %d up to %d", p->q_out_features, kCh, 4 * kCh);
   ANEMOI_REQUIRE(p->attn && p->x_res && p->wp && p->w1 && p->w2 && p->vec && p->x_out && p->workspace, "gt_cluster_chain_fwd: null operand");
-  ANEMOI_REQUIRE(p->q_out_features == 0 || (p->wq && p->q_out), "gt_cluster_chain_fwd: the trailing projection needs wq and q_out");
+  // columns of the trailing projection that go to q_out (all of them without a second destination)
+  const int q1_cols = p->q_out2 != nullptr ? (p->q_split < 0 ? 0 : (p->q_split * kCh < p->q_out_features ? p->q_split * kCh : p->q_out_features)) : p->q_out_features;
+  ANEMOI_REQUIRE(p->q_out_features == 0 || (p->wq && (q1_cols == 0 || p->q_out)), "gt_cluster_chain_fwd: the trailing projection needs wq and q_out");
   ANEMOI_REQUIRE((p->q_out_features == 0 && p->ln_out == nullptr) || p->extra == nullptr,
                  "gt_cluster_chain_fwd: the trailing projection / LayerNorm output read x2 before a second residual is added: not both");
   const auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
@@ -363,7 +367,7 @@ extern "C" int anemoi_gt_cluster_chain_fwd(const anemoi_gt_cluster_chain_args_t*
                  "gt_cluster_chain_fwd: operands must be 16-byte aligned (workspace: 128)");
   ANEMOI_REQUIRE(p->ld_attn >= kCh && p->ld_x >= kCh && p->ld_out >= kCh && p->ld_attn % 8 == 0 && p->ld_x % 8 == 0 && p->ld_out % 8 == 0 &&
                      (p->extra == nullptr || (p->ld_extra >= kCh && p->ld_extra % 8 == 0)) && (p->ln_out == nullptr || (p->ld_ln >= kCh && p->ld_ln % 8 == 0)) &&
-                     (p->q_out_features == 0 || (p->ld_q >= p->q_out_features && p->ld_q % 8 == 0)),
+                     (q1_cols == 0 || (p->ld_q >= q1_cols && p->ld_q % 8 == 0)),
                  "gt_cluster_chain_fwd: leading dimensions too small or not multiples of 8 elements (rows move as 16-byte pieces)");
   ANEMOI_REQUIRE(p->workspace_bytes >= anemoi_gt_cluster_chain_workspace_bytes(), "gt_cluster_chain_fwd: workspace of %lld bytes, need %lld",
                  (long long)p->workspace_bytes, (long long)anemoi_gt_cluster_chain_workspace_bytes());
@@ -378,6 +382,10 @@ extern "C" int anemoi_gt_cluster_chain_fwd(const anemoi_gt_cluster_chain_args_t*
   a.xout = p->x_out; a.ld_out = p->ld_out;
   a.qout = p->q_out; a.ld_q = p->ld_q;
   a.lnout = p->ln_out; a.ld_ln = p->ld_ln;
+  a.qout2 = p->q_out2; a.ld_q2 = p->ld_q2; a.q_split = p->q_split;
+  ANEMOI_REQUIRE(p->q_out2 == nullptr || (p->q_split >= 0 && p->q_split * kCh <= p->q_out_features && al16(p->q_out2) && p->ld_q2 % 8 == 0 &&
+                                          p->ld_q2 >= p->q_out_features - p->q_split * kCh),
+                 "gt_cluster_chain_fwd: q_out2 needs 0 <= 512 q_split <= q_out_features, 16-byte alignment and ld_q2 >= the columns it receives");
   // the counters first (their own 128-byte lines), the partial slots behind them
   a.counters = reinterpret_cast<unsigned*>(p->workspace);
   a.scratch = reinterpret_cast<float*>(reinterpret_cast<char*>(p->workspace) + 64 * 128);

@@ -58,6 +58,9 @@ _LAYER_CHAIN_MIN_ROWS = int(os.environ.get("ANEMOI_LAYER_CHAIN_MIN_ROWS", "0" if
 # the hidden meshes of res 3 / 4) puts four times as many CUs to work, each streaming 2 MiB of weights instead of 6.5.  ANEMOI_CLUSTER_CHAIN=0:
 # the LayerNorm-fold GEMM launches below the gate, as in round 5.
 _CLUSTER_CHAIN = os.environ.get("ANEMOI_CLUSTER_CHAIN", "1") != "0"
+# ... and on a SHARDED mesh that launch also computes the next block's projections of the local rows, so that the halo exchange moves the owners'
+# k | v rows and the LayerNorm launch and the q|k|v|self GEMM over local + halo rows disappear.  ANEMOI_CLUSTER_HALO=0: LayerNorm'd rows on the wire.
+_CLUSTER_HALO = os.environ.get("ANEMOI_CLUSTER_HALO", "1") != "0"
 
 
 _IDENTITY: dict = {}
@@ -370,11 +373,16 @@ class GraphTransformerBaseBlock(BaseBlock):
                                                          for p in m.parameters())))
 
     def _post_attention(self, attn_plus_self: Tensor, x_skip: Tensor, cond: Optional[Tensor] = None, chain: Optional[dict] = None,
-                        extra: Optional[Tensor] = None, next_block=None) -> Tensor:
+                        extra: Optional[Tensor] = None, next_block=None, halo=None) -> Tensor:
         """projection + residual, LayerNorm, MLP + residual.  Inference: the projection GEMM also emits the row statistics of
         its output and the MLP's first GEMM applies the LayerNorm from them (no LayerNorm launch); with ``chain`` the last
         GEMM does the same for the NEXT block's first LayerNorm.  ``extra`` (last block of a processor): the model's latent
         skip (encoder_processor_decoder.py:295-296), added by the last GEMM's epilogue as a second residual."""
+        # ``halo`` (a sharded processor block at inference: (HaloPlan, group)): where the cluster chain takes the tail it also computes the NEXT
+        # block's LayerNorm + projections of the LOCAL rows - q | self into a buffer of their own, k | v straight into the head of the
+        # [local + halo, 2A] buffer whose tail the halo exchange fills.  The next block then starts with that exchange (``chain["halo_pre"]``):
+        # what crosses the wire are the owners' k | v rows (2 KiB per row instead of the 1-KiB LayerNorm'd row the reference exchanges,
+        # layers/block.py:1159-1172 - the exchange is latency-bound, SURVEY 8e) and no rank projects a halo row again.
         if extra is not None and (ops._needs_grad(attn_plus_self, x_skip, extra, self.projection.weight) or extra.shape != x_skip.shape):
             return self._post_attention(attn_plus_self, x_skip, cond, chain) + extra
         ln, mlp = self.layer_norm_mlp_dst, self.node_dst_mlp
@@ -383,13 +391,17 @@ class GraphTransformerBaseBlock(BaseBlock):
         if (cond is None and (cluster or self._chain_ok(ln, attn_plus_self)) and attn_plus_self.shape == x_skip.shape
                 and (extra is None or extra.shape == x_skip.shape)):
             nb = next_block if (next_block is not None and chain is not None and extra is None and next_block._qkvs_chain_ok(x_skip)) else None
+            if halo is not None and not (_CLUSTER_HALO and cluster and nb is not None and getattr(nb, "shard_strategy", None) == "edges"):
+                nb = None  # (a sharded block's k | v need the halo rows: only the cluster chain has the LayerNorm'd rows as an output)
             hidden = mlp.mlp[0].weight.shape[0]
             supported = ops.gt_cluster_chain_supported if cluster else ops.gt_layer_chain2_supported
             if nb is not None and not supported(attn_plus_self, hidden, 4 * nb.attn_channels):
                 nb = None  # the per-column vectors of tail + trailing projection do not fit the kernel's LDS region: the tail alone
             if supported(attn_plus_self, hidden, 0 if nb is None else 4 * nb.attn_channels):
                 lin1, lin2 = mlp.mlp[0], mlp.mlp[2]
-                qlins = [] if nb is None else [nb.lin_query, nb.lin_key, nb.lin_value, nb.lin_self]
+                qlins = [] if nb is None else ([nb.lin_query, nb.lin_self, nb.lin_key, nb.lin_value] if halo is not None else
+                                              [nb.lin_query, nb.lin_key, nb.lin_value, nb.lin_self])
+                q_out = sum(lin.out_features for lin in qlins)
                 lnq = None if nb is None else nb.layer_norm_attention
                 params = [self.projection.weight, self.projection.bias, ln.weight, ln.bias, lin1.weight, lin1.bias, lin2.weight, lin2.bias]
                 params += [q for lin in qlins for q in (lin.weight, lin.bias)] + ([] if lnq is None else [lnq.weight, lnq.bias])
@@ -407,10 +419,19 @@ class GraphTransformerBaseBlock(BaseBlock):
                     return (ops.pack_weight_frag(self.projection.weight), ops.pack_weight_frag(w1g), ops.pack_weight_frag(lin2.weight),
                             torch.cat(parts).to(lin1.weight.dtype).contiguous(), wqg)
 
-                wp, w1g, w2, vec, wqg = self._fused.derived("chain2" if nb is None else f"chain2:{id(nb)}", params, build)
+                wp, w1g, w2, vec, wqg = self._fused.derived("chain2" if nb is None else f"chain2:{id(nb)}:{len(qlins)}", params, build)
+                kw = {}
+                if halo is not None and nb is not None:
+                    plan, group = halo
+                    nl = x_skip.shape[0]
+                    buf = comm.recv_buffer(nl, plan.send_counts, plan.recv_counts, 2 * nb.attn_channels, x_skip.dtype, x_skip.device, group)
+                    kw["q_out2"], kw["q_split"] = buf[:nl], 2 * nb.attn_channels // ops.CHAIN_CHANNELS
                 res = (ops.gt_cluster_chain if cluster else ops.gt_layer_chain2)(
                     attn_plus_self, x_skip, wp, w1g, w2, vec, hidden, ln.eps, extra=extra, wqg=wqg,
-                    q_out_features=0 if nb is None else 4 * nb.attn_channels, lnq_eps=1e-5 if lnq is None else lnq.eps)
+                    q_out_features=q_out, lnq_eps=1e-5 if lnq is None else lnq.eps, **kw)
+                if kw:
+                    chain["halo_pre"] = {"x": res[0], "buf": buf, "qs": res[1]}
+                    return res[0]
                 if nb is not None:
                     chain["qkvs_x"], chain["qkvs"] = res
                     return res[0]
@@ -576,6 +597,18 @@ class GraphTransformerProcessorBlock(GraphTransformerBaseBlock):
             return self._post_attention(out, x, cond, chain, kwargs.get("extra_residual"), next_block=nxt), edge_attr
         sharded = model_is_distributed(model_comm_group) and self.shard_strategy != "heads"
         x_plus_halo = None
+        pre = chain.pop("halo_pre", None) if chain is not None else None
+        if (pre is not None and pre["x"] is x and sharded and cond is None and not ops._needs_grad(x, ln.weight, self.lin_key.weight)):
+            # the previous block's cluster-chain launch left this block's q | self projection and, in the head of the [local + halo, 2A]
+            # buffer, the k | v rows of its own nodes: the exchange brings the halo nodes' k | v rows from their owners, then attention, tail
+            plan = self._halo_plan(x, edge_index, shard_info, batch_size, model_comm_group, halo_cache)
+            nl = x.shape[0]
+            kv, qs = pre["buf"], pre["qs"]
+            comm.halo_exchange_into(kv, nl, plan.send_index, plan.send_counts, plan.recv_counts, model_comm_group, ops.gather_rows)
+            csc = get_csc(plan.edge_index_local, (plan.info.total_nodes, plan.info.num_local_nodes), True)
+            out = self._attention(qs[:, :A], kv[:, :A], kv[:, A:], qs[:, A:], edge_attr, csc,
+                                  fused=dict(bufs=(qs, kv), q=(0, 0), s=(0, A), k=(1, 0), v=(1, A)), edge_prep=kwargs.get("edge_prep"))
+            return self._post_attention(out, x, cond, chain, kwargs.get("extra_residual"), next_block=nxt, halo=(plan, model_comm_group)), edge_attr
         if (sharded and cond is None and not isinstance(ln, ConditionalLayerNorm) and not ops._needs_grad(x, ln.weight)):
             # inference on a shard: LayerNorm writes the head of the [local + halo] buffer, the all-to-all receives into its tail
             plan = self._halo_plan(x, edge_index, shard_info, batch_size, model_comm_group, halo_cache)
@@ -617,6 +650,8 @@ class GraphTransformerProcessorBlock(GraphTransformerBaseBlock):
             fused = dict(bufs=(qkvs,), q=(0, 0), k=(0, A), v=(0, 2 * A), s=(0, 3 * A))
             csc = get_csc(edge_index, (n, n), edges_are_dst_sorted)
         out = self._attention(q, k, v, x_r, edge_attr, csc, fused=fused, edge_prep=kwargs.get("edge_prep"))
+        if x_plus_halo is not None and sharded and chain is not None:  # inference on a shard: the tail may prepare the next block's exchange
+            return self._post_attention(out, x, cond, chain, kwargs.get("extra_residual"), next_block=nxt, halo=(plan, model_comm_group)), edge_attr
         return self._post_attention(out, x, cond, extra=kwargs.get("extra_residual")), edge_attr
 
 

@@ -297,7 +297,13 @@ class AnemoiModelEncProcDec(nn.Module):
                                        edge_attr=ea, edge_index=ei, model_comm_group=model_comm_group, **chain_kw,
                                        **({"latent_skip": x_latent} if fuse_skip else {}))
         if self.latent_skip and not fuse_skip:
-            x_latent_proc = x_latent_proc + x_latent
+            if (x_latent_proc.is_cuda and x_latent_proc.dim() == 2 and x_latent_proc.shape == x_latent.shape and x_latent_proc.dtype == x_latent.dtype
+                    and not (torch.is_grad_enabled() and (x_latent_proc.requires_grad or x_latent.requires_grad))):
+                from ..layers.block import _identity_index  # inference (GNN processor): the add as one launch of this library, not a torch kernel
+
+                x_latent_proc = ops.gather_add_rows(x_latent_proc, x_latent, _identity_index(x_latent))
+            else:
+                x_latent_proc = x_latent_proc + x_latent
         out = {}
         for ds in names:
             ea, ei, es = self.decoder_graph_provider[ds].get_edges(batch_size=batch_size, model_comm_group=model_comm_group)

@@ -847,7 +847,7 @@ class _ClusterChainArgs(_lib.C.Structure):
     _p, _i64, _i32, _f = _lib.C.c_void_p, _lib.C.c_int64, _lib.C.c_int32, _lib.C.c_float
     _fields_ = [("attn", _p), ("ld_attn", _i64), ("x_res", _p), ("ld_x", _i64), ("wp", _p), ("w1", _p), ("hidden", _i32), ("w2", _p),
                 ("wq", _p), ("q_out_features", _i32), ("vec", _p), ("ln1_eps", _f), ("lnq_eps", _f), ("extra", _p), ("ld_extra", _i64),
-                ("x_out", _p), ("ld_out", _i64), ("q_out", _p), ("ld_q", _i64), ("ln_out", _p), ("ld_ln", _i64), ("workspace", _p),
+                ("x_out", _p), ("ld_out", _i64), ("q_out", _p), ("ld_q", _i64), ("ln_out", _p), ("ld_ln", _i64), ("q_out2", _p), ("ld_q2", _i64), ("q_split", _i32), ("workspace", _p),
                 ("workspace_bytes", _i64), ("n_rows", _i32), ("channels", _i32)]
 
 
@@ -877,12 +877,13 @@ def gt_cluster_chain_supported(x: Tensor, hidden: int, q_out: int = 0) -> bool:
 
 def gt_cluster_chain(attn: Tensor, x_res: Tensor, wp: Tensor, w1g: Tensor, w2: Tensor, vec: Tensor, hidden: int, ln1_eps: float, *,
                      extra: Optional[Tensor] = None, wqg: Optional[Tensor] = None, q_out_features: int = 0, lnq_eps: float = 1e-5,
-                     ln_out: Optional[Tensor] = None):
+                     ln_out: Optional[Tensor] = None, q_out2: Optional[Tensor] = None, q_split: int = 0):
     """``gt_layer_chain2`` for block tails of a few thousand rows (anemoi_gt_cluster_chain_fwd, csrc/gt_cluster_chain.hip): four CUs of one
     XCD share a 48-row panel as a tensor-parallel group over the MLP's hidden width and exchange the second Linear's partial sums once.
-    Same operands (``hidden`` must be 2048); ``ln_out`` (optional, [N, 512]): receives LN'(x2) WITHOUT its affine part.  Returns ``x_out``
-    or ``(x_out, q_out)``.  Inference only (no autograd)."""
-    _dev(attn, x_res, wp, w1g, w2, vec, extra, wqg, ln_out)
+    Same operands (``hidden`` must be 2048); ``ln_out`` (optional, [N, 512]): receives LN'(x2) WITHOUT its affine part; ``q_out2`` (optional,
+    [N, q_out_features - 512 q_split], a view with any row stride): receives the trailing projection's chunks from ``q_split`` on (the returned
+    ``q_out`` then holds the first ``512 q_split`` columns).  Returns ``x_out`` or ``(x_out, q_out)``.  Inference only (no autograd)."""
+    _dev(attn, x_res, wp, w1g, w2, vec, extra, wqg, ln_out, q_out2)
     N, D = attn.shape
     dt = attn.dtype
     if not gt_cluster_chain_supported(attn, hidden, q_out_features):
@@ -900,13 +901,17 @@ def gt_cluster_chain(attn: Tensor, x_res: Tensor, wp: Tensor, w1g: Tensor, w2: T
         raise ValueError(f"gt_cluster_chain: vec must be contiguous [{2 * D + hidden + q_out_features}] {dt} = cat[bp, d1, b2, dq]")
     ws = _cluster_workspace(attn.device)
     x_out = torch.empty((N, D), dtype=dt, device=attn.device)
-    q_out = torch.empty((N, q_out_features), dtype=dt, device=attn.device) if q_out_features else None
-    (ap, lda), (xp, ldx), (ep, lde), (lp, ldl) = _rows(attn, "attn", dt), _rows(x_res, "x_res", dt), _rows(extra, "extra", dt), _rows(ln_out, "ln_out", dt)
+    q_cols = q_out_features if q_out2 is None else D * q_split
+    if q_out2 is not None and (q_split < 0 or D * q_split > q_out_features or tuple(q_out2.shape) != (N, q_out_features - D * q_split)):
+        raise ValueError(f"gt_cluster_chain: q_out2 must be [N, {q_out_features} - 512 q_split] with 0 <= 512 q_split <= q_out_features")
+    q_out = torch.empty((N, q_cols), dtype=dt, device=attn.device) if q_cols else None
+    (ap, lda), (xp, ldx), (ep, lde), (lp, ldl), (q2p, ldq2) = (_rows(attn, "attn", dt), _rows(x_res, "x_res", dt), _rows(extra, "extra", dt),
+                                                              _rows(ln_out, "ln_out", dt), _rows(q_out2, "q_out2", dt))
     a = _ClusterChainArgs(ap, lda, xp, ldx, wp.data_ptr(), w1g.data_ptr(), hidden, w2.data_ptr(), 0 if wqg is None else wqg.data_ptr(), q_out_features,
                           vec.data_ptr(), float(ln1_eps), float(lnq_eps), ep, lde, x_out.data_ptr(), D, 0 if q_out is None else q_out.data_ptr(),
-                          q_out_features, lp, ldl, ws.data_ptr(), ws.numel() * 4, N, D)
+                          max(q_cols, 8), lp, ldl, q2p, ldq2, int(q_split), ws.data_ptr(), ws.numel() * 4, N, D)
     _lib.check(_lib.load().anemoi_gt_cluster_chain_fwd(_lib.C.byref(a), _dt(attn), _stream()), "gt_cluster_chain_fwd")
-    return x_out if q_out is None else (x_out, q_out)
+    return x_out if (q_out is None and q_out2 is None) else (x_out, q_out)
 
 
 class _RowChainArgs(_lib.C.Structure):

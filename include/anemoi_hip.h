@@ -386,7 +386,7 @@ int anemoi_peer_exchange_rows(const void* src, int64_t ld_src_bytes, const int32
  * in the model dtype, kept in LDS (2*512 + hidden + q_out_features <= 6144, else ANEMOI_E_UNSUPPORTED).  extra and a trailing
  * projection exclude each other (the reference adds the latent skip behind the LAST block).  channels must be 512; hidden and
  * q_out_features multiples of 512; 16-bit dtypes; all row pointers 16-byte aligned, all leading dimensions multiples of 8 elements.
- * The projection is computed by all eight waves (64 columns each), then the groups split.  rows_per_tile = 0 lets the
+ * rows_per_tile = 0 lets the
  * library choose (anemoi_gt_chain_rows_per_tile: 48). */
 typedef struct anemoi_gt_chain2_args {
   const void* attn;   int64_t ld_attn;    /* [n_rows, channels]   attention output + self term */
@@ -457,6 +457,10 @@ typedef struct anemoi_gt_cluster_chain_args {
   void* x_out;        int64_t ld_out;     /* [n_rows, channels] */
   void* q_out;        int64_t ld_q;       /* [n_rows, q_out_features] */
   void* ln_out;       int64_t ld_ln;      /* optional [n_rows, channels] */
+  void* q_out2;       int64_t ld_q2;      int32_t q_split;  /* optional second destination of the trailing projection: its 512-column chunks
+                                             q_split, q_split + 1, ... go to q_out2 [n_rows, q_out_features - 512 q_split] instead of q_out (a
+                                             sharded block: q | self for its own rows, k | v into the head of the buffer its halo rows arrive in);
+                                             q_out2 = NULL: everything to q_out */
   void* workspace;    int64_t workspace_bytes;
   int32_t n_rows;     int32_t channels;
 } anemoi_gt_cluster_chain_args_t;

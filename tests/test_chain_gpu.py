@@ -504,7 +504,7 @@ def test_mapper_with_row_chain_equals_mapper_without():
 
 
 # ------------------------------------------------------------------------------------------ cluster chain (round 6, csrc/gt_cluster_chain.hip)
-def _run_cluster(ops, attn, x, p, extra=None, ln_out=None):
+def _run_cluster(ops, attn, x, p, extra=None, ln_out=None, **kw):
     """the caller's side of anemoi_gt_cluster_chain_fwd: the operands of the layer chain (hidden = 2048)"""
     d = lambda t: None if t is None else t.to(DEV)  # noqa: E731
     dt = attn.dtype
@@ -517,7 +517,7 @@ def _run_cluster(ops, attn, x, p, extra=None, ln_out=None):
         parts.append(dq)
     vec = torch.cat(parts).to(dt).contiguous()
     return ops.gt_cluster_chain(d(attn), d(x), ops.pack_weight_frag(d(p["wp"])), ops.pack_weight_frag(w1g), ops.pack_weight_frag(d(p["w2"])), vec,
-                                p["w1"].shape[0], 1e-5, extra=d(extra), wqg=wqg, q_out_features=qf, lnq_eps=1e-5, ln_out=ln_out)
+                                p["w1"].shape[0], 1e-5, extra=d(extra), wqg=wqg, q_out_features=qf, lnq_eps=1e-5, ln_out=ln_out, **kw)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -570,6 +570,25 @@ def test_cluster_chain_variants(variant):
     if ln_out is not None:
         want = F.layer_norm(ref2, (D,), None, None, 1e-5)
         _close(ln_out, want, variant + " ln_out")
+
+
+@pytest.mark.parametrize("q_split", [0, 1, 2, 4])
+def test_cluster_chain_second_projection_destination(q_split):
+    """the trailing projection's chunks from q_split on land in the head of a wider / taller buffer (a sharded block: k | v of the local rows in
+    front of the halo rows): both destinations equal the one-destination launch, rows beyond the head untouched"""
+    from anemoi_core_amd import ops
+
+    dtype, N = torch.bfloat16, 1281
+    gen = torch.Generator().manual_seed(9)
+    p = _params(gen, dtype)
+    attn, x = torch.randn(N, D, generator=gen).to(dtype), torch.randn(N, D, generator=gen).to(dtype)
+    x2, q = _run_cluster(ops, attn, x, p)
+    w2 = 2048 - 512 * q_split
+    big = torch.full((N + 200, w2), 7.0, dtype=dtype, device=DEV)
+    y2, q1 = _run_cluster(ops, attn, x, p, q_out2=big[:N], q_split=q_split)
+    assert torch.equal(x2, y2)
+    assert (q1 is None) == (q_split == 0) and (q1 is None or torch.equal(q1, q[:, :512 * q_split]))
+    assert torch.equal(big[:N], q[:, 512 * q_split:]) and bool((big[N:] == 7.0).all())
 
 
 def test_cluster_chain_in_a_hipgraph():
