@@ -52,6 +52,8 @@ struct Chain2Args {
   const char* w1;    int hc;                // MLP-1 with LN_mlp's gamma folded in, [hidden, 512] fragment-major, hidden = 512 hc
   const char* w2;                           // MLP-2 [512, hidden] fragment-major
   const char* wq;    int qc;                // trailing projection with LN_attn' gamma folded in, [512 qc, 512] fragment-major; qc = 0: none
+  int qn;                                   // NARROW trailing projection (qc == 1): only its first 128 qn columns exist (waves 0 .. qn-1 of group A); 0: all 512
+  int q_cols;                               // columns of the trailing projection = entries of dq in vec
   const void* vec;                          // [512 b_p | 512 hc d1 | 512 b_2 | 512 qc dq]
   float eps1, epsq;
   const void* extra; int64_t ld_extra;      // optional second residual of x2
@@ -94,12 +96,12 @@ __device__ __forceinline__ void stamp2(Ctx2& c, unsigned char* smem) {
 struct VecCopy {
   u32x4 v[2];
   __device__ __forceinline__ void request(const Chain2Args& a, int tid) {
-    const int n16 = (1024 + 512 * (a.hc + a.qc)) / 8;  // <= 768
+    const int n16 = (1024 + 512 * a.hc + a.q_cols) / 8;  // <= 768
 #pragma unroll
     for (int k = 0; k < 2; ++k) v[k] = reinterpret_cast<const u32x4*>(a.vec)[min(tid + 512 * k, n16 - 1)];
   }
   __device__ __forceinline__ void store(const Chain2Args& a, int tid, unsigned char* smem) {
-    const int n16 = (1024 + 512 * (a.hc + a.qc)) / 8;
+    const int n16 = (1024 + 512 * a.hc + a.q_cols) / 8;
 #pragma unroll
     for (int k = 0; k < 2; ++k)
       if (tid + 512 * k < n16) reinterpret_cast<u32x4*>(smem + kVecOff)[tid + 512 * k] = v[k];
@@ -137,7 +139,8 @@ __device__ __forceinline__ void role_a(const Chain2Args& a, Ctx2& c, unsigned ch
   f32x4 acc[3][8];
   // the L2 warm-up: waves 0, 1 touch the CU's share of group A's next segment, waves 2, 3 of group B's (64 lines each)
   const int64_t sw2 = (int64_t)hc * kSlab;
-  auto seg_a = [&](int t) { return t < hc ? a.w1 + (int64_t)(8 * t) * kSlab : (qc > 0 ? a.wq : a.wp); };  // M1(t); behind the last chunk: Q0 / the next panel's P
+  const bool narrow_idle = a.qn > 0 && wq >= a.qn;  // a narrow trailing projection leaves this wave without a chunk
+  auto seg_a = [&](int t) { return t < hc ? a.w1 + (int64_t)(8 * t) * kSlab : ((qc > 0 && a.qn == 0) ? a.wq : a.wp); };  // M1(t); behind the last chunk: Q0 / the next panel's P (a narrow Q is not a whole segment: not touched)
   Warm warm;
   warm_init<PART>(warm, wq & 1, lane);
   auto touch = [&](const char* sa, const char* sb, int64_t pb) {
@@ -187,7 +190,7 @@ __device__ __forceinline__ void role_a(const Chain2Args& a, Ctx2& c, unsigned ch
     for (int t = 0; t < hc; ++t) {
       stamp2<TL>(c, smem);
       init_acc<T, false>(acc, vec, 512 + 512 * t, nullptr, lane, wq);
-      const char* nxt = t + 1 < hc ? w1c(t + 1) : (qc > 0 ? wqc(0) : wpw);
+      const char* nxt = t + 1 < hc ? w1c(t + 1) : ((qc > 0 && !narrow_idle) ? wqc(0) : wpw);
       if (kExperiments && a.prio_a == 1) __builtin_amdgcn_s_setprio(2);
       gemm128<T>(bufB, lane, ring, w1c(t), s1, nxt, s1, c.loff, acc);
       if (kExperiments && a.prio_a == 1) __builtin_amdgcn_s_setprio(0);
@@ -217,7 +220,7 @@ __device__ __forceinline__ void role_a(const Chain2Args& a, Ctx2& c, unsigned ch
       for (int i = 0; i < 12; ++i) {
         const int row = w0 * 12 + i;
         u32x4 v = *reinterpret_cast<const u32x4*>(xb + row * kRowBytes + ((l0 ^ (row & 15)) << 4));
-        if (row < nr) {
+        if (row < nr && a.xout != nullptr) {
           if (a.extra != nullptr) {
             // the latent skip rides on the last block's output, added to the block's ROUNDED output as `x + skip` does
             const u32x4 e = *reinterpret_cast<const u32x4*>((const T*)a.extra + (int64_t)(r0 + row) * a.ld_extra + l0 * 8);
@@ -242,6 +245,7 @@ __device__ __forceinline__ void role_a(const Chain2Args& a, Ctx2& c, unsigned ch
     lds_barrier();
     // the even chunks of the trailing projection, staged (rounded) in x2's buffer
     for (int k = 0; k < qc; k += 2) {
+      if (narrow_idle) break;  // (a narrow projection: this wave's columns do not exist)
       stamp2<TL>(c, smem);
       init_acc<T, false>(acc, vec, 1024 + 512 * hc + 512 * k, nullptr, lane, wq);
       set_chunk_prio(kExperiments && a.prio_q, k);
@@ -433,18 +437,19 @@ extern "C" int anemoi_gt_chain2_fwd(const anemoi_gt_chain2_args_t* p, anemoi_dty
   ANEMOI_REQUIRE(dtype == ANEMOI_BF16 || dtype == ANEMOI_F16, "gt_chain2_fwd: 16-bit model dtypes only");
   ANEMOI_REQUIRE(p->n_rows >= 0 && p->channels == kCh, "gt_chain2_fwd: channels=%d (this kernel is built for %d)", p->channels, kCh);
   if (p->n_rows == 0) return ANEMOI_OK;
-  ANEMOI_REQUIRE(p->hidden > 0 && p->hidden % kCh == 0 && p->q_out_features >= 0 && p->q_out_features % kCh == 0,
-                 "gt_chain2_fwd: hidden=%d and q_out_features=%d must be multiples of %d", p->hidden, p->q_out_features, kCh);
+  const bool narrow = p->q_out_features > 0 && p->q_out_features < kCh;  // a narrow trailing projection: 128, 256 or 384 columns
+  ANEMOI_REQUIRE(p->hidden > 0 && p->hidden % kCh == 0 && p->q_out_features >= 0 && (narrow ? p->q_out_features % 128 == 0 : p->q_out_features % kCh == 0),
+                 "gt_chain2_fwd: hidden=%d must be a multiple of %d, q_out_features=%d a multiple of %d (or 128, 256, 384)", p->hidden, kCh, p->q_out_features, kCh);
   const int n_vec = 2 * kCh + p->hidden + p->q_out_features;
   if (n_vec > (p->timeline != nullptr ? kVecMaxElemsTl : kVecMaxElems)) return ANEMOI_E_UNSUPPORTED;  // the per-column vectors must fit their LDS region
-  ANEMOI_REQUIRE(p->attn && p->x_res && p->wp && p->w1 && p->w2 && p->vec && p->x_out, "gt_chain2_fwd: null operand");
+  ANEMOI_REQUIRE(p->attn && p->x_res && p->wp && p->w1 && p->w2 && p->vec && (p->x_out || p->q_out_features > 0), "gt_chain2_fwd: null operand");
   ANEMOI_REQUIRE(p->q_out_features == 0 || (p->wq && p->q_out), "gt_chain2_fwd: the trailing projection needs wq and q_out");
   ANEMOI_REQUIRE(p->q_out_features == 0 || p->extra == nullptr, "gt_chain2_fwd: the trailing projection reads x2 before a second residual is added: not both");
   const auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   ANEMOI_REQUIRE(al16(p->attn) && al16(p->x_res) && al16(p->wp) && al16(p->w1) && al16(p->w2) && al16(p->x_out) && al16(p->wq) && al16(p->q_out) &&
                      al16(p->extra) && al16(p->vec),
                  "gt_chain2_fwd: operands must be 16-byte aligned");
-  ANEMOI_REQUIRE(p->ld_attn >= kCh && p->ld_x >= kCh && p->ld_out >= kCh && p->ld_attn % 8 == 0 && p->ld_x % 8 == 0 && p->ld_out % 8 == 0 &&
+  ANEMOI_REQUIRE(p->ld_attn >= kCh && p->ld_x >= kCh && (p->x_out == nullptr || (p->ld_out >= kCh && p->ld_out % 8 == 0)) && p->ld_attn % 8 == 0 && p->ld_x % 8 == 0 &&
                      (p->extra == nullptr || (p->ld_extra >= kCh && p->ld_extra % 8 == 0)) &&
                      (p->q_out_features == 0 || (p->ld_q >= p->q_out_features && p->ld_q % 8 == 0)),
                  "gt_chain2_fwd: leading dimensions too small or not multiples of 8 elements (rows move as 16-byte pieces)");
@@ -454,7 +459,8 @@ extern "C" int anemoi_gt_chain2_fwd(const anemoi_gt_chain2_args_t* p, anemoi_dty
   a.wp = (const char*)p->wp;
   a.w1 = (const char*)p->w1; a.hc = p->hidden / kCh;
   a.w2 = (const char*)p->w2;
-  a.wq = (const char*)p->wq; a.qc = p->q_out_features / kCh;
+  a.wq = (const char*)p->wq; a.qc = narrow ? 1 : p->q_out_features / kCh;
+  a.qn = narrow ? p->q_out_features / 128 : 0; a.q_cols = p->q_out_features;
   a.vec = p->vec;
   a.eps1 = p->ln1_eps; a.epsq = p->lnq_eps;
   a.extra = p->extra; a.ld_extra = p->ld_extra;

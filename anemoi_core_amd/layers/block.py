@@ -394,6 +394,17 @@ class GraphTransformerBaseBlock(BaseBlock):
             if halo is not None and not (_CLUSTER_HALO and cluster and nb is not None and getattr(nb, "shard_strategy", None) == "edges"):
                 nb = None  # (a sharded block's k | v need the halo rows: only the cluster chain has the LayerNorm'd rows as an output)
             hidden = mlp.mlp[0].weight.shape[0]
+            # a decoder's node_data_extractor (LayerNorm + Linear(512, out), layers/mapper.py:688-704) as the chain launch's NARROW trailing
+            # projection: the 40 320-row output of the tail is then neither written nor read back, and two launches disappear
+            tail = None
+            if chain is not None and nb is None and extra is None and not cluster and chain.get("tail_proj") is not None:
+                ln_t, lin_t = chain["tail_proj"]
+                o_pad = (lin_t.out_features + 127) // 128 * 128
+                if (o_pad < ops.CHAIN_CHANNELS and lin_t.in_features == ops.CHAIN_CHANNELS and type(ln_t).__name__ in ("LayerNorm", "AutocastLayerNorm")
+                        and ln_t.weight is not None and ops.gt_layer_chain2_supported(attn_plus_self, hidden, o_pad)
+                        and all(q_ is None or q_.dtype == attn_plus_self.dtype for m_ in (ln_t, lin_t) for q_ in m_.parameters())
+                        and not (torch.is_grad_enabled() and any(q_.requires_grad for m_ in (ln_t, lin_t) for q_ in m_.parameters()))):
+                    tail = (ln_t, lin_t, o_pad)
             supported = ops.gt_cluster_chain_supported if cluster else ops.gt_layer_chain2_supported
             if nb is not None and not supported(attn_plus_self, hidden, 4 * nb.attn_channels):
                 nb = None  # the per-column vectors of tail + trailing projection do not fit the kernel's LDS region: the tail alone
@@ -405,6 +416,8 @@ class GraphTransformerBaseBlock(BaseBlock):
                 lnq = None if nb is None else nb.layer_norm_attention
                 params = [self.projection.weight, self.projection.bias, ln.weight, ln.bias, lin1.weight, lin1.bias, lin2.weight, lin2.bias]
                 params += [q for lin in qlins for q in (lin.weight, lin.bias)] + ([] if lnq is None else [lnq.weight, lnq.bias])
+                if tail is not None:
+                    params += [tail[0].weight, tail[0].bias, tail[1].weight, tail[1].bias]
 
                 def build():
                     w1g, d1 = ops.fold_layer_norm(lin1.weight, lin1.bias, ln.weight, ln.bias)
@@ -416,10 +429,24 @@ class GraphTransformerBaseBlock(BaseBlock):
                         wq, dq = ops.fold_layer_norm(wq, bq, lnq.weight, lnq.bias)
                         wqg = ops.pack_weight_frag(wq)
                         parts.append(dq)
+                    elif tail is not None:
+                        ln_t, lin_t, o_pad = tail
+                        pad = o_pad - lin_t.out_features
+                        wt = torch.nn.functional.pad(lin_t.weight, (0, 0, 0, pad))  # zero rows: the padded output columns are zeros
+                        bt = torch.nn.functional.pad(lin_t.bias if lin_t.bias is not None else lin_t.weight.new_zeros(lin_t.out_features), (0, pad))
+                        wt, dq = ops.fold_layer_norm(wt, bt, ln_t.weight, ln_t.bias)
+                        wqg = ops.pack_weight_frag(wt)
+                        parts.append(dq)
                     return (ops.pack_weight_frag(self.projection.weight), ops.pack_weight_frag(w1g), ops.pack_weight_frag(lin2.weight),
                             torch.cat(parts).to(lin1.weight.dtype).contiguous(), wqg)
 
-                wp, w1g, w2, vec, wqg = self._fused.derived("chain2" if nb is None else f"chain2:{id(nb)}:{len(qlins)}", params, build)
+                wp, w1g, w2, vec, wqg = self._fused.derived(("chain2:tail" if tail is not None else "chain2") if nb is None else f"chain2:{id(nb)}:{len(qlins)}",
+                                                            params, build)
+                if tail is not None:
+                    _, q_t = ops.gt_layer_chain2(attn_plus_self, x_skip, wp, w1g, w2, vec, hidden, ln.eps, wqg=wqg, q_out_features=tail[2],
+                                                 lnq_eps=tail[0].eps, want_x_out=False)
+                    chain["tail_out"] = q_t[:, :tail[1].out_features]  # (a strided [N, out] view, as the mapper's own GEMM returns)
+                    return q_t
                 kw = {}
                 if halo is not None and nb is not None:
                     plan, group = halo

@@ -45,6 +45,9 @@ _ROW_CHAIN_MIN_ROWS = int(os.environ.get("ANEMOI_ROW_CHAIN_MIN_ROWS", "4096"))
 # (~21 us per round), the two GEMMs share each weight tile among 160 rows - between ~16 000 and ~260 000 rows the GEMM pair is as fast or
 # faster (40 320 rows: 84-86 against 75-83 us), below (one round: 10 242 rows 23 against 27 us, 5 040 rows 20 against 34) and far above
 # (542 080 rows 951 against 1 069 us: there the 555-MB round trip of the embedded rows dominates the GEMMs) the launch wins.
+# The decoder's node_data_extractor (LayerNorm + Linear(512, out)) as the narrow trailing projection of the block's chain launch (inference, block
+# tails on the row-resident chain): ANEMOI_TAIL_PROJ=0 keeps its LayerNorm launch + GEMM.
+_TAIL_PROJ = os.environ.get("ANEMOI_TAIL_PROJ", "1") != "0"
 _ROW_CHAIN_GEMM_BAND = tuple(int(v) for v in os.environ.get("ANEMOI_ROW_CHAIN_GEMM_BAND", "16384:262144").split(":"))
 
 
@@ -138,6 +141,10 @@ class GraphTransformerBaseMapper(BaseMapper):
         )
         self.emb_nodes_dst = self.layer_factory.Linear(self.in_channels_dst, self.hidden_dim)
         self._emb_src, self._emb_dst = PaddedLinear(), PaddedLinear()
+
+    def _tail_projection(self):
+        """(LayerNorm, Linear) of a post_process that is row-local and can ride at the end of the block's chain launch; None: there is none."""
+        return None
 
     def _row_chain_ok(self, x: Tensor, lin, ln, projs: list) -> bool:
         """The embedding -> LayerNorm -> projection chain launch (ops.gt_row_chain) takes this side: inference, 16-bit, 512 channels, a
@@ -233,9 +240,14 @@ class GraphTransformerBaseMapper(BaseMapper):
         # the k|v and q|self GEMMs (no LayerNorm launches on the 40 320-row side)
         ln_stats = {} if cond is None else None
         xs, xd = self.pre_process((x_src_c, x_dst), ln_stats=ln_stats)
+        tail = self._tail_projection() if (cond is None and "ln_chain" not in kwargs) else None
+        if tail is not None:  # the block's chain launch may run post_process as its trailing projection (layers/block.py)
+            kwargs["ln_chain"] = {"tail_proj": tail}
         (_, x_dst_out), _ = self.proc((xs, xd), g["edge_attr"], g["edge_index"], shard_info, batch_size,
                                       (xs.shape[0], xd.shape[0]), model_comm_group, edges_are_dst_sorted=True, ln_stats=ln_stats, **kwargs)
-        out_dst = self.post_process(x_dst_out)
+        out_dst = kwargs["ln_chain"].get("tail_out") if tail is not None else None
+        if out_dst is None:
+            out_dst = self.post_process(x_dst_out)
         if sharded and not keep_x_dst_sharded:
             out_dst = comm.gather_tensor(out_dst.contiguous(), 0, g["partition"].dst_splits, model_comm_group)
         return out_dst
@@ -319,6 +331,11 @@ class GraphTransformerBackwardMapper(GraphTransformerBaseMapper):
     def pre_process(self, x, ln_stats: Optional[dict] = None):
         x_src, x_dst = x
         return x_src, self._embed(self._emb_dst, x_dst, self.emb_nodes_dst, "dst", ln_stats)
+
+    def _tail_projection(self):
+        if not _TAIL_PROJ or torch.is_grad_enabled():
+            return None
+        return self.node_data_extractor[0], self.node_data_extractor[1]
 
     def post_process(self, x_dst):
         ln, lin = self.node_data_extractor[0], self.node_data_extractor[1]

@@ -801,20 +801,24 @@ def fold_layer_norm(weight: Tensor, bias: Optional[Tensor], gamma: Tensor, beta:
 
 
 def gt_layer_chain2_supported(x: Tensor, hidden: int, q_out: int = 0) -> bool:
-    return gt_layer_chain_supported(x, hidden, q_out) and 2 * CHAIN_CHANNELS + hidden + q_out <= CHAIN2_VEC_MAX
+    """``q_out``: a multiple of 512, or a NARROW trailing projection of 128, 256 or 384 columns (the decoder's node_data_extractor)."""
+    narrow = 0 < q_out < CHAIN_CHANNELS and q_out % 128 == 0
+    return gt_layer_chain_supported(x, hidden, 0 if narrow else q_out) and 2 * CHAIN_CHANNELS + hidden + q_out <= CHAIN2_VEC_MAX
 
 
 def gt_layer_chain2(attn: Tensor, x_res: Tensor, wp: Tensor, w1g: Tensor, w2: Tensor, vec: Tensor, hidden: int, ln1_eps: float, *,
                     extra: Optional[Tensor] = None, wqg: Optional[Tensor] = None, q_out_features: int = 0, lnq_eps: float = 1e-5,
-                    rows_per_tile: int = 0, timeline: Optional[Tensor] = None):
+                    rows_per_tile: int = 0, timeline: Optional[Tensor] = None, want_x_out: bool = True):
     """The row-local part of a GraphTransformer block in ONE launch with role-split waves (anemoi_gt_chain2_fwd, csrc/gt_chain2.hip):
 
         x1 = attn Wp^T + bp + x_res;  h = GELU(LN(x1; ln1) W1^T + b1);  x_out = h W2^T + b2 + x1 [+ extra]
         q_out = LN(x_out; lnq) Wq^T + bq        (optional: the NEXT block's LayerNorm + fused q|k|v|self projection)
 
     with the LayerNorms' affine parts folded by the caller (``fold_layer_norm``): ``w1g`` / ``wqg`` are the fragment-major images of
-    ``W diag(gamma)``, ``vec = cat[bp, d1, b2, dq]`` in the model dtype with ``d = W beta + b``.  Returns ``x_out`` or
-    ``(x_out, q_out)``.  Inference only (no autograd)."""
+    ``W diag(gamma)``, ``vec = cat[bp, d1, b2, dq]`` in the model dtype with ``d = W beta + b``.  ``q_out_features`` may also be 128, 256 or
+    384 (a narrow trailing projection, e.g. the decoder's ``node_data_extractor`` zero-padded to a multiple of 128 rows); with
+    ``want_x_out=False`` (needs a trailing projection) x_out is not written and returned as None.  Returns ``x_out`` or ``(x_out, q_out)``.
+    Inference only (no autograd)."""
     _dev(attn, x_res, wp, w1g, w2, vec, extra, wqg)
     N, D = attn.shape
     dt = attn.dtype
@@ -833,11 +837,13 @@ def gt_layer_chain2(attn: Tensor, x_res: Tensor, wp: Tensor, w1g: Tensor, w2: Te
             raise ValueError(f"gt_layer_chain2: {name} must be the contiguous fragment-major image ({numel} x {dt}) made by pack_weight_frag")
     if vec.dim() != 1 or vec.numel() != 2 * D + hidden + q_out_features or vec.dtype != dt or not vec.is_contiguous():
         raise ValueError(f"gt_layer_chain2: vec must be contiguous [{2 * D + hidden + q_out_features}] {dt} = cat[bp, d1, b2, dq]")
-    x_out = torch.empty((N, D), dtype=dt, device=attn.device)
+    if not want_x_out and not q_out_features:
+        raise ValueError("gt_layer_chain2: want_x_out=False needs a trailing projection")
+    x_out = torch.empty((N, D), dtype=dt, device=attn.device) if want_x_out else None
     q_out = torch.empty((N, q_out_features), dtype=dt, device=attn.device) if q_out_features else None
     (ap, lda), (xp, ldx), (ep, lde) = _rows(attn, "attn", dt), _rows(x_res, "x_res", dt), _rows(extra, "extra", dt)
     a = _Chain2Args(ap, lda, xp, ldx, wp.data_ptr(), w1g.data_ptr(), hidden, w2.data_ptr(), 0 if wqg is None else wqg.data_ptr(), q_out_features,
-                    vec.data_ptr(), float(ln1_eps), float(lnq_eps), ep, lde, x_out.data_ptr(), D, 0 if q_out is None else q_out.data_ptr(),
+                    vec.data_ptr(), float(ln1_eps), float(lnq_eps), ep, lde, 0 if x_out is None else x_out.data_ptr(), D, 0 if q_out is None else q_out.data_ptr(),
                     q_out_features, N, D, int(rows_per_tile), 0 if timeline is None else timeline.data_ptr())
     _lib.check(_lib.load().anemoi_gt_chain2_fwd(_lib.C.byref(a), _dt(attn), _stream()), "gt_chain2_fwd")
     return x_out if q_out is None else (x_out, q_out)

@@ -352,7 +352,7 @@ def test_gnn_model_with_chains_equals_model_without():
 
 
 # ------------------------------------------------------------------------------------------ the layer chain (csrc/gt_chain2.hip)
-def _run_chain2(ops, attn, x, p, extra=None, rows_per_tile=0):
+def _run_chain2(ops, attn, x, p, extra=None, rows_per_tile=0, **kw):
     """the caller's side of anemoi_gt_chain2_fwd: the LayerNorms' affine parts folded into the Linears that follow them"""
     d = lambda t: None if t is None else t.to(DEV)  # noqa: E731
     dt = attn.dtype
@@ -365,7 +365,7 @@ def _run_chain2(ops, attn, x, p, extra=None, rows_per_tile=0):
         parts.append(dq)
     vec = torch.cat(parts).to(dt).contiguous()
     return ops.gt_layer_chain2(d(attn), d(x), ops.pack_weight_frag(d(p["wp"])), ops.pack_weight_frag(w1g), ops.pack_weight_frag(d(p["w2"])), vec,
-                               p["w1"].shape[0], 1e-5, extra=d(extra), wqg=wqg, q_out_features=qf, lnq_eps=1e-5, rows_per_tile=rows_per_tile)
+                               p["w1"].shape[0], 1e-5, extra=d(extra), wqg=wqg, q_out_features=qf, lnq_eps=1e-5, rows_per_tile=rows_per_tile, **kw)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -415,6 +415,27 @@ def test_chain2_variants(variant):
     else:
         _close(res[0], ref2, variant)
         _close(res[1], refq, variant + " q")
+
+
+@pytest.mark.parametrize("N,q_out,want_x", [(3000, 128, True), (40320, 128, False), (10242, 256, False), (5000, 384, True), (50001, 128, False)])
+def test_chain2_narrow_trailing_projection(N, q_out, want_x):
+    """a NARROW trailing projection (the decoder's node_data_extractor: LayerNorm + Linear(512, 84) zero-padded to 128 columns): only the first
+    q_out / 128 waves of group A have a chunk, x2 is optionally not written at all; one round and several rounds of panels"""
+    from anemoi_core_amd import ops
+
+    dtype = torch.bfloat16
+    gen = torch.Generator().manual_seed(N + q_out)
+    p = _params(gen, dtype, q_out=q_out)
+    attn = torch.randn(N, D, generator=gen).to(dtype)
+    x = torch.randn(N, D, generator=gen).to(dtype)
+    x2, q = _run_chain2(ops, attn, x, p, want_x_out=want_x)
+    ref2, refq = _reference(attn, x, p, dtype)
+    assert (x2 is not None) == want_x and tuple(q.shape) == (N, q_out)
+    if want_x:
+        _close(x2, ref2, f"x2 N={N}")
+    _close(q, refq, f"narrow q N={N} q_out={q_out}")
+    x2b, qb = _run_chain2(ops, attn, x, p, want_x_out=want_x)
+    assert torch.equal(q, qb)
 
 
 @pytest.mark.parametrize("N,hidden,with_extra", [(30000, 2048, False), (50001, 2048, True), (30000, 1024, False), (30000, 1536, False)])
@@ -473,6 +494,34 @@ def test_row_chain_vs_fp32_restatement(dtype, N, K, q_out, want_x):
     _close(q, q_ref, f"q N={N} K={K}", tol=2.5e-2)
     y2, q2 = ops.gt_row_chain(*args, want_x_out=want_x)
     assert torch.equal(q, q2) and (not want_x or torch.equal(y, y2))  # deterministic
+
+
+def test_decoder_with_tail_projection_equals_decoder_without():
+    """node_data_extractor as the narrow trailing projection of the decoder's chain launch against its LayerNorm launch + GEMM (same model, same input)"""
+    import anemoi_core_amd.layers.block as B
+    import anemoi_core_amd.layers.mapper as M
+    from anemoi_core_amd.graphs.synthetic import build_synthetic_graph
+    from anemoi_core_amd.models import AnemoiModelEncProcDec
+    from anemoi_core_amd.models.configs import make_data_indices, model_config
+
+    g = build_synthetic_graph("o32", 4)
+    torch.manual_seed(0)
+    model = AnemoiModelEncProcDec(model_config=model_config("gt", 512, 2, 16, 8), data_indices=make_data_indices(6, 6),
+                                  statistics={"data": None}, n_step_input=2, n_step_output=1, graph_data=g).eval().to(DEV).to(torch.bfloat16)
+    xb = torch.randn(1, 2, 1, g.num_data, 6).to(DEV).to(torch.bfloat16)
+    outs = {}
+    saved = (M._TAIL_PROJ, B._LAYER_CHAIN_MIN_ROWS)
+    for flag in (True, False):
+        M._TAIL_PROJ, B._LAYER_CHAIN_MIN_ROWS = flag, 0  # (every block tail on the row-resident chain: the tail projection rides on it)
+        try:
+            with torch.no_grad():
+                outs[flag] = model({"data": xb})["data"].float().cpu()
+        finally:
+            M._TAIL_PROJ, B._LAYER_CHAIN_MIN_ROWS = saved
+    a, b = outs[True], outs[False]
+    scale = float(b.abs().max())
+    assert not torch.equal(a, b)  # two different paths really ran
+    assert float((a - b).abs().max()) <= 3e-2 * scale and float((a - b).abs().mean()) <= 4e-3 * scale, (float((a - b).abs().max()), scale)
 
 
 def test_mapper_with_row_chain_equals_mapper_without():
