@@ -236,12 +236,18 @@ __device__ __forceinline__ void role_a(const Chain2Args& a, Ctx2& c, unsigned ch
             for (int r = 0; r < 4; ++r) p[r] += s[r];
             const u32x2 hi = pack4<T>(p);
             v = u32x4{lo[0], lo[1], hi[0], hi[1]};
+            // (a trailing projection behind the latent skip - the decoder's k | v - reads LayerNorm(x2 + skip): the sum goes back into the panel)
+            if (qc > 0) *reinterpret_cast<u32x4*>(hbuf(hc) + row * kRowBytes + ((l0 ^ (row & 15)) << 4)) = v;
           }
           stream_store(v, reinterpret_cast<u32x4*>((T*)a.xout + (int64_t)(r0 + row) * a.ld_out + l0 * 8));
         }
       }
     }
     stamp2<TL>(c, smem);
+    if (qc > 0 && a.extra != nullptr) {  // group B re-reads x2 + skip and takes its statistics: two barriers more, both roles
+      lds_barrier();
+      lds_barrier();
+    }
     lds_barrier();
     // the even chunks of the trailing projection, staged (rounded) in x2's buffer
     for (int k = 0; k < qc; k += 2) {
@@ -327,10 +333,28 @@ __device__ __forceinline__ void role_b(const Chain2Args& a, Ctx2& c, unsigned ch
       gemm128<T>(hbuf(t - 1), lane, ring, w2c(t - 1), s2, nxt, ns, c.loff, acc);
       stamp2<TL>(c, smem);
       if (t == hc) {  // x2 (rounded) -> the h buffer nobody reads any more, for group A to store
-        if (qc > 0) round_rows<T, true>(acc, hbuf(hc), red, lane, wq);
+        if (qc > 0 && a.extra == nullptr) round_rows<T, true>(acc, hbuf(hc), red, lane, wq);
         else round_rows<T, false>(acc, hbuf(hc), nullptr, lane, wq);
         stamp2<TL>(c, smem);
       }
+      lds_barrier();
+    }
+    if (qc > 0 && a.extra != nullptr) {
+      // the latent skip AND a trailing projection: group A adds the skip to the rounded rows (whole rows, as it stores them) and writes the sums back;
+      // this group reads them in its accumulator layout and takes the statistics of x2 + skip
+      lds_barrier();
+      {
+        const Lane2 lc = lane2(lane, wq);
+#pragma unroll
+        for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 8; ++ni) {
+            float o[4];
+            unpack4<T>(*reinterpret_cast<const u32x2*>(hbuf(hc) + (mi * 16 + lc.x) * kRowBytes + lc.coff[ni]), o);
+            acc[mi][ni] = f32x4{o[0], o[1], o[2], o[3]};
+          }
+      }
+      round_rows<T, true>(acc, hbuf(hc), red, lane, wq);  // (the values are rounded already: this rewrites them unchanged and leaves the per-wave statistics)
       lds_barrier();
     }
     // S8: LayerNorm_attn'(x2) without its affine part -> bufB
@@ -444,7 +468,7 @@ extern "C" int anemoi_gt_chain2_fwd(const anemoi_gt_chain2_args_t* p, anemoi_dty
   if (n_vec > (p->timeline != nullptr ? kVecMaxElemsTl : kVecMaxElems)) return ANEMOI_E_UNSUPPORTED;  // the per-column vectors must fit their LDS region
   ANEMOI_REQUIRE(p->attn && p->x_res && p->wp && p->w1 && p->w2 && p->vec && (p->x_out || p->q_out_features > 0), "gt_chain2_fwd: null operand");
   ANEMOI_REQUIRE(p->q_out_features == 0 || (p->wq && p->q_out), "gt_chain2_fwd: the trailing projection needs wq and q_out");
-  ANEMOI_REQUIRE(p->q_out_features == 0 || p->extra == nullptr, "gt_chain2_fwd: the trailing projection reads x2 before a second residual is added: not both");
+  ANEMOI_REQUIRE(p->extra == nullptr || p->x_out != nullptr, "gt_chain2_fwd: a second residual needs x_out");
   const auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   ANEMOI_REQUIRE(al16(p->attn) && al16(p->x_res) && al16(p->wp) && al16(p->w1) && al16(p->w2) && al16(p->x_out) && al16(p->wq) && al16(p->q_out) &&
                      al16(p->extra) && al16(p->vec),

@@ -372,6 +372,17 @@ class GraphTransformerBaseBlock(BaseBlock):
                 and not (torch.is_grad_enabled() and any(p.requires_grad for m in (ln, self.lin_query, self.lin_key, self.lin_value, self.lin_self)
                                                          for p in m.parameters())))
 
+    def _kv_chain_ok(self, x: Tensor) -> bool:
+        """(mapper blocks) layer_norm_attention_src + fused [k|v] projection of the SOURCE rows can ride at the end of the chain launch that produces
+        those rows - the last processor block's, behind the latent skip."""
+        ln = getattr(self, "layer_norm_attention_src", None)
+        A = self.attn_channels
+        mods = (ln, self.lin_key, self.lin_value)
+        return (ln is not None and type(ln).__name__ in ("LayerNorm", "AutocastLayerNorm") and ln.weight is not None and not self.qk_norm
+                and x.shape[1] == ops.CHAIN_CHANNELS and (2 * A) % ops.CHAIN_CHANNELS == 0 and self.lin_key.weight.shape[1] == ops.CHAIN_CHANNELS
+                and all(p is None or p.dtype == x.dtype for m in mods for p in m.parameters())
+                and not (torch.is_grad_enabled() and any(p.requires_grad for m in mods for p in m.parameters())))
+
     def _post_attention(self, attn_plus_self: Tensor, x_skip: Tensor, cond: Optional[Tensor] = None, chain: Optional[dict] = None,
                         extra: Optional[Tensor] = None, next_block=None, halo=None) -> Tensor:
         """projection + residual, LayerNorm, MLP + residual.  Inference: the projection GEMM also emits the row statistics of
@@ -390,7 +401,15 @@ class GraphTransformerBaseBlock(BaseBlock):
         cluster = cond is None and self._chain_ok(ln, attn_plus_self, cluster=True)
         if (cond is None and (cluster or self._chain_ok(ln, attn_plus_self)) and attn_plus_self.shape == x_skip.shape
                 and (extra is None or extra.shape == x_skip.shape)):
-            nb = next_block if (next_block is not None and chain is not None and extra is None and next_block._qkvs_chain_ok(x_skip)) else None
+            # the NEXT consumer of this tail's output whose LayerNorm + projection ride at the end of the launch: the next processor block
+            # (q|k|v|self), or - behind the LAST processor block and the latent skip - the decoder's block (k|v of its source rows)
+            to_mapper = isinstance(next_block, GraphTransformerMapperBlock)
+            nb = None
+            if next_block is not None and chain is not None:
+                if to_mapper:
+                    nb = next_block if (not cluster and halo is None and next_block._kv_chain_ok(x_skip)) else None
+                elif extra is None and next_block._qkvs_chain_ok(x_skip):
+                    nb = next_block
             if halo is not None and not (_CLUSTER_HALO and cluster and nb is not None and getattr(nb, "shard_strategy", None) == "edges"):
                 nb = None  # (a sharded block's k | v need the halo rows: only the cluster chain has the LayerNorm'd rows as an output)
             hidden = mlp.mlp[0].weight.shape[0]
@@ -410,10 +429,11 @@ class GraphTransformerBaseBlock(BaseBlock):
                 nb = None  # the per-column vectors of tail + trailing projection do not fit the kernel's LDS region: the tail alone
             if supported(attn_plus_self, hidden, 0 if nb is None else 4 * nb.attn_channels):
                 lin1, lin2 = mlp.mlp[0], mlp.mlp[2]
-                qlins = [] if nb is None else ([nb.lin_query, nb.lin_self, nb.lin_key, nb.lin_value] if halo is not None else
+                qlins = [] if nb is None else ([nb.lin_key, nb.lin_value] if to_mapper else
+                                              [nb.lin_query, nb.lin_self, nb.lin_key, nb.lin_value] if halo is not None else
                                               [nb.lin_query, nb.lin_key, nb.lin_value, nb.lin_self])
                 q_out = sum(lin.out_features for lin in qlins)
-                lnq = None if nb is None else nb.layer_norm_attention
+                lnq = None if nb is None else (nb.layer_norm_attention_src if to_mapper else nb.layer_norm_attention)
                 params = [self.projection.weight, self.projection.bias, ln.weight, ln.bias, lin1.weight, lin1.bias, lin2.weight, lin2.bias]
                 params += [q for lin in qlins for q in (lin.weight, lin.bias)] + ([] if lnq is None else [lnq.weight, lnq.bias])
                 if tail is not None:

@@ -239,7 +239,10 @@ class GraphTransformerBaseMapper(BaseMapper):
         # inference: the embeddings also emit the row statistics of their outputs, and the block folds LayerNorm_src / _dst into
         # the k|v and q|self GEMMs (no LayerNorm launches on the 40 320-row side)
         ln_stats = {} if cond is None else None
+        src_proj = kwargs.pop("src_proj", None)  # model glue: (source rows, their k|v projection) computed by the launch that produced the rows
         xs, xd = self.pre_process((x_src_c, x_dst), ln_stats=ln_stats)
+        if src_proj is not None and ln_stats is not None and src_proj[0] is x_src and xs is x_src:
+            ln_stats["proj:src"] = src_proj[1]
         tail = self._tail_projection() if (cond is None and "ln_chain" not in kwargs) else None
         if tail is not None:  # the block's chain launch may run post_process as its trailing projection (layers/block.py)
             kwargs["ln_chain"] = {"tail_proj": tail}

@@ -40,10 +40,11 @@ class BaseProcessor(nn.Module):
         chain = kwargs.get("ln_chain")
         if chain is None:
             chain = kwargs.get("gnn_chain")
+        after_last = kwargs.pop("after_last_block", None)  # model glue: the decoder's block, whose source-side projection may ride on the last tail
         for i, layer in enumerate(self.proc):
             extra = last_layer_kwargs if (last_layer_kwargs and i == len(self.proc) - 1) else {}
             if chain is not None:  # a block's chain launch may compute the NEXT block's LayerNorm + projections (layers/block.py)
-                chain["next_block"] = self.proc[i + 1] if i + 1 < len(self.proc) else None
+                chain["next_block"] = self.proc[i + 1] if i + 1 < len(self.proc) else after_last
             data = layer(*data, *args, **kwargs, **extra)
         return data
 

@@ -26,6 +26,8 @@ from ..utils.tensors import version
 
 _FUSED_INPUT = os.environ.get("ANEMOI_FUSED_INPUT", "1") == "1"  # developer switch: 0 = permute-copy + cat in torch
 _PAD64 = os.environ.get("ANEMOI_PAD64", "1") == "1"  # developer switch: 0 = pad the input width to a multiple of 8 only
+# the decoder block's k|v projection of the hidden rows at the end of the last processor block's chain launch (ANEMOI_TAIL_KV=0: LayerNorm launch + GEMM)
+_TAIL_KV = os.environ.get("ANEMOI_TAIL_KV", "1") != "0"
 from ..utils.config import DotDict, instantiate
 
 _REF_PREFIX = "anemoi.models.layers."
@@ -293,9 +295,19 @@ class AnemoiModelEncProcDec(nn.Module):
         ea, ei, es = self.processor_graph_provider.get_edges(batch_size=batch_size, model_comm_group=model_comm_group)
         # the latent skip (:295-296) rides in the last processor block's last GEMM (GraphTransformer processor), else one add
         fuse_skip = self.latent_skip and isinstance(self.processor, GraphTransformerProcessor)
+        # (one dataset, GraphTransformer decoder, unsharded inference: the decoder block's layer_norm_attention_src + k|v projection of the hidden
+        # rows ride at the end of the last processor block's chain launch, behind the latent skip)
+        from ..layers.mapper import GraphTransformerBackwardMapper
+
+        dec0 = self.decoder[names[0]]
+        hand_kv = (_TAIL_KV and fuse_skip and len(names) == 1 and model_comm_group is None and "ln_chain" in chain_kw and isinstance(dec0, GraphTransformerBackwardMapper)
+                   and not torch.is_grad_enabled())
         x_latent_proc = self.processor(x=x_latent, batch_size=batch_size, shard_info=GraphShardInfo(nodes=shard_sizes_hidden, edges=es),
                                        edge_attr=ea, edge_index=ei, model_comm_group=model_comm_group, **chain_kw,
-                                       **({"latent_skip": x_latent} if fuse_skip else {}))
+                                       **({"latent_skip": x_latent} if fuse_skip else {}), **({"after_last_block": dec0.proc} if hand_kv else {}))
+        src_proj = None
+        if hand_kv and chain_kw["ln_chain"].get("qkvs_x") is x_latent_proc:
+            src_proj = (x_latent_proc, chain_kw["ln_chain"]["qkvs"])
         if self.latent_skip and not fuse_skip:
             if (x_latent_proc.is_cuda and x_latent_proc.dim() == 2 and x_latent_proc.shape == x_latent.shape and x_latent_proc.dtype == x_latent.dtype
                     and not (torch.is_grad_enabled() and (x_latent_proc.requires_grad or x_latent.requires_grad))):
@@ -309,7 +321,8 @@ class AnemoiModelEncProcDec(nn.Module):
             ea, ei, es = self.decoder_graph_provider[ds].get_edges(batch_size=batch_size, model_comm_group=model_comm_group)
             info = BipartiteGraphShardInfo(src_nodes=shard_sizes_hidden, dst_nodes=data_shards[ds], edges=es)
             x_out = self.decoder[ds]((x_latent_proc, data_latents[ds]), batch_size=batch_size, shard_info=info, edge_attr=ea,
-                                     edge_index=ei, model_comm_group=model_comm_group, keep_x_dst_sharded=in_out_sharded[ds])
+                                     edge_index=ei, model_comm_group=model_comm_group, keep_x_dst_sharded=in_out_sharded[ds],
+                                     **({"src_proj": src_proj} if src_proj is not None else {}))
             x_skip, raw, norm_in, norm_out = skips[ds]
             out[ds] = self._assemble_output(x_out, x_skip, batch_size, ensemble_size, x[ds].dtype, ds, norm=norm_in, skip_is_raw=raw,
                                             denorm=norm_out)

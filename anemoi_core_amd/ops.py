@@ -828,8 +828,8 @@ def gt_layer_chain2(attn: Tensor, x_res: Tensor, wp: Tensor, w1g: Tensor, w2: Te
         raise NotImplementedError(f"gt_layer_chain2: hidden={hidden} + q_out={q_out_features} exceed the kernel's LDS vector region")
     if tuple(x_res.shape) != (N, D) or (extra is not None and tuple(extra.shape) != (N, D)):
         raise ValueError("gt_layer_chain2: attn, x_res and extra must have the same [N, channels] shape")
-    if extra is not None and q_out_features:
-        raise ValueError("gt_layer_chain2: a trailing projection and a second residual exclude each other")
+    if extra is not None and not want_x_out:
+        raise ValueError("gt_layer_chain2: a second residual needs x_out")
     for name, w, numel in (("wp", wp, D * D), ("w1g", w1g, hidden * D), ("w2", w2, D * hidden), ("wqg", wqg, q_out_features * D)):
         if w is None and numel == 0:
             continue

@@ -383,9 +383,12 @@ int anemoi_peer_exchange_rows(const void* src, int64_t ld_src_bytes, const int32
  *     w1 = fragment-major image of W_1 diag(gamma_1) (rounded to the model dtype),   d1 = W_1 beta_1 + b_1
  *     wq = fragment-major image of W_q diag(gamma_q),                                 dq = W_q beta_q + b_q
  * and every bias enters as the START value of its GEMM's accumulators: vec = [b_p (512) | d1 (hidden) | b_2 (512) | dq (q_out_features)]
- * in the model dtype, kept in LDS (2*512 + hidden + q_out_features <= 6144, else ANEMOI_E_UNSUPPORTED).  extra and a trailing
- * projection exclude each other (the reference adds the latent skip behind the LAST block).  channels must be 512; hidden and
- * q_out_features multiples of 512; 16-bit dtypes; all row pointers 16-byte aligned, all leading dimensions multiples of 8 elements.
+ * in the model dtype, kept in LDS (2*512 + hidden + q_out_features <= 6144, else ANEMOI_E_UNSUPPORTED).  With BOTH extra and a trailing
+ * projection the projection reads LayerNorm(x2 + extra): the decoder's layer_norm_attention_src + [lin_key; lin_value] behind the last processor
+ * block and the latent skip (encoder_processor_decoder.py:295-296, layers/block.py:981-984).  q_out_features: a multiple of 512, or 128 / 256 /
+ * 384 (a NARROW trailing projection: the decoder's node_data_extractor, layers/mapper.py:688-704, zero-padded to a multiple of 128 rows); x_out
+ * may be NULL when there is a trailing projection and no extra (x2 is then not written).  channels must be 512; hidden a multiple of 512;
+ * 16-bit dtypes; all row pointers 16-byte aligned, all leading dimensions multiples of 8 elements.
  * rows_per_tile = 0 lets the
  * library choose (anemoi_gt_chain_rows_per_tile: 48). */
 typedef struct anemoi_gt_chain2_args {

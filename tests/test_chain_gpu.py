@@ -388,7 +388,7 @@ def test_chain2_vs_fp32_restatement(dtype, N, rows_per_tile):
     assert torch.equal(x2, x2b) and torch.equal(q, qb)  # deterministic
 
 
-@pytest.mark.parametrize("variant", ["no_q", "extra", "no_beta", "q1024", "q512", "q1536", "hidden1024", "hidden512", "hidden1536"])
+@pytest.mark.parametrize("variant", ["no_q", "extra", "no_beta", "q1024", "q512", "q1536", "hidden1024", "hidden512", "hidden1536", "extra_q1024", "extra_q2048"])
 def test_chain2_variants(variant):
     """no trailing projection, the latent skip as a second residual, LayerNorms without bias, odd / single chunk counts of the trailing
     projection (group B has one chunk fewer, or none) and of the hidden width (x2 lands in the other h buffer)."""
@@ -401,12 +401,13 @@ def test_chain2_variants(variant):
     old = me.HD
     me.HD = hd
     try:
-        p = _params(gen, dtype, q_out={"no_q": 0, "extra": 0, "q1024": 1024, "q512": 512, "q1536": 1536}.get(variant, 2048), beta=variant != "no_beta")
+        p = _params(gen, dtype, q_out={"no_q": 0, "extra": 0, "q1024": 1024, "q512": 512, "q1536": 1536, "extra_q1024": 1024}.get(variant, 2048), beta=variant != "no_beta")
     finally:
         me.HD = old
     attn = torch.randn(N, D, generator=gen).to(dtype)
     x = torch.randn(N, D, generator=gen).to(dtype)
-    extra = (3.0 * torch.randn(N, D, generator=gen)).to(dtype) if variant == "extra" else None
+    # (extra + a trailing projection: the decoder's k | v behind the last processor block - the projection reads LayerNorm(x2 + extra))
+    extra = (3.0 * torch.randn(N, D, generator=gen)).to(dtype) if variant.startswith("extra") else None
     res = _run_chain2(ops, attn, x, p, extra=extra)
     ref2, refq = _reference(attn, x, p, dtype, extra=extra)
     if p["wq"] is None:
