@@ -295,42 +295,54 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, ANEMOI_ATTN_MIN_WAVES) void gt
       }
 #pragma unroll
       for (int st = 0; st < PF; ++st) fetch(st, kb[st], vb[st], fb[st]);
+      // Edges in GROUPS of PF inside ONE basic block: the ring slots always hold loaded rows (refills past the end re-read the last edge), an edge
+      // beyond the chunk gets the score -inf (weight 0).  The group's scores are formed first, the running max is checked ONCE per group, and
+      // the scheduler can interleave the PF independent dependency chains (the per-edge form below is one basic block per edge: dependent
+      // packed FMAs back to back, a wait state each, and a scalar bound check + two branches per edge).  The hidden mesh's in-degrees are
+      // multiples of 6 and the decoder's exactly 3: no padded edge there.  Same-box A/B against the per-edge loop (round 5's, in
+      // csrc/experiments/gt_attention_r05_variants.hip): O96 -0.2 %, res 6 -0.2 %, N320 -0.6 % per forward; 88 instead of 94 VGPRs; per edge 60 instead of
+      // 68 issue slots (2 s_nop instead of 8, 0.7 branches instead of 3) - profiles/r06_attention_grouped_ab.txt.
       for (int j0 = 0; j0 < n; j0 += PF) {
+        float dots[PF];
 #pragma unroll
         for (int st = 0; st < PF; ++st) {
-          const int j = j0 + st;
-          if (j < n) {
-            float dot = dot_rows<T, VEC>(q_raw, kb[st]);
-            if constexpr (FE_PAD % 2 == 0) {  // feature pairs on packed FMAs (scalar-register pairs as loaded)
-              f32x2 d2[2] = {{dot, 0.f}, {0.f, 0.f}};  // two chains: dependent packed FMAs back to back cost a wait state each
+          float dot = dot_rows<T, VEC>(q_raw, kb[st]);
+          if constexpr (FE_PAD % 2 == 0) {
+            f32x2 d2[2] = {{dot, 0.f}, {0.f, 0.f}};
 #pragma unroll
-              for (int f = 0; f < FE_PAD; f += 2)
-                d2[(f / 2) & 1] = __builtin_elementwise_fma(f32x2{fb[st][f], fb[st][f + 1]}, f32x2{qw[f], qw[f + 1]}, d2[(f / 2) & 1]);
-              d2[0] += d2[1];
-              dot = d2[0][0] + d2[0][1];
-            } else {
+            for (int f = 0; f < FE_PAD; f += 2)
+              d2[(f / 2) & 1] = __builtin_elementwise_fma(f32x2{fb[st][f], fb[st][f + 1]}, f32x2{qw[f], qw[f + 1]}, d2[(f / 2) & 1]);
+            d2[0] += d2[1];
+            dot = d2[0][0] + d2[0][1];
+          } else {
 #pragma unroll
-              for (int f = 0; f < FE_PAD; ++f) dot = fmaf(fb[st][f], qw[f], dot);
-            }
-            dot = group_sum<LPH>(dot);
-            if (__builtin_amdgcn_ballot_w64(dot > m + thr) != 0) {  // always on the first edge, rare afterwards
-              const float m_new = fmaxf(m, dot);
-              const float corr = __builtin_amdgcn_exp2f((m - m_new) * sl2e);  // 2^(-inf) = 0 on the first edge
-              l *= corr;
-#pragma unroll
-              for (int jj = 0; jj < VEC; ++jj) acc[jj] *= corr;
-#pragma unroll
-              for (int f = 0; f < FE_PAD; ++f) sf[f] *= corr;
-              m = m_new;
-            }
-            const float p = __builtin_amdgcn_exp2f((dot - m) * sl2e);
-            l += p;
-#pragma unroll
-            for (int jj = 0; jj < VEC; ++jj) acc[jj] = fmaf(p, to_float(vb[st].v[jj]), acc[jj]);
-#pragma unroll
-            for (int f = 0; f < FE_PAD; ++f) sf[f] = fmaf(p, fb[st][f], sf[f]);
-            fetch(j + PF, kb[st], vb[st], fb[st]);
+            for (int f = 0; f < FE_PAD; ++f) dot = fmaf(fb[st][f], qw[f], dot);
           }
+          dot = group_sum<LPH>(dot);
+          dots[st] = (j0 + st < n) ? dot : -INFINITY;  // (wave-uniform condition)
+        }
+        float mx = dots[0];
+#pragma unroll
+        for (int st = 1; st < PF; ++st) mx = fmaxf(mx, dots[st]);
+        if (__builtin_amdgcn_ballot_w64(mx > m + thr) != 0) {  // always in the first group, rare afterwards
+          const float m_new = fmaxf(m, mx);
+          const float corr = __builtin_amdgcn_exp2f((m - m_new) * sl2e);  // 2^(-inf) = 0 in the first group
+          l *= corr;
+#pragma unroll
+          for (int jj = 0; jj < VEC; ++jj) acc[jj] *= corr;
+#pragma unroll
+          for (int f = 0; f < FE_PAD; ++f) sf[f] *= corr;
+          m = m_new;
+        }
+#pragma unroll
+        for (int st = 0; st < PF; ++st) {
+          const float p = __builtin_amdgcn_exp2f((dots[st] - m) * sl2e);  // 2^(-inf) = 0 for an edge beyond the chunk
+          l += p;
+#pragma unroll
+          for (int jj = 0; jj < VEC; ++jj) acc[jj] = fmaf(p, to_float(vb[st].v[jj]), acc[jj]);
+#pragma unroll
+          for (int f = 0; f < FE_PAD; ++f) sf[f] = fmaf(p, fb[st][f], sf[f]);
+          fetch(j0 + st + PF, kb[st], vb[st], fb[st]);
         }
       }
     }

@@ -596,10 +596,18 @@ def rccl_block(model, group, world, graph):
         if plan is not None:
             es = next(model.parameters()).element_size()
             D = model.num_channels
+            # the row that crosses the wire: the LayerNorm'd node row (D values, the reference's payload) - or, where a rank's block tails run on
+            # the cluster chain (a share below the chain's row gate, inference), the owner's k|v row (2 D values) for every layer but the first
+            import anemoi_core_amd.layers.block as B
+
+            kv_rows = (B._CLUSTER_CHAIN and B._CLUSTER_HALO and B._LAYER_CHAIN and 0 < int(plan.info.num_local_nodes) < B._LAYER_CHAIN_MIN_ROWS
+                       and D == 512 and es == 2)
+            width = 2 * D if kv_rows else D
             out.update({"halo_rows_recv": int(sum(plan.recv_counts)), "halo_rows_send": int(sum(plan.send_counts)),
                         "halo_recv_rows_per_peer": [int(c) for c in plan.recv_counts],
-                        "halo_bytes_recv_per_layer": int(sum(plan.recv_counts)) * D * es,
-                        "halo_bytes_per_peer_per_layer_max": int(max(plan.recv_counts)) * D * es if plan.recv_counts else 0,
+                        "halo_row_payload": "k|v rows of the owners (2 x channels)" if kv_rows else "LayerNorm'd node rows (channels)",
+                        "halo_bytes_recv_per_layer": int(sum(plan.recv_counts)) * width * es,
+                        "halo_bytes_per_peer_per_layer_max": int(max(plan.recv_counts)) * width * es if plan.recv_counts else 0,
                         "local_rows": int(plan.info.num_local_nodes), "layers": len(model.processor.proc)})
     except Exception as e:  # noqa: BLE001
         out["plan_error"] = f"{type(e).__name__}: {e}"
