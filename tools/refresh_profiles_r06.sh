@@ -11,5 +11,6 @@ python tools/rank_floor.py --world 8 --hidden-res 6 --wire ipc 2>/dev/null | tai
 for w in 4 8; do ANEMOI_CLUSTER_CHAIN=0 python tools/rank_floor.py --world $w --hidden-res 5 --wire ipc 2>/dev/null | tail -1 > $OUT/rank_floor_w${w}_r5_cluster_off.json; done
 ANEMOI_BENCH_TRANSPORT=ipc timeout 600 python bench.py --gpus 8 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing > $OUT/bench_8ranks_one_gpu_ipc.json 2> $OUT/bench_8ranks_one_gpu_ipc.err
 bash tools/r06_pmc_sq.sh r06 o96 > /dev/null 2>&1
+bash tools/r06_pmc_sq.sh r06 o96 hres4 --hidden-res 4 > /dev/null 2>&1
 python tools/rowchain_time.py > $OUT/rowchain_time.txt 2>&1
 ls $OUT | head -60
