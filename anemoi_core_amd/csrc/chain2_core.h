@@ -237,7 +237,8 @@ __device__ __forceinline__ void init_acc(f32x4 (&acc)[3][8], const unsigned char
 // The wave's 48 x 128 block rounded to the model dtype into the panel buffer `dst` (its own columns); acc keeps the ROUNDED values.
 // STATS: per-wave (mean, M2) of every row over the wave's 128 columns -> red[row][wq].
 // ADD: first + vec[col0 + column] + the values the panel buffer `dst` holds at the same positions (the projection's bias and skip rows).
-template <typename T, bool STATS, bool ADD = false>
+// STORE = false: the rounded values stay in acc only (dst unused) - the pipelined row chain keeps a panel in registers across a barrier.
+template <typename T, bool STATS, bool ADD = false, bool STORE = true>
 __device__ __forceinline__ void round_rows(f32x4 (&acc)[3][8], unsigned char* dst, float* red, int lane, int wq, const unsigned char* vec = nullptr, int col0 = 0) {
   const Lane2 lc = lane2(lane, wq);
 #pragma unroll
@@ -268,7 +269,7 @@ __device__ __forceinline__ void round_rows(f32x4 (&acc)[3][8], unsigned char* ds
         for (int k = 0; k < 4; ++k) o[k] += b[k] + r[k];
       }
       const u32x2 pk = pack4<T>(o);
-      *reinterpret_cast<u32x2*>(drow + lc.coff[ni]) = pk;
+      if constexpr (STORE) *reinterpret_cast<u32x2*>(drow + lc.coff[ni]) = pk;
       if (STATS) {
         unpack4<T>(pk, o);
         acc[mi][ni] = f32x4{o[0], o[1], o[2], o[3]};
@@ -337,6 +338,26 @@ __device__ __forceinline__ void normalise_rows(const f32x4 (&acc)[3][8], const f
       for (int r = 0; r < 4; ++r) o[r] = fmaf(acc[mi][ni][r], rstd, nm);
       *reinterpret_cast<u32x2*>(drow + lc.coff[ni]) = pack4<T>(o);
     }
+  }
+}
+
+// The same in REGISTERS: acc <- (acc - mean) rstd, unrounded (a round_rows<T, false> writes - and rounds - it later)
+template <typename T>
+__device__ __forceinline__ void normalise_regs(f32x4 (&acc)[3][8], const float* red, float eps, int lane, int wq) {
+  const Lane2 lc = lane2(lane, wq);
+#pragma unroll
+  for (int mi = 0; mi < 3; ++mi) {
+    const f32x4* pr = reinterpret_cast<const f32x4*>(red + (mi * 16 + lc.x) * 8);
+    const f32x4 p0 = pr[0], p1 = pr[1];
+    const float mu = ((p0[0] + p0[2]) + (p1[0] + p1[2])) * 0.25f;
+    const float d0 = p0[0] - mu, d1 = p0[2] - mu, d2 = p1[0] - mu, d3 = p1[2] - mu;
+    const float m2 = fmaf(128.0f, (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3), (p0[1] + p0[3]) + (p1[1] + p1[3]));
+    const float rstd = rsqrtf(m2 * (1.0f / (float)kCh) + eps);
+    const float nm = -mu * rstd;
+#pragma unroll
+    for (int ni = 0; ni < 8; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[mi][ni][r] = fmaf(acc[mi][ni][r], rstd, nm);
   }
 }
 

@@ -182,6 +182,173 @@ __global__ __launch_bounds__(512, 1) void gt_rowchain_kernel(RowChainArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- several panel rounds: pipelined
+// With more panels than CUs a workgroup walks a LIST of panels, and the single-panel schedule above spends ~21 us per round of which only ~12 are the
+// weight stream (1.2 MB per panel through the CU's L1 path).  Here the two wave groups work on DIFFERENT panels: group A (waves 0-3, 128 columns each)
+// computes y = x W_e^T + b_e, its statistics and LayerNorm for panel s while group B (waves 4-7) runs the projection chunks of panel s - 1:
+//
+//     phase 1   A: LN(y)(s-1), parked in its accumulators since the last step -> bufN; the rows of x(s), requested a step ago -> bufX
+//     phase 2   A: request x(s+1); acc = b_e; GEMM on bufX; rounded y in registers + row statistics     B: chunk 0 of panel s-1 on bufN -> staged -> global
+//     phase 3   A: y -> global (staged through bufX, if wanted); LN(y) in registers                    B: chunks 1 .. of panel s-1
+//
+// one s_barrier behind each phase (both groups: the hardware barrier counts all eight waves), n + 1 steps for n panels.  LDS: bufX, bufN, group B's
+// staging buffer (48 KB each) + the partials + the vectors.  in_features <= 256 (the parked rows of x(s+1) are 6 registers per lane).
+constexpr int kRc2Red = 3 * kBufBytes;                  // [48 rows][4 waves][2] fp32
+constexpr int kRc2Vec = kRc2Red + kPanel * 4 * 2 * 4;
+constexpr int kRowChain2Smem = kRc2Vec + kRcVecMax * 2;
+static_assert(kRowChain2Smem <= 160 * 1024, "LDS budget");
+
+struct XRowsA {  // a panel of input rows shared out among group A's 256 threads: <= 6 sixteen-byte slots each (in_features <= 256)
+  u32x4 v[6];
+  __device__ __forceinline__ void request(const void* x, int64_t ld, int k_in, int ng, int r0, int nr, int t, int es) {
+    const int spr = 16 * ng, n = kPanel * spr, kin16 = k_in >> 3;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int i = t + 256 * k;
+      if (k * 256 < n) {  // (wave-uniform)
+        const int row = min(i / spr, kPanel - 1), slot = i % spr;
+        const bool live = row < nr && slot < kin16 && i < n;
+        const unsigned char* p = reinterpret_cast<const unsigned char*>(x) + ((int64_t)(r0 + min(row, nr - 1)) * ld + min(slot, kin16 - 1) * 8) * es;
+        const u32x4 tv = stream_load(reinterpret_cast<const u32x4*>(p));
+        v[k] = live ? tv : u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+  }
+  __device__ __forceinline__ void store(unsigned char* buf, int ng, int t) {
+    const int spr = 16 * ng, n = kPanel * spr;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int i = t + 256 * k;
+      if (i < n) {
+        const int row = i / spr, slot = i % spr;
+        *reinterpret_cast<u32x4*>(buf + row * kRowBytes + ((slot ^ (row & 15)) << 4)) = v[k];
+      }
+    }
+  }
+};
+
+struct PipeCtx {
+  int lane, wq, tid;
+  uint32_t loff;
+  int b0, grid, n;  // this workgroup's panels: b0, b0 + grid, ... (n of them)
+};
+__device__ __forceinline__ void pipe_rows(const RowChainArgs& a, const PipeCtx& c, int s, int& r0, int& nr) {
+  r0 = (c.b0 + s * c.grid) * a.rows_per_tile;
+  nr = min(a.rows_per_tile, a.n_rows - r0);
+}
+
+// Both roles execute the SAME barriers: one behind the prologue, three per step (behind phases 1, 2, 3), n + 1 steps.
+template <typename T>
+__device__ __forceinline__ void pipe_role_a(const RowChainArgs& a, const PipeCtx& c, unsigned char* smem) {
+  unsigned char* const bufX = smem;
+  unsigned char* const bufN = smem + kBufBytes;
+  float* const red = reinterpret_cast<float*>(smem + kRc2Red);
+  const unsigned char* const vec = smem + kRc2Vec;
+  const int lane = c.lane, wq = __builtin_amdgcn_readfirstlane(c.wq), ng = a.ng, n = c.n;
+  const int64_t se = (int64_t)ng * 16384;  // one 64-column slab of the embedding image
+  const char* const wes = a.we + (int64_t)(2 * wq) * se;
+  frag8 ring[2][8];
+  f32x4 acc[3][8];
+  XRowsA xr;
+  {
+    int r0, nr;
+    pipe_rows(a, c, 0, r0, nr);
+    xr.request(a.x, a.ld_x, a.k_in, ng, r0, nr, c.tid, (int)sizeof(T));
+    ring_prologue(ring, wes, se, c.loff);
+    xr.store(bufX, ng, c.tid);
+    lds_barrier();
+  }
+  for (int s = 0; s <= n; ++s) {
+    // phase 1: LN(y)(s-1), parked in the accumulators -> bufN (rounded here); the rows of x(s) -> bufX
+    if (s >= 1) {
+      round_rows<T, false>(acc, bufN, nullptr, lane, wq);
+      if (s < n) xr.store(bufX, ng, c.tid);
+    }
+    lds_barrier();
+    // phase 2: y = x W_e^T + b_e, rounded in registers, per-wave row statistics; x(s+1) requested
+    if (s < n) {
+      if (s + 1 < n) {
+        int rn, nrn;
+        pipe_rows(a, c, s + 1, rn, nrn);
+        xr.request(a.x, a.ld_x, a.k_in, ng, rn, nrn, c.tid, (int)sizeof(T));
+      }
+      init_acc<T, false>(acc, vec, 0, nullptr, lane, wq);
+      gemm128<T>(bufX, lane, ring, wes, se, wes, se, c.loff, acc, 2 * ng);
+      round_rows<T, true, false, false>(acc, nullptr, red, lane, wq);
+    }
+    lds_barrier();
+    // phase 3: y -> global (staged through bufX: every wave of the group is behind its last read of the x rows); LN(y) in registers
+    if (s < n) {
+      if (a.xout != nullptr) {
+        int r0, nr;
+        pipe_rows(a, c, s, r0, nr);
+        round_rows<T, false>(acc, bufX, nullptr, lane, wq);
+        store_staged<T>(bufX, (T*)a.xout + (int64_t)r0 * a.ld_out, a.ld_out, nr, lane, wq);
+      }
+      normalise_regs<T>(acc, red, a.eps, lane, wq);
+    }
+    lds_barrier();
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void pipe_role_b(const RowChainArgs& a, const PipeCtx& c, unsigned char* smem) {
+  unsigned char* const bufN = smem + kBufBytes;
+  unsigned char* const bufS = smem + 2 * kBufBytes;
+  const unsigned char* const vec = smem + kRc2Vec;
+  const int lane = c.lane, wq = __builtin_amdgcn_readfirstlane(c.wq), qc = a.qc, n = c.n;
+  auto wqc = [&](int k) { return a.wq + (int64_t)(8 * k + 2 * wq) * kSlab; };
+  frag8 ring[2][8];
+  f32x4 acc[3][8];
+  ring_prologue(ring, wqc(0), kSlab, c.loff);
+  lds_barrier();
+  for (int s = 0; s <= n; ++s) {
+    int rp, nrp;
+    pipe_rows(a, c, s - 1, rp, nrp);
+    lds_barrier();  // phase 1 is group A's
+    // phase 2: chunk 0 of the projection of panel s - 1
+    if (s >= 1) {
+      init_acc<T, false>(acc, vec, 512, nullptr, lane, wq);
+      gemm128<T>(bufN, lane, ring, wqc(0), kSlab, qc > 1 ? wqc(1) : wqc(0), kSlab, c.loff, acc);
+      round_rows<T, false>(acc, bufS, nullptr, lane, wq);
+      store_staged<T>(bufS, (T*)a.qout + (int64_t)rp * a.ld_q, a.ld_q, nrp, lane, wq);
+    }
+    lds_barrier();
+    // phase 3: its other chunks
+    if (s >= 1) {
+      for (int k = 1; k < qc; ++k) {
+        init_acc<T, false>(acc, vec, 512 + 512 * k, nullptr, lane, wq);
+        gemm128<T>(bufN, lane, ring, wqc(k), kSlab, k + 1 < qc ? wqc(k + 1) : wqc(0), kSlab, c.loff, acc);
+        round_rows<T, false>(acc, bufS, nullptr, lane, wq);
+        store_staged<T>(bufS, (T*)a.qout + (int64_t)rp * a.ld_q + k * kCh, a.ld_q, nrp, lane, wq);
+      }
+    }
+    lds_barrier();
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(512, 1) void gt_rowchain_pipe_kernel(RowChainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  PipeCtx c;
+  c.tid = tid & 255;
+  c.lane = tid & 63;
+  const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  c.wq = w8 & 3;
+  c.loff = c.lane * 16;
+  c.b0 = (int)blockIdx.x;
+  c.grid = (int)gridDim.x;
+  if (c.b0 >= a.n_tiles) return;
+  c.n = (a.n_tiles - c.b0 + c.grid - 1) / c.grid;
+  {  // the per-column vectors -> LDS (visible behind the prologue's barrier)
+    const int n16 = (512 + 512 * a.qc) / 8;  // <= 320
+    if (tid < n16) reinterpret_cast<u32x4*>(smem + kRc2Vec)[tid] = reinterpret_cast<const u32x4*>(a.vec)[tid];
+  }
+  if (w8 < 4) pipe_role_a<T>(a, c, smem);
+  else pipe_role_b<T>(a, c, smem);
+}
+
 template <typename T>
 static int launch_rowchain(const RowChainArgs& a, hipStream_t st) {
   static PerDeviceOnce once;
@@ -191,6 +358,12 @@ static int launch_rowchain(const RowChainArgs& a, hipStream_t st) {
   if (a.n_tiles > 256) {
     const int rounds = (a.n_tiles + 255) / 256;
     grid = (a.n_tiles + rounds - 1) / rounds;
+  }
+  if (a.n_tiles > grid && a.k_in <= 256) {  // several rounds of panels: the two wave groups on different panels
+    static PerDeviceOnce once2;
+    once2.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gt_rowchain_pipe_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, kRowChain2Smem); });
+    hipLaunchKernelGGL((gt_rowchain_pipe_kernel<T>), dim3(grid), dim3(512), kRowChain2Smem, st, a);
+    return check_launch("gt_rowchain_pipe_kernel");
   }
   hipLaunchKernelGGL((gt_rowchain_kernel<T>), dim3(grid), dim3(512), kRowChainSmem, st, a);
   return check_launch("gt_rowchain_kernel");
