@@ -46,6 +46,9 @@ _ROW_CHAIN_MIN_ROWS = int(os.environ.get("ANEMOI_ROW_CHAIN_MIN_ROWS", "4096"))
 # ~16 000 and ~260 000 rows the GEMM pair is as fast or faster (40 320 rows: 84 against 76-82 us), below (one round: 10 242 rows 23 against 27 us,
 # 5 040 rows 20 against 33) and far above (542 080 rows 864 against 1 048 us: there the 555-MB round trip of the embedded rows dominates the GEMMs) the
 # launch wins.
+# The decoder's node_data_extractor (LayerNorm + Linear(512, out)) as the narrow trailing projection of the block's chain launch (inference, block
+# tails on the row-resident chain): ANEMOI_TAIL_PROJ=0 keeps its LayerNorm launch + GEMM.
+_TAIL_PROJ = os.environ.get("ANEMOI_TAIL_PROJ", "1") != "0"
 _ROW_CHAIN_GEMM_BAND = tuple(int(v) for v in os.environ.get("ANEMOI_ROW_CHAIN_GEMM_BAND", "16384:262144").split(":"))
 
 
