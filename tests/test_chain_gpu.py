@@ -467,11 +467,12 @@ def test_chain2_without_trailing_projection_over_several_panel_rounds(N, hidden,
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("N,K,q_out,want_x", [(37, 64, 1024, True), (642, 192, 1024, False), (10242, 64, 1024, True), (40320, 192, 1024, False),
                                               (40320, 184, 1024, True), (5000, 512, 2048, True), (3000, 128, 512, True), (2049, 8, 1536, False),
-                                              (1, 320, 1024, True)])
+                                              (1, 320, 1024, True), (30011, 96, 1024, True), (13000, 64, 512, True), (20000, 200, 1536, False)])
 def test_row_chain_vs_fp32_restatement(dtype, N, K, q_out, want_x):
     """embedding -> LayerNorm -> fused projection of one mapper side in one launch against the fp32 restatement with the reference's rounding
     points (the embedded rows and the LayerNorm output in the model dtype): every row, ragged last panels, several panels per workgroup,
-    input widths that are no multiple of the 128-column K group (zero-padded image), one / two / three / four projection chunks."""
+    input widths that are no multiple of the 128-column K group (zero-padded image), one / two / three / four projection chunks; above 12 288
+    rows the pipelined kernel (two chunks: the schedule that splits the projection 3 : 1 between the wave groups; else the plain one)."""
     from anemoi_core_amd import ops
 
     gen = torch.Generator().manual_seed(N + K + q_out)
