@@ -20,7 +20,7 @@ for P in "$PA" "$PB" "$PC"; do
   timeout 280 rocprofv3 --kernel-trace --pmc $P -d /tmp/psq_$i -o psq -- python $R/bench.py --config $c "$@" --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-graph > $OUT/pmc_sq_pass$i.log 2>&1 < /dev/null
   DB=$(find /tmp/psq_$i -name "*.db" | head -1)
   if [ -n "$DB" ]; then
-    for k in gt_chain2 gt_attn_fused gt_rowchain gt_cluster linear_mfma; do python $R/tools/pmc_summary.py $DB $k >> $OUT/pmc_sq_${name}_pass$i.txt 2>&1; done
+    for k in gt_chain2 gt_attn_fused gt_rowchain gt_cluster linear_mfma gnn_edge_chain gnn_node_chain segment_sum; do python $R/tools/pmc_summary.py $DB $k >> $OUT/pmc_sq_${name}_pass$i.txt 2>&1; done
   else
     tail -5 $OUT/pmc_sq_pass$i.log
   fi
