@@ -16,6 +16,8 @@ from anemoi_core_amd import ops  # noqa: E402
 SHAPES = {
     "512": ((10242, 512, 2048), (10242, 512, 512), (10242, 2048, 512), (40320, 512, 2048), (40320, 2048, 512), (81840, 512, 512)),
     # the reference's default width (config/model/graphtransformer.yaml:1): q|k|v|self, MLP-1, MLP-2, projection of a processor layer and the mapper sides
+    # the 40 320-row mapper sides at 512 channels: LayerNorm-fold projection (k|v, q|self), the embedding, the hidden-side projection
+    "mapper": ((40320, 512, 1024), (40320, 192, 512), (40320, 128, 512), (10242, 512, 1024), (542080, 512, 1024)),
     "1024": ((10242, 1024, 4096), (10242, 4096, 1024), (10242, 1024, 1024), (40320, 1024, 2048), (40320, 1024, 4096), (40320, 4096, 1024)),
 }
 
